@@ -1,0 +1,103 @@
+"""CPU suite: the oracle (plain-C restatement of the decode behind copy_decode, reference
+src/main.rs:463-467) against the committed golden vectors, and against the machine's libzstd
+when one is present."""
+import pytest
+
+import corpus
+import oracle
+from tests import golden_util
+
+VECS = golden_util.load_manifest()
+
+
+@pytest.mark.parametrize("v", [v for v in VECS if v.ok], ids=lambda v: v.name)
+def test_oracle_golden_positive(v):
+    want = v.expected()
+    assert oracle.xxh64(want) == v.out_xxh64 and len(want) == v.out_len  # the fixture itself
+    rc, out, blocks = oracle.decode(v.comp, cap=len(want), dictionary=v.dict, want_trace=True)
+    assert rc == 0
+    assert out == want
+    assert blocks == v.blocks  # literal / sequence hashes per block (CPU twin of each GPU phase)
+    if v.dict is None:
+        assert oracle.content_size(v.comp) in (len(want), oracle.UNKNOWN_SIZE)
+
+
+@pytest.mark.parametrize("v", [v for v in VECS if not v.ok], ids=lambda v: v.name)
+def test_oracle_golden_negative(v):
+    rc, _ = oracle.decode(v.comp, cap=1 << 22)
+    assert rc == v.oracle_class and rc < 0
+
+
+def test_reference_test_payload_is_a_raw_block():
+    # bulk::compress(b"compressed data", 0) (reference tests/convert.rs:18)
+    v = next(x for x in VECS if x.name == "ref_bulk_01")
+    assert v.comp == bytes.fromhex("28b52ffd200f790000") + b"compressed data"
+    assert oracle.decode(v.comp)[1] == b"compressed data"
+
+
+def test_xxh64_known_answers():
+    assert oracle.xxh64(b"") == 0xEF46DB3751D8E999
+    assert oracle.xxh64(b"a") == 0xD24EC4F1A98C6E5B
+    assert oracle.xxh64(b"abc") == 0x44BC2CF5AD770999
+    try:
+        import xxhash
+    except ImportError:
+        return
+    for n in (1, 31, 32, 33, 100, 4097):
+        data = corpus.gen("random", 9, n, n)
+        assert oracle.xxh64(data) == xxhash.xxh64(data).intdigest()
+        assert oracle.xxh64(data, 77) == xxhash.xxh64(data, seed=77).intdigest()
+
+
+def test_dst_too_small_and_empty_input():
+    v = next(x for x in VECS if x.name == "json_4k")
+    rc, _ = oracle.decode(v.comp, cap=100)
+    assert rc == oracle.E_DSTSIZE
+    assert oracle.decode(b"", cap=16) == (0, b"")
+
+
+needs_zstd = pytest.mark.skipif(not oracle.LibZstd.available(), reason="no libzstd shared object on this machine")
+
+
+@needs_zstd
+@pytest.mark.parametrize("kind", sorted(corpus.KINDS))
+def test_oracle_vs_libzstd_levels(kind):
+    Z = oracle.LibZstd
+    for size in (0, 1, 100, 5000, 131072, 400000):
+        raw = corpus.gen(kind, 11, size % 89, size)
+        for level in (1, 3, 7, 19, -7):
+            if level == 19 and size > 140000:
+                continue
+            comp = Z.compress(raw, level=level, checksum=(size % 2 == 0))
+            rc, out = oracle.decode(comp, cap=len(raw))
+            assert rc == 0 and out == raw, (kind, size, level)
+            assert Z.decompress(comp, len(raw) + 1, stream8k=True) == raw
+
+
+@needs_zstd
+def test_oracle_accept_reject_agrees_with_libzstd_on_mutations():
+    """Every single-byte mutation of a small frame.  Hard rule: the oracle never accepts what
+    libzstd rejects, and when both accept the bytes are equal.  The oracle follows the pinned
+    libzstd 1.5.6 (Cargo.lock:2371-2396), which is stricter than libzstd < 1.5.4 about bitstreams
+    that are not consumed exactly; with such an old library on the machine a few
+    mutations are "oracle rejects, old libzstd accepts" (checked: 1.5.7 rejects them too)."""
+    Z = oracle.LibZstd
+    old_lib = tuple(int(x) for x in Z.version().split(".")[:3]) < (1, 5, 4)
+    raw = corpus.gen("json", 12, 1, 700)
+    comp = bytearray(Z.compress(raw, 3, True))
+    hard, stricter = [], []
+    for pos in range(len(comp)):
+        for flip in (0x01, 0x80, 0xFF):
+            m = bytearray(comp)
+            m[pos] ^= flip
+            ref = Z.decompress(bytes(m), 1 << 16, stream8k=True)
+            rc, out = oracle.decode(bytes(m), cap=1 << 16)
+            if rc == 0 and (isinstance(ref, int) or out != ref):
+                hard.append((pos, flip, rc))
+            elif rc != 0 and not isinstance(ref, int):
+                stricter.append((pos, flip, rc))
+    assert not hard, hard[:10]
+    if old_lib:
+        assert len(stricter) <= 8, stricter[:10]
+    else:
+        assert not stricter, stricter[:10]
