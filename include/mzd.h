@@ -1,0 +1,146 @@
+/*
+ * include/mzd.h -- C ABI of the MI355X zstd frame decoder ("mzd").
+ *
+ * This is the drop-in boundary for the ONE codec call on fuse-zstd's read side:
+ *
+ *     zstd::stream::copy_decode(source_file, target_file).map_err(|_| libc::EFAULT)?;
+ *                                            reference src/main.rs:463-467 (inside
+ *                                            ZstdFS::open_wrapper, :451-493, reached from
+ *                                            <ZstdFS as Filesystem>::open, :980-992)
+ *
+ * copy_decode decodes EVERY concatenated frame of the file, skips skippable frames,
+ * verifies the content checksum when present and fails on any malformed input; the caller
+ * maps every failure to EFAULT (:467).  `Filesystem::read` (:931-956 -> read_wrapper
+ * :495-513) only slices the decoded bytes, so the decoded buffer is all it needs.
+ *
+ * Everything below is plain pointers and sizes (no torch / HIP types).  The decode itself
+ * runs in hand-written HIP kernels on gfx950; there is NO CPU fallback: every decode entry
+ * point returns MZD_E_DEVICE when no GPU / kernel image is usable.
+ *
+ * INTEGRATION.md shows the Rust `extern "C"` block + the 6-line patch to open_wrapper.
+ */
+#ifndef MZD_H
+#define MZD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (0 = ok, negative = error class).  The open() caller maps any
+ *      non-zero to EFAULT exactly as reference src/main.rs:467 does. ---- */
+#define MZD_OK 0
+#define MZD_E_CORRUPT (-1)     /* malformed frame / block / entropy section */
+#define MZD_E_TRUNCATED (-2)   /* input ends inside a frame */
+#define MZD_E_CHECKSUM (-3)    /* XXH64 content checksum mismatch */
+#define MZD_E_DSTSIZE (-4)     /* destination capacity too small */
+#define MZD_E_UNSUPPORTED (-5) /* reserved bit set, window > 128 MiB (streaming limit of copy_decode) */
+#define MZD_E_DEVICE (-6)      /* no GPU, HIP error, library not initialised */
+#define MZD_E_BADMAGIC (-7)    /* data that is neither a zstd nor a skippable frame */
+#define MZD_E_DICT (-8)        /* frame needs a dictionary that is missing / different / corrupt */
+#define MZD_E_PARAM (-9)       /* bad argument */
+
+/* Device-resident inputs must be readable for MZD_SRC_PADDING bytes past src_len (the
+ * kernels read the bitstreams with unaligned 8-byte loads).  Host-pointer entry points
+ * stage the input themselves and need no padding from the caller. */
+#define MZD_SRC_PADDING 16
+
+#define MZD_CONTENTSIZE_UNKNOWN (UINT64_MAX)
+#define MZD_CONTENTSIZE_ERROR (UINT64_MAX - 1)
+
+/* One file (= what one open() decodes).  Replaces the (source, destination) pair of
+ * copy_decode, reference src/main.rs:463-466. */
+typedef struct mzd_job {
+    const uint8_t* src; /* whole .zst file: all frames */
+    size_t src_len;
+    uint8_t* dst;       /* decoded bytes */
+    size_t dst_cap;
+    size_t out_len;     /* OUT: decoded length (what open_wrapper stores in user.real_size, :473-482) */
+    int32_t status;     /* OUT: MZD_OK or MZD_E_* */
+    uint32_t dict_id;   /* 0 = none, else a handle from mzd_load_dict */
+} mzd_job;
+
+/* Initialise `n` devices (HIP ordinals); ids == NULL / n == 0 -> device 0 only.
+ * Allocates per-device scratch (literal + sequence buffers for every resident workgroup).
+ * Calling it again re-initialises.  Returns MZD_OK or MZD_E_DEVICE. */
+int mzd_init(const int* device_ids, int n);
+void mzd_shutdown(void);
+int mzd_device_count(void); /* devices initialised by mzd_init (0 before) */
+
+/* Sum of Frame_Content_Size over all frames of a file (host-side header walk, no GPU):
+ * the analogue of ZSTD_getFrameContentSize the caller uses to size `dst`.
+ * MZD_CONTENTSIZE_UNKNOWN if some frame omits the field, MZD_CONTENTSIZE_ERROR if the
+ * headers are malformed.  Frames written by the reference always carry it (src/main.rs:785-788). */
+uint64_t mzd_content_size(const uint8_t* src, size_t n);
+
+/* copy_decode on host buffers: stages src to the GPU, decodes, copies the result back.
+ * Single call site shape of reference src/main.rs:463.  Thread-compatible with the
+ * single-threaded fuser loop (reference DESIGN.md:5-7); also safe from several threads. */
+int mzd_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len);
+
+/* Many files per call, HOST pointers.  Jobs are dealt round-robin over the initialised
+ * devices (job i -> device i mod N; no collective: files are independent).  Per-job
+ * status/out_len are filled in.  Returns MZD_OK if the batch ran (inspect job status),
+ * MZD_E_DEVICE / MZD_E_PARAM otherwise. */
+int mzd_decode_batch(mzd_job* jobs, size_t njobs);
+
+/* Many files per call, DEVICE pointers on `device` (index into mzd_init's list): src/dst
+ * already in HBM, nothing crosses PCIe except the job table.  `stream` is a hipStream_t
+ * (NULL = the library's own stream).  Blocks until the results are back. */
+int mzd_decode_batch_device(int device, mzd_job* jobs, size_t njobs, void* stream);
+
+/* Asynchronous form for measurement loops: the job table stays on the device.
+ * prepare uploads the table once; launch enqueues one pass on `stream` and returns at
+ * once; collect waits for the stream and copies status/out_len back into `jobs`. */
+typedef struct mzd_batch mzd_batch;
+int mzd_batch_prepare(int device, const mzd_job* jobs, size_t njobs, mzd_batch** out);
+int mzd_batch_launch(mzd_batch* b, void* stream);
+int mzd_batch_collect(mzd_batch* b, mzd_job* jobs, void* stream);
+void mzd_batch_free(mzd_batch* b);
+
+/* Dictionaries (ZSTD_dct_auto: formatted when it starts with 0xEC30A437, else raw
+ * content).  Uploaded once to every initialised device.  The reference itself cannot open
+ * dictionary frames (copy_decode has none); this serves BASELINE config 5. */
+int mzd_load_dict(const uint8_t* dict, size_t n, uint32_t* dict_id);
+
+/* Test hook: literal buffer and sequence triples {ll, ml, off, 0} (u32 x 4) of the LAST
+ * compressed block decoded by the workgroup that ran job 0 of the previous call on
+ * `device`, for phase-by-phase comparison with the oracle's trace. */
+int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit,
+                         uint32_t* seq4, size_t seq_cap, size_t* n_seq);
+
+/* Milliseconds the decode kernel of the last launch on `device` took (hipEvents on the
+ * launch stream).  Valid after the launch has been collected. */
+int mzd_last_kernel_ms(int device, float* ms);
+
+const char* mzd_strerror(int code);
+const char* mzd_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Host mirror of the caller's side of the path: the file-handle table that owns the
+ * decoded bytes (reference src/file.rs:10-135 OpenedFiles/FileHandler) and the two
+ * operations on it (open_wrapper src/main.rs:451-493, read_wrapper :495-513,
+ * release_wrapper :595-599).  The decoded buffer plays the role of the tempfile.
+ * Return values are the reference's: a file handle / byte count, or a NEGATIVE errno
+ * (EFAULT for any decode failure :467, ENOENT for an unknown handle :505, EBUSY :490).
+ * ------------------------------------------------------------------------------------ */
+typedef struct mzd_fs mzd_fs;
+mzd_fs* mzd_fs_new(void);
+void mzd_fs_free(mzd_fs* fs);
+/* open: `duplicate` an existing handle of `ino` without decoding (src/file.rs:67-102),
+ * else decode `zst` (the bytes of <data_dir>/name.zst) on the GPU and insert (:47-65).
+ * *real_size receives what goes into the user.real_size xattr (:473-482). */
+int64_t mzd_fs_open(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t* zst, size_t zst_len, uint64_t* real_size);
+/* read: bytes [offset, offset+size) of the decoded file, short at EOF (:506-511). */
+int64_t mzd_fs_read(mzd_fs* fs, uint64_t fh, int64_t offset, uint32_t size, uint8_t* out);
+/* release: drops the handle; the decoded bytes go when the last handle of the inode goes. */
+int mzd_fs_release(mzd_fs* fs, uint64_t fh);
+/* number of GPU decodes performed so far (second opens of an inode must not add one). */
+uint64_t mzd_fs_decode_count(const mzd_fs* fs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MZD_H */

@@ -509,7 +509,8 @@ static int decode_frame(const uint8_t* src, size_t n, size_t* consumed, uint8_t*
     if (rc) return rc;
     /* copy_decode is a streaming decoder: libzstd's default ZSTD_d_windowLogMax (27) applies */
     if (h.window > (1ULL << 27) + 1) return OZS_E_UNSUPPORTED;
-    if (h.dict_id && ds->formatted && ds->init.dict_id != h.dict_id) return OZS_E_DICT;
+    /* libzstd: a frame that names a dictionary fails unless exactly that dictionary is loaded */
+    if (h.dict_id && h.dict_id != (ds->formatted ? ds->init.dict_id : 0u)) return OZS_E_DICT;
     dctx* d = (dctx*)malloc(sizeof(dctx));
     if (!d) return OZS_E_CORRUPT;
     *d = ds->init;

@@ -1,0 +1,144 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(include/mzd.h), against the oracle and the committed golden vectors -- byte-exact."""
+import numpy as np
+import pytest
+
+import corpus
+import fuse_zstd_amd as mzd
+import oracle
+from tests import golden_util
+
+pytestmark = pytest.mark.gpu
+VECS = golden_util.load_manifest()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def gpu():
+    mzd.build()
+    mzd.init()  # raises MzdError(E_DEVICE) when there is no GPU: no silent fallback
+    yield
+    mzd.shutdown()
+
+
+def test_golden_positive_batch():
+    """Every positive vector without a dictionary, in ONE batch (one workgroup per file)."""
+    vs = [v for v in VECS if v.ok and v.dict is None]
+    res = mzd.decode_batch([v.comp for v in vs], [v.out_len for v in vs])
+    bad = []
+    for v, (st, out) in zip(vs, res):
+        if st != 0 or out != v.expected():
+            bad.append((v.name, st, len(out), v.out_len))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("v", [v for v in VECS if v.ok and v.dict is None], ids=lambda v: v.name)
+def test_golden_positive_single(v):
+    st, out = mzd.decode(v.comp, v.out_len)
+    assert st == 0, mzd.strerror(st)
+    assert out == v.expected()
+
+
+@pytest.mark.parametrize("v", [v for v in VECS if not v.ok], ids=lambda v: v.name)
+def test_golden_negative(v):
+    st, _ = mzd.decode(v.comp, 1 << 22)
+    assert st == v.oracle_class, (mzd.strerror(st), oracle.strerror(v.oracle_class))
+
+
+@pytest.mark.parametrize("name", ["json_4k", "json_128k", "proxy_text_128k", "proxy_dna_300k", "hand_rle_lits_rle_tables",
+                                  "hand_long_nbseq", "hand_direct_weights_4s", "json_1m"])
+def test_phase_intermediates_match_cpu_twin(name):
+    """Literal buffer (K2) and sequence triples (K4) of the last compressed block, as the GPU
+    left them in its scratch, against the oracle's dump of the same block."""
+    v = next(x for x in VECS if x.name == name)
+    rc, out, blocks, dump = oracle.decode(v.comp, cap=v.out_len, want_trace=True, dump=True)
+    assert rc == 0
+    st, got = mzd.decode(v.comp, v.out_len)
+    assert st == 0 and got == out
+    lit, seq = mzd.debug_last_block(0)
+    assert lit == dump["lit"]
+    assert seq == dump["seq"]
+
+
+def test_dst_too_small_and_empty():
+    v = next(x for x in VECS if x.name == "json_4k")
+    st, _ = mzd.decode(v.comp, 100)
+    assert st == mzd.E_DSTSIZE
+    assert mzd.decode(b"", 16) == (0, b"")
+
+
+def test_dictionary_frames():
+    vs = [v for v in VECS if v.ok and v.dict is not None]
+    did = mzd.load_dict(vs[0].dict)
+    res = mzd.decode_batch([v.comp for v in vs], [v.out_len for v in vs], [did] * len(vs))
+    for v, (st, out) in zip(vs, res):
+        assert st == 0 and out == v.expected(), v.name
+    # the same frames without the dictionary must fail like libzstd (dictionary_wrong)
+    st, _ = mzd.decode(vs[0].comp, vs[0].out_len)
+    assert st == mzd.E_DICT
+    rc, _ = oracle.decode(vs[0].comp, cap=vs[0].out_len)
+    assert rc == oracle.E_DICT
+
+
+needs_zstd = pytest.mark.skipif(not corpus.have_zstd(), reason="no libzstd shared object to compress a corpus with")
+
+
+@needs_zstd
+@pytest.mark.parametrize("kind,level", [("json", 3), ("json", 1), ("json", 19), ("text", 3), ("markup", 9), ("int32", 3),
+                                        ("dna", 3), ("xray", 3), ("random", 3), ("repeats", 3)])
+def test_seeded_corpus_vs_oracle(kind, level):
+    """Seeded inputs at sizes the oracle finishes in seconds: GPU == oracle == original."""
+    sizes = [0, 1, 17, 300, 4096, 20000, 65536, 131072, 131073, 262144, 400000][: (7 if level == 19 else 11)]
+    cp = corpus.build_corpus(kind, 21, sizes, level=level)
+    srcs = [cp.comp_file(i).tobytes() for i in range(cp.nfiles)]
+    res = mzd.decode_batch(srcs, [int(s) for s in sizes])
+    for i, (st, out) in enumerate(res):
+        raw = cp.raw_file(i).tobytes()
+        rc, ref = oracle.decode(srcs[i], cap=len(raw))
+        assert rc == 0 and ref == raw
+        assert st == 0 and out == raw, (kind, level, sizes[i], st)
+
+
+@needs_zstd
+def test_config2_shape_device_resident():
+    """BASELINE config 2 shape, scaled down to 64 files: 128 KiB single-block JSON frames decoded
+    from HBM to HBM through mzd_decode_batch_device; checked against the generator's bytes."""
+    torch = pytest.importorskip("torch")
+    nfiles = 64
+    cp = corpus.build_corpus("json", 2, [131072] * nfiles, level=3)
+    dev = torch.device("cuda:0")
+    comp = torch.from_numpy(np.concatenate([cp.comp, np.zeros(64, np.uint8)])).to(dev)
+    out = torch.zeros(nfiles * 131072, dtype=torch.uint8, device=dev)
+    jobs = mzd.api.make_jobs([comp.data_ptr() + int(o) for o in cp.comp_offs], cp.comp_sizes,
+                             [out.data_ptr() + i * 131072 for i in range(nfiles)], [131072] * nfiles)
+    torch.cuda.synchronize()
+    res = mzd.decode_batch_device(0, jobs)
+    assert all(st == 0 and n == 131072 for st, n in res), res[:4]
+    got = out.cpu().numpy()
+    for i in range(nfiles):
+        assert got[i * 131072:(i + 1) * 131072].tobytes() == cp.raw_file(i).tobytes(), i
+
+
+def test_fs_open_read_release_mirror():
+    """open_wrapper / read_wrapper / release semantics (reference src/main.rs:451-513, src/file.rs)."""
+    v = next(x for x in VECS if x.name == "json_1m")
+    want = v.expected()
+    fs = mzd.ZstdFS()
+    fh, size = fs.open(42, 0, v.comp)
+    assert size == len(want) and fs.decode_count == 1
+    fh2, size2 = fs.open(42, 0, v.comp)  # second open of the inode: duplicate, no decode
+    assert fh2 != fh and size2 == size and fs.decode_count == 1
+    got = b"".join(fs.read(fh, off, 131072) for off in range(0, len(want) + 131072, 131072))
+    assert got == want
+    assert fs.read(fh2, len(want) - 10, 4096) == want[-10:]  # short read at EOF
+    fs.release(fh)
+    assert fs.read(fh2, 0, 16) == want[:16]  # bytes stay valid while a handle remains
+    with pytest.raises(OSError) as e:
+        fs.read(fh, 0, 16)
+    import errno
+    assert e.value.errno == errno.ENOENT
+    fs.release(fh2)
+    bad = next(x for x in VECS if x.name == "bad_checksum")
+    with pytest.raises(OSError) as e:
+        fs.open(43, 0, bad.comp)
+    assert e.value.errno == errno.EFAULT  # `.map_err(|_| libc::EFAULT)` src/main.rs:467
+    fs.close()
