@@ -37,7 +37,7 @@ def lib():
         L.corpus_bound.argtypes = [C.c_size_t]
         L.corpus_bound.restype = C.c_size_t
         L.corpus_build.restype = C.c_int
-        L.corpus_build.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+        L.corpus_build.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
@@ -79,8 +79,8 @@ class Corpus:
         return self.comp[o:o + n]
 
 
-def build_corpus(kind, cfg_id, sizes, first_index=0, level=3, checksum=True, kind_mod=0, nthreads=None, align=16):
-    """Generate + compress len(sizes) files.  kind_mod>0 cycles kinds kind..kind+kind_mod-1 by index
+def build_corpus(kind, cfg_id, sizes, first_index=0, stride=1, level=3, checksum=True, kind_mod=0, nthreads=None, align=16):
+    """Generate + compress len(sizes) files with indices first_index + i*stride.  kind_mod>0 cycles kinds kind..kind+kind_mod-1 by index
     (the Silesia-proxy mix).  Compressed frames are packed at `align`-byte boundaries."""
     L = lib()
     if L.corpus_open_zstd(None) != 0:
@@ -103,7 +103,7 @@ def build_corpus(kind, cfg_id, sizes, first_index=0, level=3, checksum=True, kin
     comp_sizes = np.zeros(n, dtype=np.uint64)
     if nthreads is None:
         nthreads = min(os.cpu_count() or 1, 32)
-    rc = L.corpus_build(k, kind_mod, cfg_id, first_index, n, raw_offs.ctypes.data, sizes.ctypes.data, raw.ctypes.data,
+    rc = L.corpus_build(k, kind_mod, cfg_id, first_index, stride, n, raw_offs.ctypes.data, sizes.ctypes.data, raw.ctypes.data,
                         tmp.ctypes.data, tmp_offs.ctypes.data, comp_sizes.ctypes.data, level, 1 if checksum else 0, nthreads)
     if rc != 0:
         raise RuntimeError("corpus_build failed: %d" % rc)

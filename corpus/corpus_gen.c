@@ -204,7 +204,7 @@ const char* corpus_zstd_version(void) { return H ? p_versionString() : ""; }
 size_t corpus_bound(size_t n) { return H ? p_compressBound(n) : 0; }
 
 typedef struct {
-    int kind_base, kind_mod; uint64_t cfg_id; uint64_t first_index; uint32_t nfiles;
+    int kind_base, kind_mod; uint64_t cfg_id; uint64_t first_index; uint64_t stride; uint32_t nfiles;
     const uint64_t* raw_offs; const uint64_t* raw_sizes; uint8_t* raw;
     uint8_t* comp; const uint64_t* comp_offs; uint64_t* comp_sizes;
     int level, checksum; volatile uint32_t* next; int fail;
@@ -216,7 +216,7 @@ static void* build_worker(void* v) {
     for (;;) {
         uint32_t i = __sync_fetch_and_add(a->next, 1);
         if (i >= a->nfiles) break;
-        uint64_t idx = a->first_index + i;
+        uint64_t idx = a->first_index + (uint64_t)i * a->stride;
         int kind = a->kind_base + (a->kind_mod ? (int)(idx % (uint64_t)a->kind_mod) : 0);
         uint8_t* raw = a->raw + a->raw_offs[i];
         corpus_gen(kind, a->cfg_id, idx, raw, (size_t)a->raw_sizes[i]);
@@ -231,11 +231,12 @@ static void* build_worker(void* v) {
     return NULL;
 }
 
-/* Generates and compresses files [first_index, first_index+nfiles).  File i is of kind
+/* Generates and compresses files first_index + i*stride, i in [0, nfiles) (stride = the number of
+ * GPUs when files are dealt round-robin: rank r takes first_index = r).  File i is of kind
  * kind_base + (index % kind_mod) (kind_mod 0 => always kind_base).  raw/comp are caller
  * buffers laid out by raw_offs / comp_offs (comp slots must hold corpus_bound(raw_size)).
  * Each file is ONE frame written like the reference writer: level, checksum, pledged size. */
-int corpus_build(int kind_base, int kind_mod, uint64_t cfg_id, uint64_t first_index, uint32_t nfiles,
+int corpus_build(int kind_base, int kind_mod, uint64_t cfg_id, uint64_t first_index, uint64_t stride, uint32_t nfiles,
                  const uint64_t* raw_offs, const uint64_t* raw_sizes, uint8_t* raw,
                  uint8_t* comp, const uint64_t* comp_offs, uint64_t* comp_sizes,
                  int level, int checksum, int nthreads) {
@@ -244,7 +245,7 @@ int corpus_build(int kind_base, int kind_mod, uint64_t cfg_id, uint64_t first_in
     if (nthreads > 64) nthreads = 64;
     pthread_t th[64]; build_arg args[64]; volatile uint32_t next = 0;
     for (int t = 0; t < nthreads; t++) {
-        build_arg a = {kind_base, kind_mod, cfg_id, first_index, nfiles, raw_offs, raw_sizes, raw, comp, comp_offs, comp_sizes,
+        build_arg a = {kind_base, kind_mod, cfg_id, first_index, stride ? stride : 1, nfiles, raw_offs, raw_sizes, raw, comp, comp_offs, comp_sizes,
                        level, checksum, &next, 0};
         args[t] = a;
         pthread_create(&th[t], NULL, build_worker, &args[t]);

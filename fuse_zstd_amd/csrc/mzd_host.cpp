@@ -454,6 +454,21 @@ int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit
     return MZD_OK;
 }
 
+// Diagnostic (libmzd_diag.so, built with -DMZD_STAMPS): per-phase cycle sums of the workgroup that ran job 0.
+int mzd_debug_stamps(int device, uint64_t* out8) {
+    Device* d = get_device(device);
+    if (!d || !out8) return MZD_E_PARAM;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIPCHK(hipSetDevice(d->hip_id));
+    uint32_t slot = 0;
+    HIPCHK(hipMemcpy(&slot, d->counter + 1, 4, hipMemcpyDeviceToHost));
+    if (slot >= d->max_wg) return MZD_E_PARAM;
+    DebugSlot ds;
+    HIPCHK(hipMemcpy(&ds, d->debug + slot, sizeof(ds), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out8[i] = ds.stamp[i];
+    return MZD_OK;
+}
+
 int mzd_last_kernel_ms(int device, float* ms) {
     Device* d = get_device(device);
     if (!d || !ms) return MZD_E_PARAM;

@@ -880,6 +880,17 @@ __device__ __noinline__ void build_tables_wave(Shared& S, int wave, int lane) {
 // next step rewrites it, and all 256 lanes always take the same branch.
 #define WG_SNAPSHOT(...) do { __syncthreads(); __VA_ARGS__; __syncthreads(); } while (0)
 
+// Diagnostic build only: per-phase cycle sums of the workgroup (lane 0), never in the product .so.
+#ifdef MZD_STAMPS
+#define STAMP_DECL uint64_t st_prev = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#define STAMP_FLUSH() do { if (tid == 0 && a.debug) for (int k_ = 0; k_ < 8; k_++) a.debug[blockIdx.x].stamp[k_] = st_acc[k_]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH()
+#endif
+
 __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
     __shared__ Shared S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -904,6 +915,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
         }
         int err = 0;
         uint32_t action = 0;
+        STAMP_DECL;
 
         // ---------------- frames (K0)
         while (true) {
@@ -948,16 +960,19 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     }
                 } else {
                     const uint8_t* const blk = src + pos0;
+                    STAMP(0);
                     if (tid == 0) parse_literals(S, blk, bsize); // K1 (weights)
                     uint32_t lit_type = 0, nlit = 0, streams = 0, huf_log = 0;
                     uint64_t lit_off = 0;
                     WG_SNAPSHOT(err = c.err; lit_type = c.lit_type; nlit = c.nlit; streams = c.streams; huf_log = c.huf_log; lit_off = c.lit_off);
                     if (err) break;
+                    STAMP(1);
                     if (lit_type == 2) { // K1 (table)
                         fill_huf_table(S, tid);
                         if (tid == 0) c.huf_valid = 1;
                         __syncthreads();
                     }
+                    STAMP(2);
                     // K2: literals; lane 0 then parses the sequences header (K3)
                     const uint8_t* lit = lit_buf;
                     if (lit_type == 0) lit = src + lit_off;
@@ -971,20 +986,24 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     uint64_t seq_off = 0;
                     WG_SNAPSHOT(err = c.err; nseq = c.nseq; seq_off = c.seq_off; seq_len = c.seq_len);
                     if (err) break;
+                    STAMP(3);
                     if (nseq) { // K3 tables
                         build_tables_wave(S, wave, lane);
                         WG_SNAPSHOT(err = c.err);
                         if (err) break;
                     }
+                    STAMP(4);
                     if (wave == 0) { // K4 + K5 on one wavefront
                         int rc = 0;
                         uint64_t opos = out0;
                         if (nseq) rc = decode_sequences_wave(S, src + seq_off, seq_len, nseq, seqs, lane);
+                        STAMP(5);
                         if (!rc) rc = execute_wave(seqs, nseq, lit, nlit, dst, c.frame_out0, &opos, cap, c.dict_content, c.dict_content_len, lane);
                         if (lane == 0) {
                             if (rc) c.err = rc;
                             if (nseq) c.fse_valid = 1;
                             c.out = opos; c.pos = pos0 + bsize;
+                            STAMP(6);
                             if (a.debug) {
                                 DebugSlot& ds = a.debug[blockIdx.x];
                                 ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0; ds.lit_raw_ptr = (uint64_t)(uintptr_t)lit;
@@ -1013,12 +1032,14 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         if ((uint32_t)h != ld32(src + pos_now)) c.err = MZD_E_CHECKSUM;
                         c.pos = pos_now + 4;
                     }
+                    STAMP(7);
                 }
                 WG_SNAPSHOT(err = c.err);
                 if (err) break;
             }
         }
         if (tid == 0) { a.jobs[j].out_len = c.out; a.jobs[j].status = c.err; }
+        STAMP_FLUSH();
         __syncthreads();
     }
 }

@@ -1,0 +1,22 @@
+"""Diagnostic: per-phase cycles of one workgroup (libmzd_diag.so, -DMZD_STAMPS).  Not a benchmark."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fuse_zstd_amd.api as api
+api._SO = os.path.join(os.path.dirname(api._SO), "libmzd_diag.so")
+import fuse_zstd_amd as mzd, corpus
+mzd.init()
+kind = sys.argv[1] if len(sys.argv) > 1 else "json"
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+cp = corpus.build_corpus(kind, 2, [size] * n)
+srcs = [cp.comp_file(i).tobytes() for i in range(n)]
+for rep in range(2):
+    res = mzd.decode_batch(srcs, [size] * n)
+assert all(st == 0 for st, _ in res)
+st = (C.c_uint64 * 8)()
+api.lib().mzd_debug_stamps(0, st)
+names = ["hdr", "K1 weights+parse", "K1 table fill", "K2 literals+seqhdr", "K3 tables", "K4 seq decode", "K5 execute", "K7 xxh64"]
+tot = sum(st)
+print("kernel ms", mzd.last_kernel_ms(0), "files", n)
+for nm, v in zip(names, st):
+    print("%-22s %10d cycles %5.1f%%" % (nm, v, 100.0 * v / max(tot, 1)))
