@@ -53,6 +53,7 @@ struct KernelArgs {
     uint32_t* counter;    // work queue head
     uint8_t* lit_scratch; // kLitStride bytes per workgroup
     uint4* seq_scratch;   // kSeqStride uint4 per workgroup
+    uint2* walk_scratch;  // kSeqStride uint2 per workgroup (state-walk records)
     const DevDict* dicts;
     uint32_t ndicts;
     DebugSlot* debug;     // gridDim.x entries

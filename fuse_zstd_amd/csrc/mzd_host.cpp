@@ -43,6 +43,7 @@ struct Device {
     uint32_t max_wg = 0;
     uint8_t* lit_scratch = nullptr;
     uint4* seq_scratch = nullptr;
+    uint2* walk_scratch = nullptr;
     DebugSlot* debug = nullptr;
     uint32_t* counter = nullptr; // [0] work-queue head, [1] slot that ran job 0
     DevJob* d_jobs = nullptr;
@@ -65,7 +66,7 @@ std::vector<std::unique_ptr<Device>> g_dev;
 void free_device(Device& d) {
     hipSetDevice(d.hip_id);
     if (d.stream) hipStreamSynchronize(d.stream);
-    hipFree(d.lit_scratch); hipFree(d.seq_scratch); hipFree(d.debug); hipFree(d.counter); hipFree(d.d_jobs);
+    hipFree(d.lit_scratch); hipFree(d.seq_scratch); hipFree(d.walk_scratch); hipFree(d.debug); hipFree(d.counter); hipFree(d.d_jobs);
     hipFree(d.d_in); hipFree(d.d_out); hipFree(d.d_dicts);
     for (void* p : d.dict_bufs) hipFree(p);
     if (d.h_jobs) hipHostFree(d.h_jobs);
@@ -88,6 +89,7 @@ int init_device(Device& d, int hip_id) {
     d.max_wg = (uint32_t)(cus * per_cu);
     HIPCHK(hipMalloc(&d.lit_scratch, (size_t)d.max_wg * kLitStride));
     HIPCHK(hipMalloc(&d.seq_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
+    HIPCHK(hipMalloc(&d.walk_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint2)));
     HIPCHK(hipMalloc(&d.debug, (size_t)d.max_wg * sizeof(DebugSlot)));
     HIPCHK(hipMemset(d.debug, 0, (size_t)d.max_wg * sizeof(DebugSlot)));
     HIPCHK(hipMalloc(&d.counter, 64));
@@ -113,7 +115,7 @@ int ensure_jobs(Device& d, size_t n) {
 KernelArgs make_args(Device& d, DevJob* jobs, uint32_t njobs) {
     KernelArgs a;
     a.jobs = jobs; a.njobs = njobs; a.counter = d.counter;
-    a.lit_scratch = d.lit_scratch; a.seq_scratch = d.seq_scratch;
+    a.lit_scratch = d.lit_scratch; a.seq_scratch = d.seq_scratch; a.walk_scratch = d.walk_scratch;
     a.dicts = d.d_dicts; a.ndicts = d.ndicts; a.debug = d.debug; a.job_slot0 = d.counter + 1;
     return a;
 }

@@ -28,9 +28,9 @@
 namespace mzd {
 
 // ------------------------------------------------------------------------------------ LDS
-constexpr int kRingBytes = 4096; // sequence-bitstream ring: 4 chunks of 1 KiB
-constexpr int kRingDw = kRingBytes / 4;
+constexpr int kRingBytes = 8192; // sequence-bitstream ring: 8 chunks of 1 KiB (+16 mirrored bytes)
 constexpr int kChunk = 1024;
+constexpr int kRingChunks = kRingBytes / kChunk;
 
 struct Ctl {
     uint64_t pos;        // next unread input byte of the file
@@ -54,10 +54,13 @@ struct Ctl {
 };
 
 struct __attribute__((aligned(16))) Shared {
-    uint64_t ll[512];   // FSE entries: [31:0] base value, [47:32] next-state base, [55:48] nbBits, [63:56] extra bits
+    // FSE decode entries, 8 bytes: low dword = byte offset of the next state's entry before the
+    // fresh bits are added (8 * nextStateBase); high dword = nbBits | (extra+nbBits) << 8 | symbol << 16 | extra << 24
+    uint64_t ll[512];
     uint64_t ml[512];
     uint64_t of[256];
-    uint32_t ring[kRingDw];
+    uint8_t ring[kRingBytes + 16];
+    uint8_t stage[2048 + 16]; // K5 staging buffer (kStage)
     uint16_t huf[2048]; // sym | len << 8
     int16_t norm[3][64];
     uint16_t next[3][64];
@@ -146,7 +149,15 @@ __device__ __noinline__ int read_ncount(const uint8_t* src, uint32_t n, int max_
     return (bit + 7) >> 3;
 }
 
-// Table build (A.3) by one lane.  kind 0 LL, 1 OF, 2 ML selects the code -> (base, extra) map.
+// number of extra bits of a code: kind 0 LL, 1 OF, 2 ML
+__device__ __forceinline__ uint32_t code_extra(uint32_t s, int kind) { return kind == 0 ? LL_BITS[s] : (kind == 1 ? s : ML_BITS[s]); }
+__device__ __forceinline__ uint64_t pack_entry(uint32_t nbase, uint32_t nb, uint32_t s, int kind) {
+    uint32_t extra = code_extra(s, kind);
+    uint32_t hi = nb | ((extra + nb) << 8) | (s << 16) | (extra << 24);
+    return (uint64_t)(nbase * 8u) | ((uint64_t)hi << 32);
+}
+
+// Table build (A.3) by one lane.  kind 0 LL, 1 OF, 2 ML.
 __device__ __noinline__ int build_seq_table(uint64_t* tab, const int16_t* norm, uint16_t* next, uint32_t nsym, uint32_t log, int kind) {
     uint32_t size = 1u << log, high = size;
     for (uint32_t s = 0; s < nsym; s++)
@@ -167,22 +178,12 @@ __device__ __noinline__ int build_seq_table(uint64_t* tab, const int16_t* norm, 
         uint32_t d = next[s]++;
         uint32_t nb = log - (uint32_t)hibit(d);
         uint32_t nbase = (d << nb) - size;
-        uint32_t base, extra;
-        if (kind == 0) { base = LL_BASE[s]; extra = LL_BITS[s]; }
-        else if (kind == 1) { base = 1u << s; extra = s; }
-        else { base = ML_BASE[s]; extra = ML_BITS[s]; }
-        tab[i] = (uint64_t)base | ((uint64_t)nbase << 32) | ((uint64_t)nb << 48) | ((uint64_t)extra << 56);
+        tab[i] = pack_entry(nbase, nb, s, kind);
     }
     return 0;
 }
 
-__device__ void rle_seq_table(uint64_t* tab, uint32_t s, int kind) {
-    uint32_t base, extra;
-    if (kind == 0) { base = LL_BASE[s]; extra = LL_BITS[s]; }
-    else if (kind == 1) { base = 1u << s; extra = s; }
-    else { base = ML_BASE[s]; extra = ML_BITS[s]; }
-    tab[0] = (uint64_t)base | ((uint64_t)extra << 56);
-}
+__device__ void rle_seq_table(uint64_t* tab, uint32_t s, int kind) { tab[0] = pack_entry(0, 0, s, kind); }
 
 // ------------------------------------------------------------------------------------ K1
 // Huffman tree description (A.4) -> S.weights[0..nw), S.c.huf_log.  Lane 0.  Returns bytes used or < 0.
@@ -208,7 +209,7 @@ __device__ __noinline__ int read_huf_weights(Shared& S, const uint8_t* src, uint
         if (hdr <= 0) return MZD_E_CORRUPT;
         // tiny FSE table (<= 64 entries) built in place
         uint32_t size = 1u << log, high = size;
-        uint16_t* next = (uint16_t*)S.ring; // the ring is idle during literal decoding
+        uint16_t* next = (uint16_t*)(void*)S.ring; // the ring is idle during literal decoding
         for (uint32_t s = 0; s < nsym; s++)
             if (S.wnorm[s] == -1) { high--; S.wtab[high] = s; next[s] = 1; }
         uint32_t step = (size >> 1) + (size >> 3) + 3, pos = 0, mask = size - 1;
@@ -408,10 +409,23 @@ __device__ __noinline__ void wave_pattern(uint8_t* d, uint32_t off, uint32_t n, 
 }
 
 // ------------------------------------------------------------------------------------ K4
-// The sequence bitstream is read backwards through a 4 KiB LDS ring filled 1 KiB at a time with
-// one 16-byte load per lane.  Ring coordinates ("g-offsets") are stream byte index + bias,
-// bias = 16 + (sp & 15), so that chunk boundaries are 16-B aligned in HBM and everything below
-// the first stream byte reads as zero (bits below bit 0 of a backward stream are zero).
+// FSE sequence decode (A.5), split in two:
+//
+//  (a) walk_sequences_wave -- the part that is serial by construction.  One bitstream carries three
+//      interleaved tANS states; state i+1 depends on the bits state i consumed, so a
+//      single wavefront walks it.  On a lone wavefront every instruction costs ~4 cycles of issue,
+//      so the loop does only what the chain needs: three table reads + one 8-byte bitstream
+//      window (all LDS, issued together), the bit budget of the sequence, the three state updates.
+//      Per sequence it records {bit position, three states} (8 bytes) and nothing else.
+//  (b) convert_sequences -- everything that is NOT a chain: extra bits, base values.  One lane per
+//      sequence, all 256 lanes, straight from the records of (a).
+//  Repeat-offset resolution (a chain again, but a cheap one) happens in execute_wave.
+//
+// The bitstream is read backwards through an 8 KiB LDS ring, filled 1 KiB at a time with one 16-byte
+// load per lane (coalesced).  Ring coordinates ("g-offsets") are stream byte index + bias,
+// bias = 16 + (sp & 15): chunk boundaries are 16-B aligned in HBM and everything below the first
+// stream byte reads as zero (bits below bit 0 of a backward stream are zero).  The first 16 bytes
+// are mirrored behind the ring so that an unaligned 8-byte read never has to wrap.
 struct SeqStream {
     const uint8_t* gbase; // HBM address of g-offset 0 (16-B aligned; may lie before the buffer, never dereferenced there)
     uint32_t bias;        // g-offset of stream byte 0
@@ -419,7 +433,7 @@ struct SeqStream {
     int32_t lowest;       // lowest chunk resident in the ring
 };
 
-__device__ void ring_load_chunk(Shared& S, const SeqStream& st, int32_t chunk, int lane) {
+__device__ __forceinline__ void ring_load_chunk(Shared& S, const SeqStream& st, int32_t chunk, int lane) {
     uint32_t o = (uint32_t)chunk * kChunk + (uint32_t)lane * 16; // g-offset of this lane's piece
     uint4 v = make_uint4(0, 0, 0, 0);
     if (o + 16 > st.bias && o < st.gend) {
@@ -436,22 +450,26 @@ __device__ void ring_load_chunk(Shared& S, const SeqStream& st, int32_t chunk, i
             v = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
-    *reinterpret_cast<uint4*>(&S.ring[((uint32_t)(chunk & 3) * kChunk + (uint32_t)lane * 16) >> 2]) = v;
+    uint32_t slot = (uint32_t)chunk & (kRingChunks - 1);
+    *reinterpret_cast<uint4*>(&S.ring[slot * kChunk + (uint32_t)lane * 16]) = v;
+    if (slot == 0 && lane == 0) *reinterpret_cast<uint4*>(&S.ring[kRingBytes]) = v; // mirror
 }
 
-// 8 bytes ending at g-offset e (exclusive), as a little-endian u64.
+// the 8 ring bytes that end at g-offset e (exclusive), as a little-endian u64
 __device__ __forceinline__ uint64_t ring_read64(const Shared& S, uint32_t e) {
-    uint32_t a = (e - 8) & (kRingBytes - 1);
-    uint32_t i = a >> 2, sh = (a & 3) * 8;
-    uint32_t d0 = S.ring[i], d1 = S.ring[(i + 1) & (kRingDw - 1)], d2 = S.ring[(i + 2) & (kRingDw - 1)];
-    uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);
-    uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-    return ((uint64_t)hi << 32) | lo;
+    uint64_t v;
+    __builtin_memcpy(&v, &S.ring[(e - 8) & (kRingBytes - 1)], 8);
+    return v;
 }
 
-// FSE sequence decode (A.5) by one wavefront, wave-uniform (every lane computes the same values;
-// lane 0 stores).  Writes nseq resolved triples {ll, ml, off, 0}.  Returns 0 or an error.
-__device__ __noinline__ int decode_sequences_wave(Shared& S, const uint8_t* sp, uint32_t sl, uint32_t nseq, uint4* seqs, int lane) {
+// walk record: x = LL state offset | ML state offset << 12 ; y = g-bit position | OF state offset << 21
+//   (state offsets are byte offsets into the tables: 8 * state)
+constexpr uint32_t kWalkBatch = 32; // sequences between two ring checks (<= 89 bits each)
+
+__device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint2* walk, int lane) {
+    const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
+    // a global (not flat) pointer: flat stores would also count on lgkmcnt, i.e. sit in the LDS waits below
+    __attribute__((address_space(1))) uint64_t* const gwalk = (__attribute__((address_space(1))) uint64_t*)walk;
     if (sl == 0) return MZD_E_CORRUPT;
     uint32_t last = sp[sl - 1];
     if (last == 0) return MZD_E_CORRUPT;
@@ -460,198 +478,360 @@ __device__ __noinline__ int decode_sequences_wave(Shared& S, const uint8_t* sp, 
     st.bias = 16 + skew;
     st.gbase = sp - st.bias;
     st.gend = sl + st.bias;
-    // G = number of g-bits below the read head
-    uint64_t G = (uint64_t)(sl - 1) * 8 + (uint32_t)hibit(last) + (uint64_t)st.bias * 8;
-    const uint64_t Gzero = (uint64_t)st.bias * 8; // read head at stream bit 0
+    const uint32_t Gzero = st.bias * 8; // read head at stream bit 0
+    uint32_t G = (sl - 1) * 8 + (uint32_t)hibit(last) + Gzero; // g-bits below the read head
     int32_t top = (int32_t)((st.gend - 1) / kChunk);
     st.lowest = top;
     ring_load_chunk(S, st, top, lane);
-    for (int k = 1; k <= 2 && top - k >= 0; k++) { ring_load_chunk(S, st, top - k, lane); st.lowest = top - k; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (top >= 1) { ring_load_chunk(S, st, top - 1, lane); st.lowest = top - 1; }
 
     const uint32_t alL = S.c.al[0], alO = S.c.al[1], alM = S.c.al[2];
-    // initial states
-    uint32_t sL, sO, sM;
+    uint32_t vL, vO, vM; // state byte offsets
     {
-        uint32_t e = (uint32_t)((G + 7) >> 3);
+        uint32_t e = (G + 7) >> 3;
         uint64_t B = ring_read64(S, e) << (e * 8 - G);
         uint32_t n = alL + alO + alM;
         if (G - Gzero < n) return MZD_E_CORRUPT;
-        sL = alL ? (uint32_t)(B >> (64 - alL)) : 0; B <<= alL;
-        sO = alO ? (uint32_t)(B >> (64 - alO)) : 0; B <<= alO;
-        sM = alM ? (uint32_t)(B >> (64 - alM)) : 0;
+        vL = alL ? (uint32_t)(B >> (64 - alL)) : 0; B <<= alL;
+        vO = alO ? (uint32_t)(B >> (64 - alO)) : 0; B <<= alO;
+        vM = alM ? (uint32_t)(B >> (64 - alM)) : 0;
         G -= n;
+        vL *= 8; vO *= 8; vM *= 8;
     }
-    uint32_t rep0 = S.c.rep[0], rep1 = S.c.rep[1], rep2 = S.c.rep[2];
-    int err = 0;
-    for (uint32_t i = 0; i < nseq; i++) {
-        // keep the ring ahead of the read head (uniform branch)
-        uint32_t e = (uint32_t)((G + 7) >> 3);
-        if (st.lowest > 0 && (int32_t)e - 160 < st.lowest * kChunk) {
-            st.lowest--;
-            ring_load_chunk(S, st, st.lowest, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint8_t* const tL = reinterpret_cast<const uint8_t*>(S.ll);
+    const uint8_t* const tM = reinterpret_cast<const uint8_t*>(S.ml);
+    const uint8_t* const tO = reinterpret_cast<const uint8_t*>(S.of);
+    uint32_t i = 0;
+    const uint32_t nupd = nseq - 1; // sequences followed by a state update
+    while (i < nupd) {
+        // keep the ring kWalkBatch sequences ahead of the read head (uniform branch, once per batch)
+        {
+            uint32_t e = __builtin_amdgcn_readfirstlane((G + 7) >> 3);
+            while (st.lowest > 0 && (int32_t)e - (int32_t)(kWalkBatch * 12 + 24) < st.lowest * kChunk) {
+                st.lowest--;
+                ring_load_chunk(S, st, st.lowest, lane);
+            }
         }
-        uint64_t eL = S.ll[sL], eO = S.of[sO], eM = S.ml[sM];
-        uint64_t X = ring_read64(S, e);
-        uint32_t s0 = (uint32_t)(e * 8 - G);
-        uint32_t xO = (uint32_t)(eO >> 56), xM = (uint32_t)(eM >> 56), xL = (uint32_t)(eL >> 56);
-        uint32_t nL = (uint32_t)(eL >> 48) & 0xFF, nM = (uint32_t)(eM >> 48) & 0xFF, nO = (uint32_t)(eO >> 48) & 0xFF;
-        const bool lastseq = (i + 1 == nseq);
-        if (lastseq) { nL = nM = nO = 0; }
-        uint32_t total = xO + xM + xL + nL + nM + nO;
-        if (G - Gzero < total) { err = MZD_E_CORRUPT; break; }
-        uint32_t vO, vM, vL, uL, uM, uO;
-        if (s0 + total <= 64) { // one window covers the whole sequence (the common case)
-            uint64_t B = X << s0;
-            vO = xO ? (uint32_t)(B >> (64 - xO)) : 0; B <<= xO;
-            vM = xM ? (uint32_t)(B >> (64 - xM)) : 0; B <<= xM;
-            vL = xL ? (uint32_t)(B >> (64 - xL)) : 0; B <<= xL;
-            uL = nL ? (uint32_t)(B >> (64 - nL)) : 0; B <<= nL;
-            uM = nM ? (uint32_t)(B >> (64 - nM)) : 0; B <<= nM;
-            uO = nO ? (uint32_t)(B >> (64 - nO)) : 0;
+        uint32_t stop = i + kWalkBatch < nupd ? i + kWalkBatch : nupd;
+        for (; i < stop; i++) {
+            uint64_t eL, eM, eO;
+            __builtin_memcpy(&eL, tL + vL, 8);
+            __builtin_memcpy(&eM, tM + vM, 8);
+            __builtin_memcpy(&eO, tO + vO, 8);
+            uint32_t t = G - 57;
+            uint64_t X;
+            __builtin_memcpy(&X, &S.ring[(t >> 3) & (kRingBytes - 1)], 8); // the 8 bytes ending at ceil(G/8)
+            gwalk[i] = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(G | (vO << 21)) << 32);
+            // all four LDS reads must be in flight together: pin the window load above the branch
+            asm volatile("" : "+v"(X));
+            uint32_t hL = (uint32_t)(eL >> 32), hM = (uint32_t)(eM >> 32), hO = (uint32_t)(eO >> 32);
+            uint32_t total = ((hL + hM + hO) >> 8) & 0xFF;
+            uint32_t r = t & 7;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(total > 57 + r) != 0, 0)) { // long extra-bit fields: window again below them
+                uint32_t extra = (hL >> 24) + (hM >> 24) + (hO >> 24);
+                uint32_t G2 = G - extra;
+                uint32_t e2 = (G2 + 7) >> 3;
+                uint64_t B = ring_read64(S, e2) << (e2 * 8 - G2);
+                uint32_t nL = hL & 63, nM = hM & 63, nO = hO & 63;
+                uint32_t uL = nL ? (uint32_t)(B >> (64 - nL)) : 0; B <<= nL;
+                uint32_t uM = nM ? (uint32_t)(B >> (64 - nM)) : 0; B <<= nM;
+                uint32_t uO = nO ? (uint32_t)(B >> (64 - nO)) : 0;
+                vL = (uint32_t)eL + uL * 8; vM = (uint32_t)eM + uM * 8; vO = (uint32_t)eO + uO * 8;
+                G -= total;
+                continue;
+            }
+            // fresh state bits sit at the bottom of what this sequence consumes: OF lowest, then ML, then LL
+            uint32_t oO = r + 57 - total;
+            uint32_t oM = oO + hO; // only the low 6 bits matter (nbBits lives in [5:0])
+            uint32_t oL = oM + hM;
+            uint32_t bO = __builtin_amdgcn_ubfe((uint32_t)(X >> (oO & 63)), 0, hO);
+            uint32_t bM = __builtin_amdgcn_ubfe((uint32_t)(X >> (oM & 63)), 0, hM);
+            uint32_t bL = __builtin_amdgcn_ubfe((uint32_t)(X >> (oL & 63)), 0, hL);
+            vO = (uint32_t)eO + (bO << 3);
+            vM = (uint32_t)eM + (bM << 3);
+            vL = (uint32_t)eL + (bL << 3);
             G -= total;
-        } else { // long extra-bit fields: re-window between the three groups
-            uint64_t B = X << s0;
-            vO = xO ? (uint32_t)(B >> (64 - xO)) : 0;
-            G -= xO;
-            uint32_t e2 = (uint32_t)((G + 7) >> 3);
-            B = ring_read64(S, e2) << (e2 * 8 - G);
-            vM = xM ? (uint32_t)(B >> (64 - xM)) : 0; B <<= xM;
-            vL = xL ? (uint32_t)(B >> (64 - xL)) : 0;
-            G -= xM + xL;
-            e2 = (uint32_t)((G + 7) >> 3);
-            B = ring_read64(S, e2) << (e2 * 8 - G);
-            uL = nL ? (uint32_t)(B >> (64 - nL)) : 0; B <<= nL;
-            uM = nM ? (uint32_t)(B >> (64 - nM)) : 0; B <<= nM;
-            uO = nO ? (uint32_t)(B >> (64 - nO)) : 0;
-            G -= nL + nM + nO;
         }
-        // next states first: they start the next iteration's table reads
-        sL = ((uint32_t)(eL >> 32) & 0xFFFF) + uL;
-        sM = ((uint32_t)(eM >> 32) & 0xFFFF) + uM;
-        sO = ((uint32_t)(eO >> 32) & 0xFFFF) + uO;
-        uint32_t ll = (uint32_t)eL + vL, ml = (uint32_t)eM + vM, ofv = (uint32_t)eO + vO;
-        uint32_t off;
-        if (ofv > 3) { off = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
-        else {
-            uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
-            if (idx == 0) off = rep0;
-            else if (idx == 1) { off = rep1; rep1 = rep0; rep0 = off; }
-            else if (idx == 2) { off = rep2; rep2 = rep1; rep1 = rep0; rep0 = off; }
-            else { off = rep0 - 1; if (off == 0) { err = MZD_E_CORRUPT; break; } rep2 = rep1; rep1 = rep0; rep0 = off; }
-        }
-        if (lane == 0) seqs[i] = make_uint4(ll, ml, off, 0);
+        if ((int32_t)(G - Gzero) < 0) return MZD_E_CORRUPT; // over-read
     }
-    if (err) return err;
-    if (G != Gzero) return MZD_E_CORRUPT; // the bitstream must be consumed exactly
-    if (lane == 0) { S.c.rep[0] = rep0; S.c.rep[1] = rep1; S.c.rep[2] = rep2; }
-    wg_fence(); // lane 0's stores of the triples -> the loads of all 64 lanes in execute_wave
+    // last sequence: extra bits only
+    {
+        uint64_t eL, eM, eO;
+        __builtin_memcpy(&eL, tL + vL, 8);
+        __builtin_memcpy(&eM, tM + vM, 8);
+        __builtin_memcpy(&eO, tO + vO, 8);
+        gwalk[nupd] = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(G | (vO << 21)) << 32);
+        uint32_t extra = (uint32_t)(eL >> 56) + (uint32_t)(eM >> 56) + (uint32_t)(eO >> 56);
+        if (G - Gzero != extra) return MZD_E_CORRUPT; // the bitstream must be consumed exactly
+    }
     return 0;
 }
 
-// ------------------------------------------------------------------------------------ K5
-// Sequence execution (A.5) by one wavefront, 64 sequences per step.
-//   1. scans of ll and ll+ml give every lane its literal source and output position;
-//   2. literal runs are copied (long ones by the whole wave);
-//   3. matches are resolved in rounds: a match is ready when its source lies below the
-//      output of the first unfinished sequence; ready short matches are copied one per
-//      lane, long ones by the whole wave; overlapping matches replicate their pattern.
-// dst/frame_start/opos are absolute; returns 0 or an error; *opos_io advances.
-constexpr uint32_t kLongCopy = 48;
+// n bits (n <= 32) whose top is g-bit `top` (exclusive), read from HBM
+__device__ __forceinline__ uint32_t stream_bits(const uint8_t* gbase, uint32_t top, uint32_t n) {
+    uint32_t lo = top - n;
+    uint64_t v = ldu64(gbase + (lo >> 3)) >> (lo & 7);
+    return n ? (uint32_t)v & (uint32_t)((1ull << n) - 1) : 0u;
+}
 
-__device__ __noinline__ int execute_wave(const uint4* seqs, uint32_t nseq, const uint8_t* lit, uint32_t nlit, uint8_t* dst,
-                            uint64_t frame_start, uint64_t* opos_io, uint64_t cap, const uint8_t* dict, uint32_t dict_len, int lane) {
+// (b): one lane per sequence -> {ll, ml, offset_value, 0}.  All 256 lanes.
+__device__ void convert_sequences(const Shared& S, const uint8_t* sp, uint32_t nseq, const uint2* walk, uint4* seqs, int tid) {
+    const uint32_t bias = 16 + (uint32_t)((uintptr_t)sp & 15);
+    const uint8_t* gbase = sp - bias;
+    for (uint32_t i = tid; i < nseq; i += kWG) {
+        uint2 w = walk[i];
+        uint32_t vL = w.x & 0xFFF, vM = w.x >> 12, vO = w.y >> 21, G = w.y & 0x1FFFFF;
+        uint32_t hL = (uint32_t)(S.ll[vL >> 3] >> 32), hM = (uint32_t)(S.ml[vM >> 3] >> 32), hO = (uint32_t)(S.of[vO >> 3] >> 32);
+        uint32_t cL = (hL >> 16) & 0xFF, cM = (hM >> 16) & 0xFF, cO = (hO >> 16) & 0xFF;
+        uint32_t xL = hL >> 24, xM = hM >> 24, xO = hO >> 24;
+        uint32_t ofv = (1u << cO) + stream_bits(gbase, G, xO);
+        uint32_t ml = ML_BASE[cM] + stream_bits(gbase, G - xO, xM);
+        uint32_t ll = LL_BASE[cL] + stream_bits(gbase, G - xO - xM, xL);
+        seqs[i] = make_uint4(ll, ml, ofv, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------ K5
+// Sequence execution (A.5) by one wavefront, 64 sequences per step (lane = sequence).
+//   1. repeat offsets: the rule of A.5 is a chain over the sequences; it is resolved with a
+//      wave scan over "symbolic" register-file transforms (each of the three slots is either a
+//      constant or an input slot plus a delta), so 64 sequences cost log2(64) shuffle rounds;
+//   2. scans of ll and ll+ml give every lane its literal source and its output position;
+//   3. runs of short sequences are assembled in an LDS staging buffer (kStage bytes): literals and
+//      matches whose source lies before the run come from HBM with 8-byte accesses, matches
+//      whose source is inside the run are resolved LDS->LDS in rounds (a match is ready when its
+//      source lies below the output of the first unfinished sequence), then the run is flushed
+//      to HBM with coalesced 16-byte stores;
+//   4. long literal runs / matches bypass the staging buffer and are copied by all 64 lanes
+//      (overlapping matches replicate their pattern).
+constexpr uint32_t kStage = 2048;
+constexpr uint32_t kShort = 64; // longest literal run / match that goes through the staging buffer
+
+typedef __attribute__((address_space(3))) uint8_t* lds_p;
+
+struct RepOp { uint32_t s; int32_t v0, v1, v2; }; // s: 2 bits per slot (0..2 input slot, 3 constant)
+__device__ __forceinline__ uint32_t rep_src(uint32_t s, int j) { return (s >> (2 * j)) & 3; }
+// result = g applied after f
+__device__ __forceinline__ RepOp rep_compose(const RepOp& g, const RepOp& f) {
+    RepOp r;
+    r.s = 0;
+    int32_t gv[3] = {g.v0, g.v1, g.v2}, rv[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        uint32_t gs = rep_src(g.s, j);
+        uint32_t fs = gs == 0 ? rep_src(f.s, 0) : (gs == 1 ? rep_src(f.s, 1) : rep_src(f.s, 2));
+        int32_t fv = gs == 0 ? f.v0 : (gs == 1 ? f.v1 : f.v2);
+        uint32_t ns = gs == 3 ? 3u : fs;
+        rv[j] = gs == 3 ? gv[j] : fv + gv[j];
+        r.s |= ns << (2 * j);
+    }
+    r.v0 = rv[0]; r.v1 = rv[1]; r.v2 = rv[2];
+    return r;
+}
+__device__ __forceinline__ uint32_t rep_eval(const RepOp& f, int j, uint32_t r0, uint32_t r1, uint32_t r2) {
+    uint32_t src = rep_src(f.s, j);
+    int32_t v = j == 0 ? f.v0 : (j == 1 ? f.v1 : f.v2);
+    uint32_t in = src == 0 ? r0 : (src == 1 ? r1 : r2);
+    return src == 3 ? (uint32_t)v : in + (uint32_t)v;
+}
+
+// copy n (<= 64) bytes with 8-byte accesses and an exact 4/2/1 tail; all loads are issued before the stores
+template <class LD, class ST>
+__device__ __forceinline__ void copy_short(uint32_t n, LD ld, ST st) {
+    uint64_t v[8];
+    uint32_t q = n >> 3;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) v[j] = j < q ? ld.u64(j * 8) : 0;
+    uint32_t t = q * 8, t4 = 0, t2 = 0, t1 = 0;
+    if (n & 4) { t4 = ld.u32(t); }
+    if (n & 2) { t2 = ld.u16(t + (n & 4)); }
+    if (n & 1) { t1 = ld.u8(t + (n & 6)); }
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) if (j < q) st.u64(j * 8, v[j]);
+    if (n & 4) st.u32(t, t4);
+    if (n & 2) st.u16(t + (n & 4), t2);
+    if (n & 1) st.u8(t + (n & 6), t1);
+}
+struct GlobalLd {
+    const uint8_t* p;
+    __device__ __forceinline__ uint64_t u64(uint32_t o) const { uint64_t v; __builtin_memcpy(&v, p + o, 8); return v; }
+    __device__ __forceinline__ uint32_t u32(uint32_t o) const { uint32_t v; __builtin_memcpy(&v, p + o, 4); return v; }
+    __device__ __forceinline__ uint32_t u16(uint32_t o) const { uint16_t v; __builtin_memcpy(&v, p + o, 2); return v; }
+    __device__ __forceinline__ uint32_t u8(uint32_t o) const { return p[o]; }
+};
+struct LdsLd {
+    const uint8_t* p;
+    __device__ __forceinline__ uint64_t u64(uint32_t o) const { uint64_t v; __builtin_memcpy(&v, p + o, 8); return v; }
+    __device__ __forceinline__ uint32_t u32(uint32_t o) const { uint32_t v; __builtin_memcpy(&v, p + o, 4); return v; }
+    __device__ __forceinline__ uint32_t u16(uint32_t o) const { uint16_t v; __builtin_memcpy(&v, p + o, 2); return v; }
+    __device__ __forceinline__ uint32_t u8(uint32_t o) const { return p[o]; }
+};
+struct LdsSt {
+    uint8_t* p;
+    __device__ __forceinline__ void u64(uint32_t o, uint64_t v) const { __builtin_memcpy(p + o, &v, 8); }
+    __device__ __forceinline__ void u32(uint32_t o, uint32_t v) const { __builtin_memcpy(p + o, &v, 4); }
+    __device__ __forceinline__ void u16(uint32_t o, uint32_t v) const { uint16_t w = (uint16_t)v; __builtin_memcpy(p + o, &w, 2); }
+    __device__ __forceinline__ void u8(uint32_t o, uint32_t v) const { p[o] = (uint8_t)v; }
+};
+
+struct ExecCtx {
+    uint8_t* dst;            // the file's output buffer
+    uint64_t frame_start;    // offset of the current frame's first byte in dst
+    uint64_t cap;
+    const uint8_t* dict;     // dictionary content (logically just before frame_start) or null
+    uint32_t dict_len;
+    const uint8_t* lit;      // literal buffer of the block
+    uint32_t nlit;
+};
+
+__device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_in, const ExecCtx& cx, uint64_t* opos_io, uint32_t* rep, int lane) {
+    const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
+    uint8_t* const dst = cx.dst;
+    const uint8_t* const lit = cx.lit;
+    uint8_t* const stage = S.stage;
     uint64_t opos = *opos_io;
     const uint64_t block_start = opos;
     uint32_t lpos = 0;
+    uint32_t r0 = __builtin_amdgcn_readfirstlane(rep[0]), r1 = __builtin_amdgcn_readfirstlane(rep[1]), r2 = __builtin_amdgcn_readfirstlane(rep[2]);
     for (uint32_t base = 0; base < nseq; base += 64) {
-        uint32_t i = base + (uint32_t)lane;
-        bool valid = i < nseq;
-        uint4 s = valid ? seqs[i] : make_uint4(0, 0, 0, 0);
-        uint32_t ll = s.x, ml = s.y, off = s.z;
-        uint32_t incl_t = wave_incl_scan(ll + ml, lane), incl_l = wave_incl_scan(ll, lane);
-        uint32_t chunk_tot = __shfl(incl_t, 63), chunk_lit = __shfl(incl_l, 63);
-        if (chunk_lit > nlit - lpos) return MZD_E_CORRUPT;
-        if ((opos - block_start) + chunk_tot > kBlockMax) return MZD_E_CORRUPT;
-        if (chunk_tot > cap - opos) return MZD_E_DSTSIZE;
-        uint32_t rel_out = incl_t - (ll + ml);      // relative to opos
-        uint32_t my_lit = lpos + (incl_l - ll);
-        uint32_t rel_m = rel_out + ll;               // match destination, relative
-        uint64_t mdst = opos + rel_m;
-        uint64_t avail = (mdst - frame_start) + dict_len;
-        bool bad = valid && ml && (off == 0 || off > avail);
-        if (__any(bad)) return MZD_E_CORRUPT;
-        // ---- literals
-        uint64_t longl = __ballot(ll > kLongCopy);
-        while (longl) {
-            int src_lane = __builtin_ctzll(longl);
-            longl &= longl - 1;
-            uint32_t l = __shfl(ll, src_lane), ro = __shfl(rel_out, src_lane), lp = __shfl(my_lit, src_lane);
-            wave_copy(dst + opos + ro, lit + lp, l, lane);
-        }
-        if (ll <= kLongCopy) {
-            uint8_t* d = dst + opos + rel_out;
-            const uint8_t* sp = lit + my_lit;
-            for (uint32_t k = 0; k < ll; k++) d[k] = sp[k];
-        }
-        wg_fence();
-        // ---- matches
-        bool pending = valid && ml > 0;
-        // matches that start inside the dictionary: handled by the owning lane, byte by byte
-        if (pending && off > mdst - frame_start) {
-            uint64_t back = off - (mdst - frame_start);
-            const uint8_t* dp = dict + dict_len - back;
-            uint8_t* d = dst + mdst;
-            uint32_t k = 0;
-            for (; k < ml && k < back; k++) d[k] = dp[k];
-            // remainder continues from the start of the frame's own output
-            // (source index k - back relative to frame_start), sequential semantics
-            for (; k < ml; k++) d[k] = dst[frame_start + (k - back)];
-            pending = false;
-        }
-        int64_t rel_src = (int64_t)rel_m - (int64_t)off; // may be far negative: earlier chunks
-        uint32_t span = ml < off ? ml : off;             // bytes of source actually distinct
-        uint64_t pm = __ballot(pending);
-        while (pm) {
-            int first = __builtin_ctzll(pm);
-            int64_t hwm = (int64_t)__shfl(rel_m, first);
-            bool ready = pending && (rel_src + (int64_t)span <= hwm);
-            uint64_t rlong = __ballot(ready && ml > kLongCopy);
-            while (rlong) {
-                int sl_ = __builtin_ctzll(rlong);
-                rlong &= rlong - 1;
-                uint32_t m = __shfl(ml, sl_), o = __shfl(off, sl_), rm = __shfl(rel_m, sl_);
-                uint8_t* d = dst + opos + rm;
-                if (o >= m) wave_copy(d, d - o, m, lane);
-                else wave_pattern(d, o, m, lane);
+        const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
+        const uint32_t i = base + (uint32_t)lane;
+        const bool valid = (uint32_t)lane < cnt;
+        uint4 sq = valid ? seqs[i] : make_uint4(0, 0, 4, 0);
+        const uint32_t ll = sq.x, ml = sq.y, ofv = sq.z;
+        // ---- 1. repeat offsets
+        uint32_t off;
+        {
+            RepOp op;
+            uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
+            if (!valid || (ofv <= 3 && idx == 0)) { op.s = 0 | (1 << 2) | (2 << 4); op.v0 = 0; op.v1 = 0; op.v2 = 0; }
+            else if (ofv > 3) { op.s = 3 | (0 << 2) | (1 << 4); op.v0 = (int32_t)(ofv - 3); op.v1 = 0; op.v2 = 0; }
+            else if (idx == 1) { op.s = 1 | (0 << 2) | (2 << 4); op.v0 = 0; op.v1 = 0; op.v2 = 0; }
+            else if (idx == 2) { op.s = 2 | (0 << 2) | (1 << 4); op.v0 = 0; op.v1 = 0; op.v2 = 0; }
+            else { op.s = 0 | (0 << 2) | (1 << 4); op.v0 = -1; op.v1 = 0; op.v2 = 0; }
+            RepOp acc = op; // inclusive scan: acc = op_lane o ... o op_0
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                RepOp f;
+                f.s = __shfl_up(acc.s, d); f.v0 = __shfl_up(acc.v0, d); f.v1 = __shfl_up(acc.v1, d); f.v2 = __shfl_up(acc.v2, d);
+                if (lane >= d) acc = rep_compose(acc, f);
             }
-            if (ready && ml <= kLongCopy) {
-                uint8_t* d = dst + mdst;
-                const uint8_t* sp = d - off;
-                uint32_t idx = 0;
-                for (uint32_t k = 0; k < ml; k++) {
-                    d[k] = sp[idx];
-                    idx++;
-                    if (idx == off) idx = 0;
+            RepOp before; // exclusive
+            before.s = __shfl_up(acc.s, 1); before.v0 = __shfl_up(acc.v0, 1); before.v1 = __shfl_up(acc.v1, 1); before.v2 = __shfl_up(acc.v2, 1);
+            if (lane == 0) { before.s = 0 | (1 << 2) | (2 << 4); before.v0 = 0; before.v1 = 0; before.v2 = 0; }
+            uint32_t b0 = rep_eval(before, 0, r0, r1, r2), b1 = rep_eval(before, 1, r0, r1, r2), b2 = rep_eval(before, 2, r0, r1, r2);
+            if (ofv > 3) off = ofv - 3;
+            else off = idx == 0 ? b0 : (idx == 1 ? b1 : (idx == 2 ? b2 : b0 - 1));
+            uint32_t e0 = rep_eval(acc, 0, r0, r1, r2), e1 = rep_eval(acc, 1, r0, r1, r2), e2 = rep_eval(acc, 2, r0, r1, r2);
+            r0 = __builtin_amdgcn_readlane(e0, 63); r1 = __builtin_amdgcn_readlane(e1, 63); r2 = __builtin_amdgcn_readlane(e2, 63);
+            if (valid) seqs[i].z = off; // keep the resolved triple (mzd_debug_last_block / phase tests)
+        }
+        // ---- 2. positions
+        const uint32_t tot = ll + ml;
+        const uint32_t incl_t = wave_incl_scan(tot, lane), incl_l = wave_incl_scan(ll, lane);
+        const uint32_t chunk_tot = __builtin_amdgcn_readlane(incl_t, 63), chunk_lit = __builtin_amdgcn_readlane(incl_l, 63);
+        if (chunk_lit > cx.nlit - lpos) return MZD_E_CORRUPT;
+        if ((opos - block_start) + chunk_tot > kBlockMax) return MZD_E_CORRUPT;
+        if (chunk_tot > cx.cap - opos) return MZD_E_DSTSIZE;
+        const uint32_t ex_t = incl_t - tot;                 // this sequence's output offset inside the 64-chunk
+        const uint32_t my_lit = lpos + (incl_l - ll);
+        const uint64_t mdst = opos + ex_t + ll;              // absolute match destination
+        const uint64_t avail = (mdst - cx.frame_start) + cx.dict_len;
+        if (__any(valid && (off == 0 || off > avail))) return MZD_E_CORRUPT;
+        const bool in_dict = valid && off > mdst - cx.frame_start;
+        const bool islong = valid && (ll > kShort || ml > kShort || in_dict);
+
+        // ---- 3/4. runs of short sequences through LDS, long ones directly
+        uint32_t a = 0;
+        while (a < cnt) {
+            const uint32_t base_t = __builtin_amdgcn_readlane(ex_t, a);
+            const uint64_t run_pos = opos + base_t; // absolute output position of lane a's literals
+            if ((__ballot(islong) >> a) & 1) {
+                const uint32_t l = __builtin_amdgcn_readlane(ll, a), m = __builtin_amdgcn_readlane(ml, a);
+                const uint32_t o = __builtin_amdgcn_readlane(off, a), lp = __builtin_amdgcn_readlane(my_lit, a);
+                wg_fence(); // earlier flushes are visible
+                wave_copy(dst + run_pos, lit + lp, l, lane);
+                wg_fence();
+                uint8_t* d = dst + run_pos + l;
+                const uint64_t have = run_pos + l - cx.frame_start;
+                if (o > have) { // starts inside the dictionary: owner lane, sequential semantics
+                    if ((uint32_t)lane == a) {
+                        uint64_t back = o - have;
+                        const uint8_t* dp = cx.dict + cx.dict_len - back;
+                        uint32_t k = 0;
+                        for (; k < m && k < back; k++) d[k] = dp[k];
+                        for (; k < m; k++) d[k] = dst[cx.frame_start + (k - back)];
+                    }
+                } else if (o >= m) wave_copy(d, d - o, m, lane);
+                else wave_pattern(d, o, m, lane);
+                wg_fence();
+                a++;
+                continue;
+            }
+            // run [a, b): short sequences whose bytes fit the staging buffer
+            const uint64_t stop = __ballot(valid && (uint32_t)lane > a && (islong || incl_t - base_t > kStage));
+            const uint32_t b = stop ? (uint32_t)__builtin_ctzll(stop) : cnt;
+            const uint32_t T = __builtin_amdgcn_readlane(incl_t, b - 1) - base_t;
+            const bool act = (uint32_t)lane >= a && (uint32_t)lane < b;
+            const uint32_t rel_out = ex_t - base_t, rel_m = rel_out + ll;
+            // literals: HBM -> LDS
+            if (act && ll) copy_short(ll, GlobalLd{lit + my_lit}, LdsSt{stage + rel_out});
+            // matches whose whole source lies before the run: HBM -> LDS (earlier flushes must have landed)
+            const int64_t rel_src = (int64_t)rel_m - (int64_t)off;
+            const bool plain = off >= ml; // source and destination do not overlap
+            wg_fence();
+            bool pending = act && ml > 0;
+            if (pending && plain && rel_src + (int64_t)ml <= 0) {
+                copy_short(ml, GlobalLd{dst + run_pos + rel_src}, LdsSt{stage + rel_m});
+                pending = false;
+            }
+            // the rest in rounds, LDS -> LDS
+            const uint32_t span = ml < off ? ml : off;
+            uint64_t pm = __ballot(pending);
+            while (pm) {
+                const int first = __builtin_ctzll(pm);
+                const int64_t hwm = (int64_t)__builtin_amdgcn_readlane(rel_m, first);
+                const bool ready = pending && rel_src + (int64_t)span <= hwm;
+                if (ready) {
+                    if (plain && rel_src >= 0) copy_short(ml, LdsLd{stage + rel_src}, LdsSt{stage + rel_m});
+                    else { // overlapping match, or a source that straddles the start of the run
+                        uint32_t idx = 0;
+                        for (uint32_t k = 0; k < ml; k++) {
+                            int64_t p = rel_src + idx;
+                            stage[rel_m + k] = p < 0 ? dst[run_pos + p] : stage[p];
+                            idx++;
+                            if (idx == off) idx = 0;
+                        }
+                    }
+                }
+                pending = pending && !ready;
+                pm = __ballot(pending);
+            }
+            // flush the run: LDS -> HBM, 16 bytes per lane
+            {
+                uint8_t* g = dst + run_pos;
+                for (uint32_t k = (uint32_t)lane * 16; k < T; k += 1024) {
+                    if (k + 16 <= T) {
+                        uint4 v = *reinterpret_cast<const uint4*>(stage + k);
+                        __builtin_memcpy(g + k, &v, 16);
+                    } else {
+                        for (uint32_t j = k; j < T; j++) g[j] = stage[j];
+                    }
                 }
             }
-            pending = pending && !ready;
-            wg_fence();
-            pm = __ballot(pending);
+            a = b;
         }
         opos += chunk_tot;
         lpos += chunk_lit;
     }
-    uint32_t rest = nlit - lpos;
-    if (rest > cap - opos) return MZD_E_DSTSIZE;
+    const uint32_t rest = cx.nlit - lpos;
+    if (rest > cx.cap - opos) return MZD_E_DSTSIZE;
     if ((opos - block_start) + rest > kBlockMax) return MZD_E_CORRUPT;
     wave_copy(dst + opos, lit + lpos, rest, lane);
     opos += rest;
     wg_fence();
     *opos_io = opos;
+    if (lane == 0) { rep[0] = r0; rep[1] = r1; rep[2] = r2; }
     return 0;
 }
 
@@ -896,6 +1076,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* const lit_buf = a.lit_scratch + (size_t)blockIdx.x * kLitStride;
     uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
+    uint2* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
     Ctl& c = S.c;
 
     for (;;) {
@@ -993,12 +1174,22 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         if (err) break;
                     }
                     STAMP(4);
-                    if (wave == 0) { // K4 + K5 on one wavefront
+                    if (nseq) { // K4: serial state walk on one wavefront, then field conversion on all four
+                        if (wave == 0) {
+                            int rc = walk_sequences_wave(S, src + seq_off, seq_len, nseq, walk, lane);
+                            if (rc && lane == 0) c.err = rc;
+                        }
+                        WG_SNAPSHOT(err = c.err);
+                        if (err) break;
+                        STAMP(5);
+                        convert_sequences(S, src + seq_off, nseq, walk, seqs, tid);
+                        __syncthreads();
+                    }
+                    if (wave == 0) { // K5
                         int rc = 0;
                         uint64_t opos = out0;
-                        if (nseq) rc = decode_sequences_wave(S, src + seq_off, seq_len, nseq, seqs, lane);
-                        STAMP(5);
-                        if (!rc) rc = execute_wave(seqs, nseq, lit, nlit, dst, c.frame_out0, &opos, cap, c.dict_content, c.dict_content_len, lane);
+                        ExecCtx cx{dst, c.frame_out0, cap, c.dict_content, c.dict_content_len, lit, nlit};
+                        rc = execute_wave(S, seqs, nseq, cx, &opos, c.rep, lane);
                         if (lane == 0) {
                             if (rc) c.err = rc;
                             if (nseq) c.fse_valid = 1;
