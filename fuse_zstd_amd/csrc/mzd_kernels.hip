@@ -47,6 +47,8 @@ struct Ctl {
     uint32_t lit_type, nlit, streams, huf_log, huf_valid, huf_nw;
     uint32_t s_off[4], s_len[4], s_out[4], s_n[4];
     uint32_t lit_is_raw;
+    uint32_t huf_tree_off, huf_tree_len;           // Huffman tree description inside the block
+    uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
     uint32_t nseq, mode[3], al[3], nsym[3], fse_valid, seq_len;
     uint32_t rep[3];
     uint32_t dict_content_len;
@@ -110,6 +112,19 @@ __device__ const uint8_t ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0
 __device__ const int16_t LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
 __device__ const int16_t ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
 __device__ const int16_t OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+// Intra-workgroup flags in LDS (the block pipeline): relaxed atomics + workgroup fences.  Every spin
+// also ends when an error is posted, and is bounded.
+__device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void flag_store(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+__device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want, const int32_t* err) {
+    for (uint32_t it = 0; it < (1u << 24); it++) {
+        if (flag_load(p) >= want) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
+        if (__atomic_load_n(err, __ATOMIC_RELAXED)) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
 
 // ------------------------------------------------------------------------------------ K3
 // Normalized-count header (A.3), forward bitstream.  Lane 0.  Returns bytes used or < 0.
@@ -209,7 +224,7 @@ __device__ __noinline__ int read_huf_weights(Shared& S, const uint8_t* src, uint
         if (hdr <= 0) return MZD_E_CORRUPT;
         // tiny FSE table (<= 64 entries) built in place
         uint32_t size = 1u << log, high = size;
-        uint16_t* next = (uint16_t*)(void*)S.ring; // the ring is idle during literal decoding
+        uint16_t* next = (uint16_t*)(void*)S.stage; // the executor's staging buffer is idle until the literals exist
         for (uint32_t s = 0; s < nsym; s++)
             if (S.wnorm[s] == -1) { high--; S.wtab[high] = s; next[s] = 1; }
         uint32_t step = (size >> 1) + (size >> 3) + 3, pos = 0, mask = size - 1;
@@ -276,15 +291,17 @@ __device__ __noinline__ int read_huf_weights(Shared& S, const uint8_t* src, uint
 }
 
 // Canonical table fill by all 256 lanes: lane s owns symbol s.
-__device__ __noinline__ void fill_huf_table(Shared& S, int tid) {
-    uint32_t wt = S.weights[tid];
-    if (wt) {
-        uint32_t before = 0;
-        for (int s = 0; s < tid; s++) before += (S.weights[s] == wt);
-        uint32_t cnt = 1u << (wt - 1);
-        uint32_t at = S.rank_start[wt] + before * cnt;
-        uint16_t e = (uint16_t)((uint32_t)tid | ((S.c.huf_log + 1 - wt) << 8));
-        for (uint32_t i = 0; i < cnt; i++) S.huf[at + i] = e;
+__device__ __noinline__ void fill_huf_table(Shared& S, int first, int stride) {
+    for (int sym = first; sym < 256; sym += stride) {
+        uint32_t wt = S.weights[sym];
+        if (wt) {
+            uint32_t before = 0;
+            for (int s = 0; s < sym; s++) before += (S.weights[s] == wt);
+            uint32_t cnt = 1u << (wt - 1);
+            uint32_t at = S.rank_start[wt] + before * cnt;
+            uint16_t e = (uint16_t)((uint32_t)sym | ((S.c.huf_log + 1 - wt) << 8));
+            for (uint32_t i = 0; i < cnt; i++) S.huf[at + i] = e;
+        }
     }
 }
 
@@ -408,6 +425,84 @@ __device__ __noinline__ void wave_pattern(uint8_t* d, uint32_t off, uint32_t n, 
     }
 }
 
+// ------------------------------------------------------------------------------------ K3 (wave-parallel)
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= d && t > v) v = t;
+    }
+    return v;
+}
+
+// FSE decode table (A.3) built by the 64 lanes of one wavefront; same result as build_seq_table.
+//   A (lane = symbol)  counts -> low-probability symbols at the top, slot ranges by a scan
+//   B (lane = 8 slots) slot -> symbol by a max-scan over range-start marks
+//   C (lane = step j)  position (j*step)&mask, ranked among the positions below `high` by ballot
+//   D (lane = symbol)  state numbering in table order: every symbol walks the table once
+// tmp: 1 KiB of LDS scratch (tabsym[512], mark[512]).
+__device__ __noinline__ void build_seq_table_wave(uint64_t* tab, const int16_t* norm, uint32_t nsym, uint32_t log, int kind, uint8_t* tmp, int lane) {
+    uint8_t* const tabsym = tmp;
+    uint8_t* const mark = tmp + 512;
+    const uint32_t size = 1u << log, mask = size - 1;
+    for (uint32_t k = lane; k < size; k += 64) mark[k] = 0;
+    // A
+    const int c = (uint32_t)lane < nsym ? norm[lane] : 0;
+    const uint32_t is_low = c == -1 ? 1u : 0u, p = c > 0 ? (uint32_t)c : 0u;
+    const uint32_t low_incl = wave_incl_scan(is_low, lane), p_incl = wave_incl_scan(p, lane);
+    const uint32_t n_low = __builtin_amdgcn_readlane(low_incl, 63);
+    const uint32_t high = size - n_low;
+    if (is_low) tabsym[size - low_incl] = (uint8_t)lane; // first low symbol -> size-1, next -> size-2, ...
+    if (p) mark[p_incl - p] = (uint8_t)lane;
+    // B: slotSym[k] = max mark at or before k (symbols ascend with k; symbol 0's mark is 0 like "no mark")
+    {
+        const uint32_t k0 = (uint32_t)lane * 8;
+        uint32_t m[8], run = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) { uint32_t v = k0 + t < size ? mark[k0 + t] : 0; run = v > run ? v : run; m[t] = run; }
+        uint32_t incl = wave_incl_max(run, lane);
+        uint32_t prev = __shfl_up(incl, 1);
+        if (lane == 0) prev = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) if (k0 + t < size) mark[k0 + t] = (uint8_t)(m[t] > prev ? m[t] : prev);
+    }
+    // C
+    {
+        const uint32_t step = (size >> 1) + (size >> 3) + 3;
+        uint32_t running = 0;
+        for (uint32_t j0 = 0; j0 < size; j0 += 64) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const uint32_t pj = (j * step) & mask;
+            const bool v = j < size && pj < high;
+            const uint64_t bal = __ballot(v);
+            const uint32_t k = running + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1));
+            if (v) tabsym[pj] = mark[k];
+            running += (uint32_t)__builtin_popcountll(bal);
+        }
+    }
+    // D: 16 table positions per LDS read (every lane reads the same 16 bytes: a broadcast)
+    {
+        const bool mine = (uint32_t)lane < nsym && c != 0;
+        uint32_t d = c == -1 ? 1u : (uint32_t)c;
+        const uint32_t extra = mine ? code_extra((uint32_t)lane, kind) : 0;
+        const uint32_t hi_const = ((uint32_t)lane << 16) | (extra << 24);
+        for (uint32_t i0 = 0; i0 < size; i0 += 16) {
+            const uint4 w = *reinterpret_cast<const uint4*>(tabsym + i0);
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const uint32_t sy = (ww[t >> 2] >> ((t & 3) * 8)) & 0xFF;
+                if (mine && sy == (uint32_t)lane) {
+                    const uint32_t nb = log - (uint32_t)hibit(d);
+                    const uint32_t hi = nb | ((extra + nb) << 8) | hi_const;
+                    tab[i0 + t] = (uint64_t)(((d << nb) - size) * 8u) | ((uint64_t)hi << 32);
+                    d++;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ K4
 // FSE sequence decode (A.5), split in two:
 //
@@ -417,8 +512,9 @@ __device__ __noinline__ void wave_pattern(uint8_t* d, uint32_t off, uint32_t n, 
 //      so the loop does only what the chain needs: three table reads + one 8-byte bitstream
 //      window (all LDS, issued together), the bit budget of the sequence, the three state updates.
 //      Per sequence it records {bit position, three states} (8 bytes) and nothing else.
-//  (b) convert_sequences -- everything that is NOT a chain: extra bits, base values.  One lane per
-//      sequence, all 256 lanes, straight from the records of (a).
+//  (b) field conversion -- everything that is NOT a chain: extra bits, base values.  One lane per
+//      sequence, straight from the records of (a); done by the executing wavefront (execute_wave),
+//      64 sequences at a time, while the walker is already further down the stream.
 //  Repeat-offset resolution (a chain again, but a cheap one) happens in execute_wave.
 //
 // The bitstream is read backwards through an 8 KiB LDS ring, filled 1 KiB at a time with one 16-byte
@@ -466,7 +562,9 @@ __device__ __forceinline__ uint64_t ring_read64(const Shared& S, uint32_t e) {
 //   (state offsets are byte offsets into the tables: 8 * state)
 constexpr uint32_t kWalkBatch = 32; // sequences between two ring checks (<= 89 bits each)
 
-__device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint2* walk, int lane) {
+constexpr uint32_t kWalkFin = 0x80000000u;
+
+__device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint2* walk, uint32_t* prog, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
     // a global (not flat) pointer: flat stores would also count on lgkmcnt, i.e. sit in the LDS waits below
     __attribute__((address_space(1))) uint64_t* const gwalk = (__attribute__((address_space(1))) uint64_t*)walk;
@@ -553,6 +651,9 @@ __device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, ui
             G -= total;
         }
         if ((int32_t)(G - Gzero) < 0) return MZD_E_CORRUPT; // over-read
+        // publish the batch BEFORE this one: all but the newest kWalkBatch stores have landed
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        if (lane == 0 && i >= kWalkBatch) flag_store(prog, i - kWalkBatch);
     }
     // last sequence: extra bits only
     {
@@ -564,7 +665,7 @@ __device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, ui
         uint32_t extra = (uint32_t)(eL >> 56) + (uint32_t)(eM >> 56) + (uint32_t)(eO >> 56);
         if (G - Gzero != extra) return MZD_E_CORRUPT; // the bitstream must be consumed exactly
     }
-    return 0;
+    return 0; // the caller publishes nseq | kWalkFin after a release fence
 }
 
 // n bits (n <= 32) whose top is g-bit `top` (exclusive), read from HBM
@@ -572,23 +673,6 @@ __device__ __forceinline__ uint32_t stream_bits(const uint8_t* gbase, uint32_t t
     uint32_t lo = top - n;
     uint64_t v = ldu64(gbase + (lo >> 3)) >> (lo & 7);
     return n ? (uint32_t)v & (uint32_t)((1ull << n) - 1) : 0u;
-}
-
-// (b): one lane per sequence -> {ll, ml, offset_value, 0}.  All 256 lanes.
-__device__ void convert_sequences(const Shared& S, const uint8_t* sp, uint32_t nseq, const uint2* walk, uint4* seqs, int tid) {
-    const uint32_t bias = 16 + (uint32_t)((uintptr_t)sp & 15);
-    const uint8_t* gbase = sp - bias;
-    for (uint32_t i = tid; i < nseq; i += kWG) {
-        uint2 w = walk[i];
-        uint32_t vL = w.x & 0xFFF, vM = w.x >> 12, vO = w.y >> 21, G = w.y & 0x1FFFFF;
-        uint32_t hL = (uint32_t)(S.ll[vL >> 3] >> 32), hM = (uint32_t)(S.ml[vM >> 3] >> 32), hO = (uint32_t)(S.of[vO >> 3] >> 32);
-        uint32_t cL = (hL >> 16) & 0xFF, cM = (hM >> 16) & 0xFF, cO = (hO >> 16) & 0xFF;
-        uint32_t xL = hL >> 24, xM = hM >> 24, xO = hO >> 24;
-        uint32_t ofv = (1u << cO) + stream_bits(gbase, G, xO);
-        uint32_t ml = ML_BASE[cM] + stream_bits(gbase, G - xO, xM);
-        uint32_t ll = LL_BASE[cL] + stream_bits(gbase, G - xO - xM, xL);
-        seqs[i] = make_uint4(ll, ml, ofv, 0);
-    }
 }
 
 // ------------------------------------------------------------------------------------ K5
@@ -675,6 +759,10 @@ struct LdsSt {
 };
 
 struct ExecCtx {
+    const uint2* walk;       // state-walk records of the block (HBM scratch)
+    const uint8_t* seq_sp;   // the block's sequence bitstream
+    const uint32_t* prog;    // walker progress (LDS)
+    const int32_t* err;      // workgroup error word (LDS)
     uint8_t* dst;            // the file's output buffer
     uint64_t frame_start;    // offset of the current frame's first byte in dst
     uint64_t cap;
@@ -697,8 +785,31 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
         const uint32_t i = base + (uint32_t)lane;
         const bool valid = (uint32_t)lane < cnt;
-        uint4 sq = valid ? seqs[i] : make_uint4(0, 0, 4, 0);
-        const uint32_t ll = sq.x, ml = sq.y, ofv = sq.z;
+        // wait for the walker to be 64 sequences ahead, then K4(b): fields of this lane's sequence
+        {
+            const uint32_t need = base + cnt;
+            uint32_t pg = 0;
+            for (uint32_t it = 0; it < (1u << 24); it++) {
+                pg = flag_load(cx.prog);
+                if ((pg & ~kWalkFin) >= need || (pg & kWalkFin)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if ((pg & ~kWalkFin) < need) return MZD_E_CORRUPT; // the walker failed (it posted the error) or never got there
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        uint32_t ll = 0, ml = 0, ofv = 4;
+        if (valid) {
+            const uint32_t bias = 16 + (uint32_t)((uintptr_t)cx.seq_sp & 15);
+            const uint8_t* gbase = cx.seq_sp - bias;
+            uint2 w = cx.walk[i];
+            uint32_t vL = w.x & 0xFFF, vM = w.x >> 12, vO = w.y >> 21, G = w.y & 0x1FFFFF;
+            uint32_t hL = (uint32_t)(S.ll[vL >> 3] >> 32), hM = (uint32_t)(S.ml[vM >> 3] >> 32), hO = (uint32_t)(S.of[vO >> 3] >> 32);
+            uint32_t cL = (hL >> 16) & 0xFF, cM = (hM >> 16) & 0xFF, cO = (hO >> 16) & 0xFF;
+            uint32_t xL = hL >> 24, xM = hM >> 24, xO = hO >> 24;
+            ofv = (1u << cO) + stream_bits(gbase, G, xO);
+            ml = ML_BASE[cM] + stream_bits(gbase, G - xO, xM);
+            ll = LL_BASE[cL] + stream_bits(gbase, G - xO - xM, xL);
+        }
         // ---- 1. repeat offsets
         uint32_t off;
         {
@@ -724,7 +835,7 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
             else off = idx == 0 ? b0 : (idx == 1 ? b1 : (idx == 2 ? b2 : b0 - 1));
             uint32_t e0 = rep_eval(acc, 0, r0, r1, r2), e1 = rep_eval(acc, 1, r0, r1, r2), e2 = rep_eval(acc, 2, r0, r1, r2);
             r0 = __builtin_amdgcn_readlane(e0, 63); r1 = __builtin_amdgcn_readlane(e1, 63); r2 = __builtin_amdgcn_readlane(e2, 63);
-            if (valid) seqs[i].z = off; // keep the resolved triple (mzd_debug_last_block / phase tests)
+            if (valid) seqs[i] = make_uint4(ll, ml, off, 0); // the resolved triple (mzd_debug_last_block / phase tests)
         }
         // ---- 2. positions
         const uint32_t tot = ll + ml;
@@ -973,10 +1084,13 @@ __device__ __noinline__ void parse_literals(Shared& S, const uint8_t* b, uint32_
     if (regen > c.block_max || regen == 0 || (streams == 4 && regen < 6) || hs + comp > n) { c.err = MZD_E_CORRUPT; return; }
     const uint8_t* p = b + hs;
     uint32_t rem = comp;
-    if (type == 2) {
-        int used = read_huf_weights(S, p, rem);
-        if (used <= 0) { c.err = MZD_E_CORRUPT; return; }
-        p += used; rem -= (uint32_t)used;
+    if (type == 2) { // the tree is decoded later by another wavefront; here only its extent
+        if (rem < 1) { c.err = MZD_E_CORRUPT; return; }
+        uint32_t hb = p[0];
+        uint32_t tl = hb >= 128 ? 1 + ((hb - 127) + 1) / 2 : 1 + hb;
+        if (tl > rem) { c.err = MZD_E_CORRUPT; return; }
+        c.huf_tree_off = (uint32_t)(p - b); c.huf_tree_len = tl;
+        p += tl; rem -= tl;
     } else if (!c.huf_valid) { c.err = MZD_E_CORRUPT; return; }
     uint32_t base = (uint32_t)(p - b); // offset of the streams inside the block
     if (streams == 1) {
@@ -1033,25 +1147,24 @@ __device__ __noinline__ void parse_seq_header(Shared& S, const uint8_t* b, uint3
     c.seq_len = (uint32_t)(end - p);
 }
 
-__device__ __noinline__ void build_tables_wave(Shared& S, int wave, int lane) {
-    // wave t builds table t (0 LL, 1 OF, 2 ML); lane 0 of each does the work
-    if (wave > 2 || lane != 0) return;
+// The three sequence tables of a block, built one after the other by ONE wavefront.
+__device__ __noinline__ void build_tables_wave(Shared& S, int lane) {
     Ctl& c = S.c;
-    int t = wave;
-    uint64_t* tab = t == 0 ? S.ll : (t == 1 ? S.of : S.ml);
-    uint32_t m = c.mode[t];
-    int rc = 0;
-    if (m == 0) {
-        if (t == 0) { for (int i = 0; i < 36; i++) S.norm[0][i] = LL_DEF[i]; rc = build_seq_table(tab, S.norm[0], S.next[0], 36, 6, 0); c.al[0] = 6; }
-        else if (t == 1) { for (int i = 0; i < 29; i++) S.norm[1][i] = OF_DEF[i]; rc = build_seq_table(tab, S.norm[1], S.next[1], 29, 5, 1); c.al[1] = 5; }
-        else { for (int i = 0; i < 53; i++) S.norm[2][i] = ML_DEF[i]; rc = build_seq_table(tab, S.norm[2], S.next[2], 53, 6, 2); c.al[2] = 6; }
-    } else if (m == 1) {
-        rle_seq_table(tab, c.nsym[t], t);
-        c.al[t] = 0;
-    } else if (m == 2) {
-        rc = build_seq_table(tab, S.norm[t], S.next[t], c.nsym[t], c.al[t], t);
+    for (int t = 0; t < 3; t++) {
+        uint64_t* tab = t == 0 ? S.ll : (t == 1 ? S.of : S.ml);
+        const uint32_t m = c.mode[t];
+        if (m == 0) {
+            const int16_t* def = t == 0 ? LL_DEF : (t == 1 ? OF_DEF : ML_DEF);
+            const uint32_t n = t == 0 ? 36 : (t == 1 ? 29 : 53), lg = t == 1 ? 5 : 6;
+            if ((uint32_t)lane < n) S.norm[t][lane] = def[lane];
+            build_seq_table_wave(tab, S.norm[t], n, lg, t, S.ring, lane);
+            if (lane == 0) c.al[t] = lg;
+        } else if (m == 1) {
+            if (lane == 0) { rle_seq_table(tab, c.nsym[t], t); c.al[t] = 0; }
+        } else if (m == 2) {
+            build_seq_table_wave(tab, S.norm[t], c.nsym[t], c.al[t], t, S.ring, lane);
+        }
     }
-    if (rc) c.err = rc;
 }
 
 // Control words live in LDS and are written by lane 0 (or one lane per wavefront).  Every
@@ -1142,67 +1255,86 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                 } else {
                     const uint8_t* const blk = src + pos0;
                     STAMP(0);
-                    if (tid == 0) parse_literals(S, blk, bsize); // K1 (weights)
-                    uint32_t lit_type = 0, nlit = 0, streams = 0, huf_log = 0;
-                    uint64_t lit_off = 0;
-                    WG_SNAPSHOT(err = c.err; lit_type = c.lit_type; nlit = c.nlit; streams = c.streams; huf_log = c.huf_log; lit_off = c.lit_off);
+                    if (tid == 0) { // K0/K1/K3 headers: where everything is; nothing is decoded yet
+                        c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0;
+                        parse_literals(S, blk, bsize);
+                        if (!c.err) parse_seq_header(S, src + c.seq_off, c.seq_len);
+                    }
+                    uint32_t lit_type = 0, nlit = 0, streams = 0, nseq = 0, seq_len = 0;
+                    uint64_t lit_off = 0, seq_off = 0;
+                    WG_SNAPSHOT(err = c.err; lit_type = c.lit_type; nlit = c.nlit; streams = c.streams; lit_off = c.lit_off;
+                                nseq = c.nseq; seq_off = c.seq_off; seq_len = c.seq_len);
                     if (err) break;
                     STAMP(1);
-                    if (lit_type == 2) { // K1 (table)
-                        fill_huf_table(S, tid);
-                        if (tid == 0) c.huf_valid = 1;
-                        __syncthreads();
-                    }
-                    STAMP(2);
-                    // K2: literals; lane 0 then parses the sequences header (K3)
-                    const uint8_t* lit = lit_buf;
-                    if (lit_type == 0) lit = src + lit_off;
-                    else if (lit_type == 1) wg_fill(lit_buf, src[lit_off], nlit, tid);
-                    else if ((uint32_t)wave < streams) {
-                        int rc = huf_stream_wave(blk + c.s_off[wave], c.s_len[wave], lit_buf + c.s_out[wave], c.s_n[wave], S.huf, huf_log, lane);
-                        if (rc && lane == 0) c.err = rc;
-                    }
-                    if (tid == 0) parse_seq_header(S, src + c.seq_off, c.seq_len);
-                    uint32_t nseq = 0, seq_len = 0;
-                    uint64_t seq_off = 0;
-                    WG_SNAPSHOT(err = c.err; nseq = c.nseq; seq_off = c.seq_off; seq_len = c.seq_len);
-                    if (err) break;
-                    STAMP(3);
-                    if (nseq) { // K3 tables
-                        build_tables_wave(S, wave, lane);
-                        WG_SNAPSHOT(err = c.err);
-                        if (err) break;
-                    }
-                    STAMP(4);
-                    if (nseq) { // K4: serial state walk on one wavefront, then field conversion on all four
-                        if (wave == 0) {
-                            int rc = walk_sequences_wave(S, src + seq_off, seq_len, nseq, walk, lane);
-                            if (rc && lane == 0) c.err = rc;
-                        }
-                        WG_SNAPSHOT(err = c.err);
-                        if (err) break;
-                        STAMP(5);
-                        convert_sequences(S, src + seq_off, nseq, walk, seqs, tid);
-                        __syncthreads();
-                    }
-                    if (wave == 0) { // K5
-                        int rc = 0;
-                        uint64_t opos = out0;
-                        ExecCtx cx{dst, c.frame_out0, cap, c.dict_content, c.dict_content_len, lit, nlit};
-                        rc = execute_wave(S, seqs, nseq, cx, &opos, c.rep, lane);
-                        if (lane == 0) {
-                            if (rc) c.err = rc;
-                            if (nseq) c.fse_valid = 1;
-                            c.out = opos; c.pos = pos0 + bsize;
-                            STAMP(6);
-                            if (a.debug) {
-                                DebugSlot& ds = a.debug[blockIdx.x];
-                                ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0; ds.lit_raw_ptr = (uint64_t)(uintptr_t)lit;
+                    const uint8_t* const lit = lit_type == 0 ? src + lit_off : lit_buf;
+                    // ---- the block pipeline: wave 0 sequences (K3 tables, K4a walk); waves 1-3 literals
+                    //      (K1, K2); wave 1 then executes (K4b, K5) behind the walker
+                    if (wave == 0) {
+                        if (nseq) {
+                            build_tables_wave(S, lane);
+                            STAMP(4);
+                            int rc = walk_sequences_wave(S, src + seq_off, seq_len, nseq, walk, &c.walk_prog, lane);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) {
+                                if (rc) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
+                                c.fse_valid = 1;
+                                flag_store(&c.walk_prog, rc ? kWalkFin : (nseq | kWalkFin)); // a failed walk publishes nothing
                             }
+                            STAMP(5);
+                        }
+                    } else {
+                        int rc = 0;
+                        if (lit_type == 2) { // K1: weights by one lane, table by 192
+                            if (tid == 64) {
+                                int used = read_huf_weights(S, blk + c.huf_tree_off, c.huf_tree_len);
+                                if (used <= 0) __atomic_store_n(&c.err, MZD_E_CORRUPT, __ATOMIC_RELAXED);
+                                else c.huf_valid = 1;
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                flag_store(&c.huf_ready, 1);
+                            }
+                            if (spin_ge(&c.huf_ready, 1, &c.err)) fill_huf_table(S, tid - 64, kWG - 64);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) __atomic_fetch_add(&c.huf_fill, 1u, __ATOMIC_RELAXED);
+                            spin_ge(&c.huf_fill, 3, &c.err);
+                        }
+                        const bool failed = __atomic_load_n(&c.err, __ATOMIC_RELAXED) != 0;
+                        if (lit_type == 1) { // RLE literals
+                            uint32_t w = (uint32_t)src[lit_off] * 0x01010101u;
+                            for (uint32_t k = (uint32_t)(tid - 64) * 16; k < nlit; k += (kWG - 64) * 16)
+                                *reinterpret_cast<uint4*>(lit_buf + k) = make_uint4(w, w, w, w); // lit_buf has slack past nlit
+                        } else if (lit_type >= 2 && !failed) { // K2: wave 1 takes streams 0 and 3, wave 2 stream 1, wave 3 stream 2
+                            const uint32_t hl = c.huf_log;
+                            const int first = wave == 1 ? 0 : wave - 1;
+                            if ((uint32_t)first < streams) rc = huf_stream_wave(blk + c.s_off[first], c.s_len[first], lit_buf + c.s_out[first], c.s_n[first], S.huf, hl, lane);
+                            if (!rc && wave == 1 && streams == 4) rc = huf_stream_wave(blk + c.s_off[3], c.s_len[3], lit_buf + c.s_out[3], c.s_n[3], S.huf, hl, lane);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) {
+                            if (rc) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
+                            __atomic_fetch_add(&c.lit_done, 1u, __ATOMIC_RELAXED);
+                        }
+                        STAMP(3);
+                        if (wave == 1) { // K4b + K5
+                            uint64_t opos = out0;
+                            rc = MZD_E_CORRUPT;
+                            if (spin_ge(&c.lit_done, 3, &c.err)) {
+                                ExecCtx cx{walk, src + seq_off, &c.walk_prog, &c.err, dst, c.frame_out0, cap, c.dict_content, c.dict_content_len, lit, nlit};
+                                rc = execute_wave(S, seqs, nseq, cx, &opos, c.rep, lane);
+                            }
+                            if (lane == 0) {
+                                if (rc && !__atomic_load_n(&c.err, __ATOMIC_RELAXED)) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
+                                c.out = opos; c.pos = pos0 + bsize;
+                                if (a.debug) {
+                                    DebugSlot& ds = a.debug[blockIdx.x];
+                                    ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0; ds.lit_raw_ptr = (uint64_t)(uintptr_t)lit;
+                                }
+                            }
+                            STAMP(6);
                         }
                     }
                 }
                 WG_SNAPSHOT(err = c.err);
+                STAMP(6);
                 if (err || last) break;
             }
             if (err) break;
@@ -1261,7 +1393,7 @@ __global__ __launch_bounds__(kWG) void mzd_dict_kernel(const uint8_t* dict, uint
         return;
     }
     if (c.err) { if (tid == 0) *status = c.err; return; }
-    fill_huf_table(S, tid);
+    fill_huf_table(S, tid, kWG);
     __syncthreads();
     if (tid == 0) {
         const uint8_t* p = dict + pos_after_huf;
@@ -1280,9 +1412,8 @@ __global__ __launch_bounds__(kWG) void mzd_dict_kernel(const uint8_t* dict, uint
     }
     __syncthreads();
     if (c.err) { if (tid == 0) *status = MZD_E_DICT; return; }
-    build_tables_wave(S, wave, lane);
+    if (wave == 0) build_tables_wave(S, lane);
     __syncthreads();
-    if (c.err) { if (tid == 0) *status = MZD_E_DICT; return; }
     for (int i = tid; i < 512; i += kWG) { out->ll[i] = S.ll[i]; out->ml[i] = S.ml[i]; }
     for (int i = tid; i < 256; i += kWG) out->of[i] = S.of[i];
     for (int i = tid; i < 2048; i += kWG) out->huf[i] = S.huf[i];
