@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/mzd.h"
 #include "mzd_device.h"
 
@@ -49,6 +51,9 @@ struct Ctl {
     uint32_t lit_is_raw;
     uint32_t huf_tree_off, huf_tree_len;           // Huffman tree description inside the block
     uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
+    uint32_t exec_done;                            // the executing wavefront has finished the block
+    uint64_t exec_pos;                             // output bytes complete and visible (published by the executor)
+    uint32_t diag_slow;                            // diagnostic build: walker iterations that needed a lower window
     uint32_t nseq, mode[3], al[3], nsym[3], fse_valid, seq_len;
     uint32_t rep[3];
     uint32_t dict_content_len;
@@ -567,7 +572,15 @@ constexpr uint32_t kWalkFin = 0x80000000u;
 __device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint2* walk, uint32_t* prog, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
     // a global (not flat) pointer: flat stores would also count on lgkmcnt, i.e. sit in the LDS waits below
-    __attribute__((address_space(1))) uint64_t* const gwalk = (__attribute__((address_space(1))) uint64_t*)walk;
+    __attribute__((address_space(1))) uint8_t* gwalk;
+    {
+        uint64_t wp = (uint64_t)(uintptr_t)walk;
+        wp = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wp) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wp >> 32)) << 32); // the builtin returns int: no sign extension
+        gwalk = (__attribute__((address_space(1))) uint8_t*)wp;
+    }
+    uint32_t woff = 0; // byte offset of the next record (a VGPR next to a scalar base: cheapest store form)
+    asm volatile("" : "+v"(woff));
+    uint64_t bad = 0;
     if (sl == 0) return MZD_E_CORRUPT;
     uint32_t last = sp[sl - 1];
     if (last == 0) return MZD_E_CORRUPT;
@@ -610,45 +623,56 @@ __device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, ui
                 ring_load_chunk(S, st, st.lowest, lane);
             }
         }
-        uint32_t stop = i + kWalkBatch < nupd ? i + kWalkBatch : nupd;
-        for (; i < stop; i++) {
+        const uint32_t stop = i + kWalkBatch < nupd ? i + kWalkBatch : nupd;
+        // One step of the chain.  CAREFUL = false is the hot form: no branch at all; it only notes (in
+        // `bad`) that some sequence had more bits than its window holds (long extra-bit fields: about
+        // one sequence in thousands).  The batch is then redone with CAREFUL = true, which moves the
+        // window down a dword at a time.  (A branch on freshly loaded LDS data costs ~35 cycles per
+        // sequence on a lone wavefront; micro-benchmarked.)
+        auto step = [&](auto careful) {
             uint64_t eL, eM, eO;
             __builtin_memcpy(&eL, tL + vL, 8);
             __builtin_memcpy(&eM, tM + vM, 8);
             __builtin_memcpy(&eO, tO + vO, 8);
-            uint32_t t = G - 57;
+            // window: the 8 ring bytes at the 4-byte aligned address whose 64 bits end at or above the
+            // read head (two aligned dwords; an unaligned 8-byte LDS read costs ~40 cycles more)
+            const uint32_t u = G - 33;
+            uint32_t ra = (u >> 3) & (kRingBytes - 4);
             uint64_t X;
-            __builtin_memcpy(&X, &S.ring[(t >> 3) & (kRingBytes - 1)], 8); // the 8 bytes ending at ceil(G/8)
-            gwalk[i] = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(G | (vO << 21)) << 32);
-            // all four LDS reads must be in flight together: pin the window load above the branch
-            asm volatile("" : "+v"(X));
-            uint32_t hL = (uint32_t)(eL >> 32), hM = (uint32_t)(eM >> 32), hO = (uint32_t)(eO >> 32);
-            uint32_t total = ((hL + hM + hO) >> 8) & 0xFF;
-            uint32_t r = t & 7;
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(total > 57 + r) != 0, 0)) { // long extra-bit fields: window again below them
-                uint32_t extra = (hL >> 24) + (hM >> 24) + (hO >> 24);
-                uint32_t G2 = G - extra;
-                uint32_t e2 = (G2 + 7) >> 3;
-                uint64_t B = ring_read64(S, e2) << (e2 * 8 - G2);
-                uint32_t nL = hL & 63, nM = hM & 63, nO = hO & 63;
-                uint32_t uL = nL ? (uint32_t)(B >> (64 - nL)) : 0; B <<= nL;
-                uint32_t uM = nM ? (uint32_t)(B >> (64 - nM)) : 0; B <<= nM;
-                uint32_t uO = nO ? (uint32_t)(B >> (64 - nO)) : 0;
-                vL = (uint32_t)eL + uL * 8; vM = (uint32_t)eM + uM * 8; vO = (uint32_t)eO + uO * 8;
-                G -= total;
-                continue;
+            __builtin_memcpy(&X, &S.ring[ra], 8);
+            *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(G | (vO << 21)) << 32);
+            woff += 8;
+            asm volatile("" : "+v"(X)); // keep all four LDS reads in flight together
+            const uint32_t hL = (uint32_t)(eL >> 32), hM = (uint32_t)(eM >> 32), hO = (uint32_t)(eO >> 32);
+            const uint32_t total = ((hL + hM + hO) >> 8) & 0xFF;
+            uint32_t av = (u & 31) + 33; // bits of the window below the read head: 33..64
+            if (decltype(careful)::value) {
+                while (__builtin_amdgcn_ballot_w64(total > av) != 0) {
+                    ra = (ra - 4) & (kRingBytes - 4);
+                    __builtin_memcpy(&X, &S.ring[ra], 8);
+                    av += 32;
+                }
+            } else {
+                bad |= __builtin_amdgcn_ballot_w64(total > av);
             }
             // fresh state bits sit at the bottom of what this sequence consumes: OF lowest, then ML, then LL
-            uint32_t oO = r + 57 - total;
-            uint32_t oM = oO + hO; // only the low 6 bits matter (nbBits lives in [5:0])
-            uint32_t oL = oM + hM;
-            uint32_t bO = __builtin_amdgcn_ubfe((uint32_t)(X >> (oO & 63)), 0, hO);
-            uint32_t bM = __builtin_amdgcn_ubfe((uint32_t)(X >> (oM & 63)), 0, hM);
-            uint32_t bL = __builtin_amdgcn_ubfe((uint32_t)(X >> (oL & 63)), 0, hL);
+            const uint32_t oO = av - total;
+            const uint32_t oM = oO + hO; // only the low 6 bits matter (nbBits lives in [5:0])
+            const uint32_t oL = oM + hM;
+            const uint32_t bO = __builtin_amdgcn_ubfe((uint32_t)(X >> (oO & 63)), 0, hO);
+            const uint32_t bM = __builtin_amdgcn_ubfe((uint32_t)(X >> (oM & 63)), 0, hM);
+            const uint32_t bL = __builtin_amdgcn_ubfe((uint32_t)(X >> (oL & 63)), 0, hL);
             vO = (uint32_t)eO + (bO << 3);
             vM = (uint32_t)eM + (bM << 3);
             vL = (uint32_t)eL + (bL << 3);
             G -= total;
+        };
+        const uint32_t sL = vL, sM = vM, sO = vO, sG = G, sW = woff, i0 = i;
+        bad = 0;
+        for (; i < stop; i++) step(std::false_type{});
+        if (__builtin_expect(bad != 0, 0)) {
+            vL = sL; vM = sM; vO = sO; G = sG; woff = sW;
+            for (i = i0; i < stop; i++) step(std::true_type{});
         }
         if ((int32_t)(G - Gzero) < 0) return MZD_E_CORRUPT; // over-read
         // publish the batch BEFORE this one: all but the newest kWalkBatch stores have landed
@@ -661,7 +685,7 @@ __device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, ui
         __builtin_memcpy(&eL, tL + vL, 8);
         __builtin_memcpy(&eM, tM + vM, 8);
         __builtin_memcpy(&eO, tO + vO, 8);
-        gwalk[nupd] = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(G | (vO << 21)) << 32);
+        *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(G | (vO << 21)) << 32);
         uint32_t extra = (uint32_t)(eL >> 56) + (uint32_t)(eM >> 56) + (uint32_t)(eO >> 56);
         if (G - Gzero != extra) return MZD_E_CORRUPT; // the bitstream must be consumed exactly
     }
@@ -763,6 +787,7 @@ struct ExecCtx {
     const uint8_t* seq_sp;   // the block's sequence bitstream
     const uint32_t* prog;    // walker progress (LDS)
     const int32_t* err;      // workgroup error word (LDS)
+    uint64_t* pub_pos;       // where the executor publishes finished output (LDS), for the hashing wavefront
     uint8_t* dst;            // the file's output buffer
     uint64_t frame_start;    // offset of the current frame's first byte in dst
     uint64_t cap;
@@ -861,6 +886,7 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
                 const uint32_t l = __builtin_amdgcn_readlane(ll, a), m = __builtin_amdgcn_readlane(ml, a);
                 const uint32_t o = __builtin_amdgcn_readlane(off, a), lp = __builtin_amdgcn_readlane(my_lit, a);
                 wg_fence(); // earlier flushes are visible
+                if (lane == 0) __atomic_store_n(cx.pub_pos, run_pos, __ATOMIC_RELAXED);
                 wave_copy(dst + run_pos, lit + lp, l, lane);
                 wg_fence();
                 uint8_t* d = dst + run_pos + l;
@@ -891,6 +917,7 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
             const int64_t rel_src = (int64_t)rel_m - (int64_t)off;
             const bool plain = off >= ml; // source and destination do not overlap
             wg_fence();
+            if (lane == 0) __atomic_store_n(cx.pub_pos, run_pos, __ATOMIC_RELAXED); // everything before this run has landed
             bool pending = act && ml > 0;
             if (pending && plain && rel_src + (int64_t)ml <= 0) {
                 copy_short(ml, GlobalLd{dst + run_pos + rel_src}, LdsSt{stage + rel_m});
@@ -941,6 +968,7 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
     wave_copy(dst + opos, lit + lpos, rest, lane);
     opos += rest;
     wg_fence();
+    if (lane == 0) __atomic_store_n(cx.pub_pos, opos, __ATOMIC_RELAXED);
     *opos_io = opos;
     if (lane == 0) { rep[0] = r0; rep[1] = r1; rep[2] = r2; }
     return 0;
@@ -953,30 +981,35 @@ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) 
 __device__ __forceinline__ uint64_t xround(uint64_t acc, uint64_t in) { acc += in * XP2; acc = rotl64(acc, 31); return acc * XP1; }
 __device__ __forceinline__ uint64_t xmerge(uint64_t h, uint64_t v) { v = xround(0, v); h ^= v; return h * XP1 + XP4; }
 
-// XXH64(seed 0) of p[0..n) by one wavefront: lanes 0..3 carry the four accumulators.
-__device__ __noinline__ uint64_t xxh64_wave(const uint8_t* p, uint64_t n, int lane) {
-    uint64_t h;
-    uint64_t done = 0;
-    if (n >= 32) {
-        uint64_t v = 0;
-        if (lane == 0) v = XP1 + XP2; else if (lane == 1) v = XP2; else if (lane == 2) v = 0; else if (lane == 3) v = 0 - XP1;
-        uint64_t stripes = n / 32;
-        if (lane < 4) {
-            // the accumulator chain is serial; keep 8 stripes of loads in flight ahead of it
-            const uint8_t* q = p + lane * 8;
-            uint64_t cur[8], nxt[8];
+// XXH64(seed 0) by one wavefront, incrementally: lanes 0..3 carry the four accumulators `v`;
+// `stripes` counts the 32-byte stripes already absorbed.  The hashing wavefront follows the
+// executing one through the frame (xxh_advance up to the published output position) and closes
+// the digest at the frame end (xxh_finish).
+__device__ __forceinline__ uint64_t xxh_init(int lane) {
+    return lane == 0 ? XP1 + XP2 : (lane == 1 ? XP2 : (lane == 2 ? 0ull : 0ull - XP1));
+}
+__device__ __noinline__ void xxh_advance(uint64_t& v, uint64_t& stripes, uint64_t upto, const uint8_t* p, int lane) {
+    if (upto <= stripes) return;
+    if (lane < 4) {
+        // the accumulator chain is serial; keep 8 stripes of loads in flight ahead of it
+        const uint8_t* q = p + lane * 8;
+        uint64_t cur[8], nxt[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) cur[k] = (uint64_t)k < stripes ? ldu64(q + (uint64_t)k * 32) : 0;
-            for (uint64_t s = 0; s < stripes; s += 8) {
+        for (int k = 0; k < 8; k++) cur[k] = stripes + k < upto ? ldu64(q + (stripes + k) * 32) : 0;
+        for (uint64_t s = stripes; s < upto; s += 8) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) nxt[k] = s + 8 + k < stripes ? ldu64(q + (s + 8 + k) * 32) : 0;
+            for (int k = 0; k < 8; k++) nxt[k] = s + 8 + k < upto ? ldu64(q + (s + 8 + k) * 32) : 0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) if (s + k < stripes) v = xround(v, cur[k]);
+            for (int k = 0; k < 8; k++) if (s + k < upto) v = xround(v, cur[k]);
 #pragma unroll
-                for (int k = 0; k < 8; k++) cur[k] = nxt[k];
-            }
+            for (int k = 0; k < 8; k++) cur[k] = nxt[k];
         }
-        done = stripes * 32;
+    }
+    stripes = upto;
+}
+__device__ __noinline__ uint64_t xxh_finish(uint64_t v, const uint8_t* p, uint64_t n, int lane) {
+    uint64_t h;
+    if (n >= 32) {
         uint64_t v1 = __shfl(v, 0), v2 = __shfl(v, 1), v3 = __shfl(v, 2), v4 = __shfl(v, 3);
         h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
         h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
@@ -984,7 +1017,7 @@ __device__ __noinline__ uint64_t xxh64_wave(const uint8_t* p, uint64_t n, int la
         h = XP5;
     }
     h += n;
-    const uint8_t* q = p + done;
+    const uint8_t* q = p + (n / 32) * 32;
     const uint8_t* end = p + n;
     while (q + 8 <= end) { h ^= xround(0, ld64(q)); h = rotl64(h, 27) * XP1 + XP4; q += 8; }
     if (q + 4 <= end) { h ^= (uint64_t)ld32(q) * XP1; h = rotl64(h, 23) * XP2 + XP3; q += 4; }
@@ -1177,7 +1210,7 @@ __device__ __noinline__ void build_tables_wave(Shared& S, int lane) {
 #ifdef MZD_STAMPS
 #define STAMP_DECL uint64_t st_prev = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
-#define STAMP_FLUSH() do { if (tid == 0 && a.debug) for (int k_ = 0; k_ < 8; k_++) a.debug[blockIdx.x].stamp[k_] = st_acc[k_]; } while (0)
+#define STAMP_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 8; k_++) a.debug[blockIdx.x].stamp[k_] = st_acc[k_]; a.debug[blockIdx.x].stamp[2] = S.c.diag_slow; } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(k)
@@ -1203,12 +1236,13 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
         const uint64_t cap = a.jobs[j].dst_cap;
         const uint32_t job_dict = a.jobs[j].dict;
         if (tid == 0) {
-            c.pos = 0; c.out = 0; c.err = 0; c.action = 0;
+            c.pos = 0; c.out = 0; c.err = 0; c.action = 0; c.diag_slow = 0;
             if (j == 0 && a.job_slot0) *a.job_slot0 = blockIdx.x;
             if (job_dict > a.ndicts) c.err = MZD_E_DICT;
         }
         int err = 0;
         uint32_t action = 0;
+        uint64_t xv = 0, xstripes = 0; // K7 state of the hashing wavefront (wave 2)
         STAMP_DECL;
 
         // ---------------- frames (K0)
@@ -1217,6 +1251,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
             WG_SNAPSHOT(err = c.err; action = c.action);
             if (err || action == 2) break;
             if (action == 1) continue; // skippable frame
+            xv = xxh_init(lane); xstripes = 0;
+            const bool hashing = c.has_cksum != 0; // stable for the whole frame
             if (action == 3) { // dictionary: entropy tables, repeat offsets and content
                 const DevDict* dd = &a.dicts[job_dict - 1];
                 if (dd->formatted) {
@@ -1256,7 +1292,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     const uint8_t* const blk = src + pos0;
                     STAMP(0);
                     if (tid == 0) { // K0/K1/K3 headers: where everything is; nothing is decoded yet
-                        c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0;
+                        c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = out0;
                         parse_literals(S, blk, bsize);
                         if (!c.err) parse_seq_header(S, src + c.seq_off, c.seq_len);
                     }
@@ -1318,9 +1354,11 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             uint64_t opos = out0;
                             rc = MZD_E_CORRUPT;
                             if (spin_ge(&c.lit_done, 3, &c.err)) {
-                                ExecCtx cx{walk, src + seq_off, &c.walk_prog, &c.err, dst, c.frame_out0, cap, c.dict_content, c.dict_content_len, lit, nlit};
+                                ExecCtx cx{walk, src + seq_off, &c.walk_prog, &c.err, &c.exec_pos, dst, c.frame_out0, cap, c.dict_content, c.dict_content_len, lit, nlit};
                                 rc = execute_wave(S, seqs, nseq, cx, &opos, c.rep, lane);
                             }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) flag_store(&c.exec_done, 1);
                             if (lane == 0) {
                                 if (rc && !__atomic_load_n(&c.err, __ATOMIC_RELAXED)) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
                                 c.out = opos; c.pos = pos0 + bsize;
@@ -1330,6 +1368,18 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                                 }
                             }
                             STAMP(6);
+                        } else if (wave == 2 && hashing) { // K7: hash behind the executor while it works
+                            const uint8_t* fp = dst + c.frame_out0;
+                            for (uint32_t it = 0; it < (1u << 24); it++) {
+                                const uint32_t fin = flag_load(&c.exec_done);
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                const uint64_t pos = __atomic_load_n(&c.exec_pos, __ATOMIC_RELAXED);
+                                const uint64_t upto = (pos - c.frame_out0) / 32;
+                                if (upto > xstripes) xxh_advance(xv, xstripes, upto, fp, lane);
+                                else if (fin || __atomic_load_n(&c.err, __ATOMIC_RELAXED)) break;
+                                else __builtin_amdgcn_s_sleep(8);
+                                if (fin) break;
+                            }
                         }
                     }
                 }
@@ -1349,8 +1399,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
             WG_SNAPSHOT(err = c.err; has_ck = c.has_cksum; fout0 = c.frame_out0; out_now = c.out; pos_now = c.pos);
             if (err) break;
             if (has_ck) {
-                if (wave == 0) {
-                    uint64_t h = xxh64_wave(dst + fout0, out_now - fout0, lane);
+                if (wave == 2) {
+                    xxh_advance(xv, xstripes, (out_now - fout0) / 32, dst + fout0, lane);
+                    uint64_t h = xxh_finish(xv, dst + fout0, out_now - fout0, lane);
                     if (lane == 0) {
                         if ((uint32_t)h != ld32(src + pos_now)) c.err = MZD_E_CHECKSUM;
                         c.pos = pos_now + 4;

@@ -15,7 +15,7 @@ for rep in range(2):
 assert all(st == 0 for st, _ in res)
 st = (C.c_uint64 * 8)()
 api.lib().mzd_debug_stamps(0, st)
-names = ["hdr", "K1 weights+parse", "K1 table fill", "K2 literals+seqhdr", "K3 tables", "K4 seq decode", "K5 execute", "K7 xxh64"]
+names = ["hdr", "K1 weights+parse", "(count) walker slow-window iterations", "K2 literals+seqhdr", "K3 tables", "K4 seq decode", "K5 execute", "K7 xxh64"]
 tot = sum(st)
 print("kernel ms", mzd.last_kernel_ms(0), "files", n)
 for nm, v in zip(names, st):
