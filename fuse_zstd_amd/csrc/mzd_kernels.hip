@@ -51,7 +51,8 @@ struct Ctl {
     uint32_t lit_is_raw;
     uint32_t huf_tree_off, huf_tree_len;           // Huffman tree description inside the block
     uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
-    uint32_t exec_done;                            // the executing wavefront has finished the block
+    uint32_t tables_ready, plan_prog, copy_prog, plan_lit_used; // walker -> planner -> copier
+    uint32_t exec_done;                            // the copying wavefront has finished the block
     uint64_t exec_pos;                             // output bytes complete and visible (published by the executor)
     uint32_t diag_slow;                            // diagnostic build: walker iterations that needed a lower window
     uint32_t nseq, mode[3], al[3], nsym[3], fse_valid, seq_len;
@@ -68,6 +69,9 @@ struct __attribute__((aligned(16))) Shared {
     uint64_t of[256];
     uint8_t ring[kRingBytes + 16];
     uint8_t stage[2048 + 16]; // K5 staging buffer (kStage)
+    uint4 planA[4][64];       // plan ring (kPlanRing chunks): {ll, ml, off, output offset inside the chunk}
+    uint32_t planB[4][64];    //   literal index of each sequence
+    uint32_t plan_hdr[4][4];  //   per chunk: bytes, sequences
     uint16_t huf[2048]; // sym | len << 8
     int16_t norm[3][64];
     uint16_t next[3][64];
@@ -77,6 +81,10 @@ struct __attribute__((aligned(16))) Shared {
     uint32_t rank_start[16];
     Ctl c;
 };
+
+// The workgroup's LDS image.  File scope, so that every device function addresses it with DS
+// instructions and immediate offsets (a `Shared&` parameter would be a flat pointer).
+__shared__ Shared S;
 
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 __device__ __forceinline__ uint32_t ld24(const uint8_t* p) { return ld16(p) | ((uint32_t)p[2] << 16); }
@@ -207,7 +215,7 @@ __device__ void rle_seq_table(uint64_t* tab, uint32_t s, int kind) { tab[0] = pa
 
 // ------------------------------------------------------------------------------------ K1
 // Huffman tree description (A.4) -> S.weights[0..nw), S.c.huf_log.  Lane 0.  Returns bytes used or < 0.
-__device__ __noinline__ int read_huf_weights(Shared& S, const uint8_t* src, uint32_t n) {
+__device__ __noinline__ int read_huf_weights(const uint8_t* src, uint32_t n) {
     if (n < 1) return MZD_E_CORRUPT;
     uint32_t hb = src[0], nw = 0;
     int used;
@@ -296,7 +304,7 @@ __device__ __noinline__ int read_huf_weights(Shared& S, const uint8_t* src, uint
 }
 
 // Canonical table fill by all 256 lanes: lane s owns symbol s.
-__device__ __noinline__ void fill_huf_table(Shared& S, int first, int stride) {
+__device__ __noinline__ void fill_huf_table(int first, int stride) {
     for (int sym = first; sym < 256; sym += stride) {
         uint32_t wt = S.weights[sym];
         if (wt) {
@@ -518,9 +526,9 @@ __device__ __noinline__ void build_seq_table_wave(uint64_t* tab, const int16_t* 
 //      window (all LDS, issued together), the bit budget of the sequence, the three state updates.
 //      Per sequence it records {bit position, three states} (8 bytes) and nothing else.
 //  (b) field conversion -- everything that is NOT a chain: extra bits, base values.  One lane per
-//      sequence, straight from the records of (a); done by the executing wavefront (execute_wave),
+//      sequence, straight from the records of (a); done by the planning wavefront (plan_wave),
 //      64 sequences at a time, while the walker is already further down the stream.
-//  Repeat-offset resolution (a chain again, but a cheap one) happens in execute_wave.
+//  Repeat-offset resolution (a chain again, but a cheap one) happens in plan_wave.
 //
 // The bitstream is read backwards through an 8 KiB LDS ring, filled 1 KiB at a time with one 16-byte
 // load per lane (coalesced).  Ring coordinates ("g-offsets") are stream byte index + bias,
@@ -534,7 +542,7 @@ struct SeqStream {
     int32_t lowest;       // lowest chunk resident in the ring
 };
 
-__device__ __forceinline__ void ring_load_chunk(Shared& S, const SeqStream& st, int32_t chunk, int lane) {
+__device__ __forceinline__ void ring_load_chunk(const SeqStream& st, int32_t chunk, int lane) {
     uint32_t o = (uint32_t)chunk * kChunk + (uint32_t)lane * 16; // g-offset of this lane's piece
     uint4 v = make_uint4(0, 0, 0, 0);
     if (o + 16 > st.bias && o < st.gend) {
@@ -557,7 +565,7 @@ __device__ __forceinline__ void ring_load_chunk(Shared& S, const SeqStream& st, 
 }
 
 // the 8 ring bytes that end at g-offset e (exclusive), as a little-endian u64
-__device__ __forceinline__ uint64_t ring_read64(const Shared& S, uint32_t e) {
+__device__ __forceinline__ uint64_t ring_read64(uint32_t e) {
     uint64_t v;
     __builtin_memcpy(&v, &S.ring[(e - 8) & (kRingBytes - 1)], 8);
     return v;
@@ -569,7 +577,7 @@ constexpr uint32_t kWalkBatch = 32; // sequences between two ring checks (<= 89 
 
 constexpr uint32_t kWalkFin = 0x80000000u;
 
-__device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint2* walk, uint32_t* prog, int lane) {
+__device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint2* walk, uint32_t* prog, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
     // a global (not flat) pointer: flat stores would also count on lgkmcnt, i.e. sit in the LDS waits below
     __attribute__((address_space(1))) uint8_t* gwalk;
@@ -593,14 +601,14 @@ __device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, ui
     uint32_t G = (sl - 1) * 8 + (uint32_t)hibit(last) + Gzero; // g-bits below the read head
     int32_t top = (int32_t)((st.gend - 1) / kChunk);
     st.lowest = top;
-    ring_load_chunk(S, st, top, lane);
-    if (top >= 1) { ring_load_chunk(S, st, top - 1, lane); st.lowest = top - 1; }
+    ring_load_chunk(st, top, lane);
+    if (top >= 1) { ring_load_chunk(st, top - 1, lane); st.lowest = top - 1; }
 
     const uint32_t alL = S.c.al[0], alO = S.c.al[1], alM = S.c.al[2];
     uint32_t vL, vO, vM; // state byte offsets
     {
         uint32_t e = (G + 7) >> 3;
-        uint64_t B = ring_read64(S, e) << (e * 8 - G);
+        uint64_t B = ring_read64(e) << (e * 8 - G);
         uint32_t n = alL + alO + alM;
         if (G - Gzero < n) return MZD_E_CORRUPT;
         vL = alL ? (uint32_t)(B >> (64 - alL)) : 0; B <<= alL;
@@ -620,7 +628,7 @@ __device__ __noinline__ int walk_sequences_wave(Shared& S, const uint8_t* sp, ui
             uint32_t e = __builtin_amdgcn_readfirstlane((G + 7) >> 3);
             while (st.lowest > 0 && (int32_t)e - (int32_t)(kWalkBatch * 12 + 24) < st.lowest * kChunk) {
                 st.lowest--;
-                ring_load_chunk(S, st, st.lowest, lane);
+                ring_load_chunk(st, st.lowest, lane);
             }
         }
         const uint32_t stop = i + kWalkBatch < nupd ? i + kWalkBatch : nupd;
@@ -782,36 +790,34 @@ struct LdsSt {
     __device__ __forceinline__ void u8(uint32_t o, uint32_t v) const { p[o] = (uint8_t)v; }
 };
 
-struct ExecCtx {
+constexpr int kPlanRing = 4; // chunks of 64 planned sequences buffered between the planner and the copier
+constexpr uint32_t kPlanFin = 0x80000000u;
+
+struct PlanCtx { // what the planning wavefront needs
     const uint2* walk;       // state-walk records of the block (HBM scratch)
     const uint8_t* seq_sp;   // the block's sequence bitstream
     const uint32_t* prog;    // walker progress (LDS)
-    const int32_t* err;      // workgroup error word (LDS)
-    uint64_t* pub_pos;       // where the executor publishes finished output (LDS), for the hashing wavefront
-    uint8_t* dst;            // the file's output buffer
     uint64_t frame_start;    // offset of the current frame's first byte in dst
     uint64_t cap;
-    const uint8_t* dict;     // dictionary content (logically just before frame_start) or null
     uint32_t dict_len;
-    const uint8_t* lit;      // literal buffer of the block
     uint32_t nlit;
 };
 
-__device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_in, const ExecCtx& cx, uint64_t* opos_io, uint32_t* rep, int lane) {
+// K4(b) + the bookkeeping half of K5, by one wavefront, 64 sequences per step (lane = sequence):
+// field conversion from the walk records, repeat offsets, positions, validation.  The result goes
+// to the plan ring in LDS: per sequence {ll, ml, off, output offset inside the chunk} + literal index,
+// per chunk {bytes, literal bytes, sequences}.  Returns 0 or an error.
+__device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanCtx& cx, uint64_t opos, uint32_t* rep, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
-    uint8_t* const dst = cx.dst;
-    const uint8_t* const lit = cx.lit;
-    uint8_t* const stage = S.stage;
-    uint64_t opos = *opos_io;
     const uint64_t block_start = opos;
     uint32_t lpos = 0;
     uint32_t r0 = __builtin_amdgcn_readfirstlane(rep[0]), r1 = __builtin_amdgcn_readfirstlane(rep[1]), r2 = __builtin_amdgcn_readfirstlane(rep[2]);
-    for (uint32_t base = 0; base < nseq; base += 64) {
+    uint32_t chunk = 0;
+    for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
         const uint32_t i = base + (uint32_t)lane;
         const bool valid = (uint32_t)lane < cnt;
-        // wait for the walker to be 64 sequences ahead, then K4(b): fields of this lane's sequence
-        {
+        { // the walker must be past this chunk, and the copier must have freed the ring slot
             const uint32_t need = base + cnt;
             uint32_t pg = 0;
             for (uint32_t it = 0; it < (1u << 24); it++) {
@@ -820,6 +826,11 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
                 __builtin_amdgcn_s_sleep(4);
             }
             if ((pg & ~kWalkFin) < need) return MZD_E_CORRUPT; // the walker failed (it posted the error) or never got there
+            for (uint32_t it = 0; it < (1u << 24); it++) {
+                if (chunk - flag_load(&S.c.copy_prog) < (uint32_t)kPlanRing) break;
+                if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
+                __builtin_amdgcn_s_sleep(4);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         uint32_t ll = 0, ml = 0, ofv = 4;
@@ -835,7 +846,7 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
             ml = ML_BASE[cM] + stream_bits(gbase, G - xO, xM);
             ll = LL_BASE[cL] + stream_bits(gbase, G - xO - xM, xL);
         }
-        // ---- 1. repeat offsets
+        // ---- repeat offsets
         uint32_t off;
         {
             RepOp op;
@@ -862,22 +873,76 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
             r0 = __builtin_amdgcn_readlane(e0, 63); r1 = __builtin_amdgcn_readlane(e1, 63); r2 = __builtin_amdgcn_readlane(e2, 63);
             if (valid) seqs[i] = make_uint4(ll, ml, off, 0); // the resolved triple (mzd_debug_last_block / phase tests)
         }
-        // ---- 2. positions
+        // ---- positions and validation
         const uint32_t tot = ll + ml;
         const uint32_t incl_t = wave_incl_scan(tot, lane), incl_l = wave_incl_scan(ll, lane);
         const uint32_t chunk_tot = __builtin_amdgcn_readlane(incl_t, 63), chunk_lit = __builtin_amdgcn_readlane(incl_l, 63);
         if (chunk_lit > cx.nlit - lpos) return MZD_E_CORRUPT;
         if ((opos - block_start) + chunk_tot > kBlockMax) return MZD_E_CORRUPT;
         if (chunk_tot > cx.cap - opos) return MZD_E_DSTSIZE;
-        const uint32_t ex_t = incl_t - tot;                 // this sequence's output offset inside the 64-chunk
-        const uint32_t my_lit = lpos + (incl_l - ll);
-        const uint64_t mdst = opos + ex_t + ll;              // absolute match destination
+        const uint32_t ex_t = incl_t - tot; // this sequence's output offset inside the 64-chunk
+        const uint64_t mdst = opos + ex_t + ll;
         const uint64_t avail = (mdst - cx.frame_start) + cx.dict_len;
         if (__any(valid && (off == 0 || off > avail))) return MZD_E_CORRUPT;
+        const uint32_t slot = chunk & (kPlanRing - 1);
+        S.planA[slot][lane] = make_uint4(ll, ml, off, ex_t);
+        S.planB[slot][lane] = lpos + (incl_l - ll);
+        if (lane == 0) { S.plan_hdr[slot][0] = chunk_tot; S.plan_hdr[slot][1] = cnt; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) flag_store(&S.c.plan_prog, chunk + 1);
+        opos += chunk_tot;
+        lpos += chunk_lit;
+    }
+    const uint32_t rest = cx.nlit - lpos;
+    if (rest > cx.cap - opos) return MZD_E_DSTSIZE;
+    if ((opos - block_start) + rest > kBlockMax) return MZD_E_CORRUPT;
+    if (lane == 0) { rep[0] = r0; rep[1] = r1; rep[2] = r2; S.c.plan_lit_used = lpos; }
+    return 0;
+}
+
+struct CopyCtx {
+    uint8_t* dst;            // the file's output buffer
+    uint64_t frame_start;    // offset of the current frame's first byte in dst
+    const uint8_t* dict;     // dictionary content (logically just before frame_start) or null
+    uint32_t dict_len;
+    const uint8_t* lit;      // literal buffer of the block
+    uint32_t nlit;
+};
+
+// The copying half of K5, by one wavefront, one planned chunk of 64 sequences at a time.  It publishes the
+// finished output position in S.c.exec_pos for the hashing wavefront.
+__device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint64_t* opos_io, int lane) {
+    const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
+    uint8_t* const dst = cx.dst;
+    const uint8_t* const lit = cx.lit;
+    uint8_t* const stage = S.stage;
+    uint64_t opos = *opos_io;
+    uint32_t chunk = 0;
+    for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
+        { // wait for the plan of this chunk
+            uint32_t pg = 0;
+            for (uint32_t it = 0; it < (1u << 24); it++) {
+                pg = flag_load(&S.c.plan_prog);
+                if ((pg & ~kPlanFin) > chunk || (pg & kPlanFin)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if ((pg & ~kPlanFin) <= chunk) return MZD_E_CORRUPT; // the planner failed and posted the error
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        const uint32_t slot = chunk & (kPlanRing - 1);
+        const uint4 pe = S.planA[slot][lane];
+        const uint32_t my_lit = S.planB[slot][lane];
+        const uint32_t chunk_tot = S.plan_hdr[slot][0], cnt = S.plan_hdr[slot][1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the reads above are done: the slot may be refilled
+        if (lane == 0) flag_store(&S.c.copy_prog, chunk + 1);
+        const bool valid = (uint32_t)lane < cnt;
+        const uint32_t ll = valid ? pe.x : 0, ml = valid ? pe.y : 0, off = pe.z, ex_t = pe.w;
+        const uint32_t incl_t = ex_t + ll + ml;
+        const uint64_t mdst = opos + ex_t + ll; // absolute match destination
         const bool in_dict = valid && off > mdst - cx.frame_start;
         const bool islong = valid && (ll > kShort || ml > kShort || in_dict);
 
-        // ---- 3/4. runs of short sequences through LDS, long ones directly
+        // runs of short sequences through LDS, long ones directly
         uint32_t a = 0;
         while (a < cnt) {
             const uint32_t base_t = __builtin_amdgcn_readlane(ex_t, a);
@@ -886,7 +951,7 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
                 const uint32_t l = __builtin_amdgcn_readlane(ll, a), m = __builtin_amdgcn_readlane(ml, a);
                 const uint32_t o = __builtin_amdgcn_readlane(off, a), lp = __builtin_amdgcn_readlane(my_lit, a);
                 wg_fence(); // earlier flushes are visible
-                if (lane == 0) __atomic_store_n(cx.pub_pos, run_pos, __ATOMIC_RELAXED);
+                if (lane == 0) __atomic_store_n(&S.c.exec_pos, run_pos, __ATOMIC_RELAXED);
                 wave_copy(dst + run_pos, lit + lp, l, lane);
                 wg_fence();
                 uint8_t* d = dst + run_pos + l;
@@ -917,7 +982,7 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
             const int64_t rel_src = (int64_t)rel_m - (int64_t)off;
             const bool plain = off >= ml; // source and destination do not overlap
             wg_fence();
-            if (lane == 0) __atomic_store_n(cx.pub_pos, run_pos, __ATOMIC_RELAXED); // everything before this run has landed
+            if (lane == 0) __atomic_store_n(&S.c.exec_pos, run_pos, __ATOMIC_RELAXED); // everything before this run has landed
             bool pending = act && ml > 0;
             if (pending && plain && rel_src + (int64_t)ml <= 0) {
                 copy_short(ml, GlobalLd{dst + run_pos + rel_src}, LdsSt{stage + rel_m});
@@ -935,8 +1000,11 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
                     else { // overlapping match, or a source that straddles the start of the run
                         uint32_t idx = 0;
                         for (uint32_t k = 0; k < ml; k++) {
-                            int64_t p = rel_src + idx;
-                            stage[rel_m + k] = p < 0 ? dst[run_pos + p] : stage[p];
+                            const int64_t p = rel_src + idx;
+                            uint8_t bv; // two typed loads: hipcc 7.2 miscompiles a load through a pointer selected between HBM and LDS
+                            if (p < 0) bv = *(const __attribute__((address_space(1))) uint8_t*)(dst + run_pos + p);
+                            else bv = *(const __attribute__((address_space(3))) uint8_t*)(stage + p);
+                            stage[rel_m + k] = bv;
                             idx++;
                             if (idx == off) idx = 0;
                         }
@@ -960,17 +1028,26 @@ __device__ __noinline__ int execute_wave(Shared& S, uint4* seqs, uint32_t nseq_i
             a = b;
         }
         opos += chunk_tot;
-        lpos += chunk_lit;
+    }
+    // the literals after the last sequence: the planner has validated them once it is finished
+    uint32_t lpos = 0;
+    if (nseq) {
+        for (uint32_t it = 0; it < (1u << 24); it++) {
+            if (flag_load(&S.c.plan_prog) & kPlanFin) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
+        lpos = __atomic_load_n(&S.c.plan_lit_used, __ATOMIC_RELAXED);
+    } else {
+        if (cx.nlit > kBlockMax) return MZD_E_CORRUPT;
     }
     const uint32_t rest = cx.nlit - lpos;
-    if (rest > cx.cap - opos) return MZD_E_DSTSIZE;
-    if ((opos - block_start) + rest > kBlockMax) return MZD_E_CORRUPT;
     wave_copy(dst + opos, lit + lpos, rest, lane);
     opos += rest;
     wg_fence();
-    if (lane == 0) __atomic_store_n(cx.pub_pos, opos, __ATOMIC_RELAXED);
+    if (lane == 0) __atomic_store_n(&S.c.exec_pos, opos, __ATOMIC_RELAXED);
     *opos_io = opos;
-    if (lane == 0) { rep[0] = r0; rep[1] = r1; rep[2] = r2; }
     return 0;
 }
 
@@ -1027,7 +1104,7 @@ __device__ __noinline__ uint64_t xxh_finish(uint64_t v, const uint8_t* p, uint64
 }
 
 // ------------------------------------------------------------------------------------ K0 + block driver
-__device__ __noinline__ void parse_frame_or_skip(Shared& S, const uint8_t* src, uint64_t n, const DevDict* dicts, uint32_t ndicts, uint32_t job_dict) {
+__device__ __noinline__ void parse_frame_or_skip(const uint8_t* src, uint64_t n, const DevDict* dicts, uint32_t ndicts, uint32_t job_dict) {
     Ctl& c = S.c;
     uint64_t pos = c.pos;
     if (pos >= n) { c.action = 2; return; }
@@ -1077,7 +1154,7 @@ __device__ __noinline__ void parse_frame_or_skip(Shared& S, const uint8_t* src, 
     if (dd) c.action = 3; // frame with dictionary: tables are copied in by the workgroup
 }
 
-__device__ __noinline__ void parse_block_header(Shared& S, const uint8_t* src, uint64_t n) {
+__device__ __noinline__ void parse_block_header(const uint8_t* src, uint64_t n) {
     Ctl& c = S.c;
     if (n - c.pos < 3) { c.err = MZD_E_TRUNCATED; return; }
     uint32_t bh = ld24(src + c.pos);
@@ -1090,7 +1167,7 @@ __device__ __noinline__ void parse_block_header(Shared& S, const uint8_t* src, u
 }
 
 // literals section header (+ Huffman weights).  Lane 0.
-__device__ __noinline__ void parse_literals(Shared& S, const uint8_t* b, uint32_t n) {
+__device__ __noinline__ void parse_literals(const uint8_t* b, uint32_t n) {
     Ctl& c = S.c;
     uint32_t type = b[0] & 3, sf = (b[0] >> 2) & 3;
     uint32_t regen, comp = 0, hs, streams = 0;
@@ -1146,7 +1223,7 @@ __device__ __noinline__ void parse_literals(Shared& S, const uint8_t* b, uint32_
 }
 
 // sequences section header: nbSeq, modes, table descriptions.  Lane 0.
-__device__ __noinline__ void parse_seq_header(Shared& S, const uint8_t* b, uint32_t n) {
+__device__ __noinline__ void parse_seq_header(const uint8_t* b, uint32_t n) {
     Ctl& c = S.c;
     if (n < 1) { c.err = MZD_E_CORRUPT; return; }
     const uint8_t* p = b;
@@ -1181,7 +1258,7 @@ __device__ __noinline__ void parse_seq_header(Shared& S, const uint8_t* b, uint3
 }
 
 // The three sequence tables of a block, built one after the other by ONE wavefront.
-__device__ __noinline__ void build_tables_wave(Shared& S, int lane) {
+__device__ __noinline__ void build_tables_wave(int lane) {
     Ctl& c = S.c;
     for (int t = 0; t < 3; t++) {
         uint64_t* tab = t == 0 ? S.ll : (t == 1 ? S.of : S.ml);
@@ -1218,7 +1295,6 @@ __device__ __noinline__ void build_tables_wave(Shared& S, int lane) {
 #endif
 
 __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
-    __shared__ Shared S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* const lit_buf = a.lit_scratch + (size_t)blockIdx.x * kLitStride;
     uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
@@ -1247,7 +1323,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
 
         // ---------------- frames (K0)
         while (true) {
-            if (tid == 0 && !c.err) parse_frame_or_skip(S, src, n, a.dicts, a.ndicts, job_dict);
+            if (tid == 0 && !c.err) parse_frame_or_skip(src, n, a.dicts, a.ndicts, job_dict);
             WG_SNAPSHOT(err = c.err; action = c.action);
             if (err || action == 2) break;
             if (action == 1) continue; // skippable frame
@@ -1271,7 +1347,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
             // ---------------- blocks
             uint32_t last = 0;
             while (true) {
-                if (tid == 0) parse_block_header(S, src, n);
+                if (tid == 0) parse_block_header(src, n);
                 uint32_t btype = 0, bsize = 0;
                 uint64_t out0 = 0, pos0 = 0;
                 WG_SNAPSHOT(err = c.err; btype = c.btype; bsize = c.bsize; last = c.last; out0 = c.out; pos0 = c.pos);
@@ -1293,8 +1369,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     STAMP(0);
                     if (tid == 0) { // K0/K1/K3 headers: where everything is; nothing is decoded yet
                         c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = out0;
-                        parse_literals(S, blk, bsize);
-                        if (!c.err) parse_seq_header(S, src + c.seq_off, c.seq_len);
+                        c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0;
+                        parse_literals(blk, bsize);
+                        if (!c.err) parse_seq_header(src + c.seq_off, c.seq_len);
                     }
                     uint32_t lit_type = 0, nlit = 0, streams = 0, nseq = 0, seq_len = 0;
                     uint64_t lit_off = 0, seq_off = 0;
@@ -1303,13 +1380,18 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     if (err) break;
                     STAMP(1);
                     const uint8_t* const lit = lit_type == 0 ? src + lit_off : lit_buf;
-                    // ---- the block pipeline: wave 0 sequences (K3 tables, K4a walk); waves 1-3 literals
-                    //      (K1, K2); wave 1 then executes (K4b, K5) behind the walker
+                    // ---- the block pipeline, one role per wavefront:
+                    //   wave 0  K3 tables, K4a serial state walk
+                    //   wave 1  K1/K2 literals (streams 0,1), then the copying half of K5
+                    //   wave 2  K2 literals (streams 2,3), then K7 hashing behind the copier
+                    //   wave 3  K4b field conversion + repeat offsets + positions (the plan), behind the walker
                     if (wave == 0) {
                         if (nseq) {
-                            build_tables_wave(S, lane);
+                            build_tables_wave(lane);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) flag_store(&c.tables_ready, 1);
                             STAMP(4);
-                            int rc = walk_sequences_wave(S, src + seq_off, seq_len, nseq, walk, &c.walk_prog, lane);
+                            int rc = walk_sequences_wave(src + seq_off, seq_len, nseq, walk, &c.walk_prog, lane);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) {
                                 if (rc) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
@@ -1318,31 +1400,43 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             }
                             STAMP(5);
                         }
+                    } else if (wave == 3) {
+                        if (nseq) {
+                            int rc = MZD_E_CORRUPT;
+                            if (spin_ge(&c.tables_ready, 1, &c.err)) {
+                                PlanCtx px{walk, src + seq_off, &c.walk_prog, c.frame_out0, cap, c.dict_content_len, nlit};
+                                rc = plan_wave(seqs, nseq, px, out0, c.rep, lane);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) {
+                                if (rc && !__atomic_load_n(&c.err, __ATOMIC_RELAXED)) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
+                                flag_store(&c.plan_prog, flag_load(&c.plan_prog) | kPlanFin);
+                            }
+                        }
                     } else {
                         int rc = 0;
-                        if (lit_type == 2) { // K1: weights by one lane, table by 192
+                        if (lit_type == 2) { // K1: weights by one lane, table by 128
                             if (tid == 64) {
-                                int used = read_huf_weights(S, blk + c.huf_tree_off, c.huf_tree_len);
+                                int used = read_huf_weights(blk + c.huf_tree_off, c.huf_tree_len);
                                 if (used <= 0) __atomic_store_n(&c.err, MZD_E_CORRUPT, __ATOMIC_RELAXED);
                                 else c.huf_valid = 1;
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                 flag_store(&c.huf_ready, 1);
                             }
-                            if (spin_ge(&c.huf_ready, 1, &c.err)) fill_huf_table(S, tid - 64, kWG - 64);
+                            if (spin_ge(&c.huf_ready, 1, &c.err)) fill_huf_table(tid - 64, 128);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) __atomic_fetch_add(&c.huf_fill, 1u, __ATOMIC_RELAXED);
-                            spin_ge(&c.huf_fill, 3, &c.err);
+                            spin_ge(&c.huf_fill, 2, &c.err);
                         }
                         const bool failed = __atomic_load_n(&c.err, __ATOMIC_RELAXED) != 0;
                         if (lit_type == 1) { // RLE literals
                             uint32_t w = (uint32_t)src[lit_off] * 0x01010101u;
-                            for (uint32_t k = (uint32_t)(tid - 64) * 16; k < nlit; k += (kWG - 64) * 16)
+                            for (uint32_t k = (uint32_t)(tid - 64) * 16; k < nlit; k += 128 * 16)
                                 *reinterpret_cast<uint4*>(lit_buf + k) = make_uint4(w, w, w, w); // lit_buf has slack past nlit
-                        } else if (lit_type >= 2 && !failed) { // K2: wave 1 takes streams 0 and 3, wave 2 stream 1, wave 3 stream 2
+                        } else if (lit_type >= 2 && !failed) { // K2: wave 1 takes streams 0 and 1, wave 2 streams 2 and 3
                             const uint32_t hl = c.huf_log;
-                            const int first = wave == 1 ? 0 : wave - 1;
-                            if ((uint32_t)first < streams) rc = huf_stream_wave(blk + c.s_off[first], c.s_len[first], lit_buf + c.s_out[first], c.s_n[first], S.huf, hl, lane);
-                            if (!rc && wave == 1 && streams == 4) rc = huf_stream_wave(blk + c.s_off[3], c.s_len[3], lit_buf + c.s_out[3], c.s_n[3], S.huf, hl, lane);
+                            for (uint32_t st = (uint32_t)(wave - 1) * 2; st < (uint32_t)(wave - 1) * 2 + 2 && st < streams && !rc; st++)
+                                rc = huf_stream_wave(blk + c.s_off[st], c.s_len[st], lit_buf + c.s_out[st], c.s_n[st], S.huf, hl, lane);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) {
@@ -1350,17 +1444,17 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             __atomic_fetch_add(&c.lit_done, 1u, __ATOMIC_RELAXED);
                         }
                         STAMP(3);
-                        if (wave == 1) { // K4b + K5
+                        if (wave == 1) { // the copying half of K5
                             uint64_t opos = out0;
                             rc = MZD_E_CORRUPT;
-                            if (spin_ge(&c.lit_done, 3, &c.err)) {
-                                ExecCtx cx{walk, src + seq_off, &c.walk_prog, &c.err, &c.exec_pos, dst, c.frame_out0, cap, c.dict_content, c.dict_content_len, lit, nlit};
-                                rc = execute_wave(S, seqs, nseq, cx, &opos, c.rep, lane);
+                            if (spin_ge(&c.lit_done, 2, &c.err)) {
+                                CopyCtx cx{dst, c.frame_out0, c.dict_content, c.dict_content_len, lit, nlit};
+                                rc = copy_wave(nseq, cx, &opos, lane);
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                            if (lane == 0) flag_store(&c.exec_done, 1);
                             if (lane == 0) {
                                 if (rc && !__atomic_load_n(&c.err, __ATOMIC_RELAXED)) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
+                                flag_store(&c.exec_done, 1);
                                 c.out = opos; c.pos = pos0 + bsize;
                                 if (a.debug) {
                                     DebugSlot& ds = a.debug[blockIdx.x];
@@ -1368,7 +1462,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                                 }
                             }
                             STAMP(6);
-                        } else if (wave == 2 && hashing) { // K7: hash behind the executor while it works
+                        } else if (hashing) { // wave 2, K7: hash behind the copier while it works
                             const uint8_t* fp = dst + c.frame_out0;
                             for (uint32_t it = 0; it < (1u << 24); it++) {
                                 const uint32_t fin = flag_load(&c.exec_done);
@@ -1421,7 +1515,6 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
 // Dictionary (A.7) -> DevDict: the entropy tables in the exact LDS layout, built once on the
 // device with the same routines the decoder uses.  One workgroup.
 __global__ __launch_bounds__(kWG) void mzd_dict_kernel(const uint8_t* dict, uint32_t n, DevDict* out, int32_t* status) {
-    __shared__ Shared S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Ctl& c = S.c;
     __shared__ uint32_t pos_after_huf, pos_after_tables;
@@ -1429,7 +1522,7 @@ __global__ __launch_bounds__(kWG) void mzd_dict_kernel(const uint8_t* dict, uint
         c.err = 0; c.action = 0;
         if (n < 8 || ld32(dict) != 0xEC30A437u) c.action = 1; // raw content
         else {
-            int used = read_huf_weights(S, dict + 8, n - 8);
+            int used = read_huf_weights(dict + 8, n - 8);
             if (used <= 0) c.err = MZD_E_DICT;
             pos_after_huf = 8 + (uint32_t)(used > 0 ? used : 0);
         }
@@ -1444,7 +1537,7 @@ __global__ __launch_bounds__(kWG) void mzd_dict_kernel(const uint8_t* dict, uint
         return;
     }
     if (c.err) { if (tid == 0) *status = c.err; return; }
-    fill_huf_table(S, tid, kWG);
+    fill_huf_table(tid, kWG);
     __syncthreads();
     if (tid == 0) {
         const uint8_t* p = dict + pos_after_huf;
@@ -1463,7 +1556,7 @@ __global__ __launch_bounds__(kWG) void mzd_dict_kernel(const uint8_t* dict, uint
     }
     __syncthreads();
     if (c.err) { if (tid == 0) *status = MZD_E_DICT; return; }
-    if (wave == 0) build_tables_wave(S, lane);
+    if (wave == 0) build_tables_wave(lane);
     __syncthreads();
     for (int i = tid; i < 512; i += kWG) { out->ll[i] = S.ll[i]; out->ml[i] = S.ml[i]; }
     for (int i = tid; i < 256; i += kWG) out->of[i] = S.of[i];
