@@ -141,17 +141,30 @@ __device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want, const 
 
 // ------------------------------------------------------------------------------------ K3
 // Normalized-count header (A.3), forward bitstream.  Lane 0.  Returns bytes used or < 0.
-__device__ __noinline__ int read_ncount(const uint8_t* src, uint32_t n, int max_log, int max_sym, int16_t* norm, uint32_t* nsym_out, uint32_t* log_out) {
+// LD(byte) returns the 8 bytes at `byte` of the header (readable past its end); the variants differ only in
+// where the header lives: HBM (dictionary, Huffman weights) or the LDS staging area (sequence headers).
+template <class LD>
+__device__ __forceinline__ int read_ncount_t(LD ld, uint32_t n, int max_log, int max_sym, int16_t* norm, uint32_t* nsym_out, uint32_t* log_out) {
     if (n < 1) return MZD_E_CORRUPT;
-    int32_t bit = 0, limit = (int32_t)(n > 4096 ? 4096 : n) * 8;
-    int al = 5 + (int)bits_at(src, n, bit, 4);
+    const int32_t limit = (int32_t)(n > 4096 ? 4096 : n) * 8;
+    // bits [bit, bit+nb) of the header, zero past its end; nb <= 16
+    auto take = [&](int32_t bit, int nb) -> int {
+        uint32_t byte = (uint32_t)bit >> 3;
+        if (byte >= n) return 0;
+        uint64_t v = ld(byte);
+        uint32_t avail = n - byte;
+        if (avail < 8) v &= (1ull << (avail * 8)) - 1;
+        return (int)((v >> (bit & 7)) & ((1u << nb) - 1));
+    };
+    int32_t bit = 0;
+    int al = 5 + take(bit, 4);
     bit += 4;
     if (al > max_log) return MZD_E_CORRUPT;
     int remaining = 1 << al, sym = 0;
     while (remaining > 0 && sym <= max_sym) {
         int nb = hibit((uint32_t)(remaining + 1)) + 1;
         if (bit >= limit) return MZD_E_CORRUPT;
-        int val = (int)bits_at(src, n, bit, nb);
+        int val = take(bit, nb);
         bit += nb;
         int lower = (1 << (nb - 1)) - 1;
         int thr = (1 << nb) - 1 - (remaining + 1);
@@ -164,7 +177,7 @@ __device__ __noinline__ int read_ncount(const uint8_t* src, uint32_t n, int max_
         if (p == 0) {
             for (;;) {
                 if (bit >= limit) return MZD_E_CORRUPT;
-                int r = (int)bits_at(src, n, bit, 2);
+                int r = take(bit, 2);
                 bit += 2;
                 for (int i = 0; i < r; i++) { if (sym > max_sym) return MZD_E_CORRUPT; norm[sym++] = 0; }
                 if (r != 3) break;
@@ -175,6 +188,17 @@ __device__ __noinline__ int read_ncount(const uint8_t* src, uint32_t n, int max_
     *nsym_out = (uint32_t)sym;
     *log_out = (uint32_t)al;
     return (bit + 7) >> 3;
+}
+struct HbmBytes { const uint8_t* p; __device__ __forceinline__ uint64_t operator()(uint32_t o) const { return ldu64(p + o); } };
+struct StageBytes { // offset into S.stage
+    uint32_t base;
+    __device__ __forceinline__ uint64_t operator()(uint32_t o) const { uint64_t v; __builtin_memcpy(&v, &S.stage[base + o], 8); return v; }
+};
+__device__ __noinline__ int read_ncount(const uint8_t* src, uint32_t n, int max_log, int max_sym, int16_t* norm, uint32_t* nsym_out, uint32_t* log_out) {
+    return read_ncount_t(HbmBytes{src}, n, max_log, max_sym, norm, nsym_out, log_out);
+}
+__device__ __noinline__ int read_ncount_staged(uint32_t stage_off, uint32_t n, int max_log, int max_sym, int16_t* norm, uint32_t* nsym_out, uint32_t* log_out) {
+    return read_ncount_t(StageBytes{stage_off}, n, max_log, max_sym, norm, nsym_out, log_out);
 }
 
 // number of extra bits of a code: kind 0 LL, 1 OF, 2 ML
@@ -453,7 +477,7 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, int lane) {
 //   B (lane = 8 slots) slot -> symbol by a max-scan over range-start marks
 //   C (lane = step j)  position (j*step)&mask, ranked among the positions below `high` by ballot
 //   D (lane = symbol)  state numbering in table order: every symbol walks the table once
-// tmp: 1 KiB of LDS scratch (tabsym[512], mark[512]).
+// tmp: 2 KiB of LDS scratch (tabsym[512], mark[512], per-symbol masks / counters / extra-bit counts).
 __device__ __noinline__ void build_seq_table_wave(uint64_t* tab, const int16_t* norm, uint32_t nsym, uint32_t log, int kind, uint8_t* tmp, int lane) {
     uint8_t* const tabsym = tmp;
     uint8_t* const mark = tmp + 512;
@@ -493,23 +517,32 @@ __device__ __noinline__ void build_seq_table_wave(uint64_t* tab, const int16_t* 
             running += (uint32_t)__builtin_popcountll(bal);
         }
     }
-    // D: 16 table positions per LDS read (every lane reads the same 16 bytes: a broadcast)
+    // D (lane = table position, 64 ascending positions per step): the state number of a position is the
+    // symbol's count + the number of lower positions holding the same symbol.  Inside a step that rank
+    // comes from a per-symbol lane mask built with LDS atomic ORs; across steps from a per-symbol counter.
     {
-        const bool mine = (uint32_t)lane < nsym && c != 0;
-        uint32_t d = c == -1 ? 1u : (uint32_t)c;
-        const uint32_t extra = mine ? code_extra((uint32_t)lane, kind) : 0;
-        const uint32_t hi_const = ((uint32_t)lane << 16) | (extra << 24);
-        for (uint32_t i0 = 0; i0 < size; i0 += 16) {
-            const uint4 w = *reinterpret_cast<const uint4*>(tabsym + i0);
-            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int t = 0; t < 16; t++) {
-                const uint32_t sy = (ww[t >> 2] >> ((t & 3) * 8)) & 0xFF;
-                if (mine && sy == (uint32_t)lane) {
-                    const uint32_t nb = log - (uint32_t)hibit(d);
-                    const uint32_t hi = nb | ((extra + nb) << 8) | hi_const;
-                    tab[i0 + t] = (uint64_t)(((d << nb) - size) * 8u) | ((uint64_t)hi << 32);
-                    d++;
+        uint64_t* const smask = reinterpret_cast<uint64_t*>(tmp + 1024); // [64]
+        uint32_t* const scnt = reinterpret_cast<uint32_t*>(tmp + 1536);  // [64]
+        uint32_t* const sext = reinterpret_cast<uint32_t*>(tmp + 1792);  // [64] extra bits of each code
+        smask[lane] = 0;
+        scnt[lane] = c == -1 ? 1u : (c > 0 ? (uint32_t)c : 0u);
+        sext[lane] = (uint32_t)lane < nsym ? code_extra((uint32_t)lane, kind) : 0;
+        for (uint32_t i0 = 0; i0 < size; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool act = i < size;
+            const uint32_t sy = act ? tabsym[i] : 63;
+            if (act) __atomic_fetch_or(&smask[sy], 1ull << lane, __ATOMIC_RELAXED);
+            const uint64_t m = __atomic_load_n(&smask[sy], __ATOMIC_RELAXED);
+            const uint32_t basec = scnt[sy];
+            if (act) {
+                const uint32_t d = basec + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1));
+                const uint32_t nb = log - (uint32_t)hibit(d);
+                const uint32_t extra = sext[sy];
+                const uint32_t hi = nb | ((extra + nb) << 8) | (sy << 16) | (extra << 24);
+                tab[i] = (uint64_t)(((d << nb) - size) * 8u) | ((uint64_t)hi << 32);
+                if ((uint32_t)lane == 63u - (uint32_t)__builtin_clzll(m)) { // the symbol's highest position in this step
+                    scnt[sy] = basec + (uint32_t)__builtin_popcountll(m);
+                    __atomic_store_n(&smask[sy], 0ull, __ATOMIC_RELAXED);
                 }
             }
         }
@@ -1246,7 +1279,8 @@ __device__ __noinline__ void parse_seq_header(const uint8_t* b, uint32_t n) {
             if (p + 1 > end || *p > max_sym[t]) { c.err = MZD_E_CORRUPT; return; }
             c.nsym[t] = *p++; // the symbol itself
         } else if (m == 2) {
-            int used = read_ncount(p, (uint32_t)(end - p), max_log[t], max_sym[t], S.norm[t], &c.nsym[t], &c.al[t]);
+            // the header was staged at S.stage + 256 by the caller
+            int used = read_ncount_staged(256 + (uint32_t)(p - b), (uint32_t)(end - p), max_log[t], max_sym[t], S.norm[t], &c.nsym[t], &c.al[t]);
             if (used <= 0) { c.err = MZD_E_CORRUPT; return; }
             p += used;
         } else if (m == 3) {
@@ -1367,16 +1401,26 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                 } else {
                     const uint8_t* const blk = src + pos0;
                     STAMP(0);
-                    if (tid == 0) { // K0/K1/K3 headers: where everything is; nothing is decoded yet
+                    // K0/K1/K3 headers: where everything is; nothing is decoded yet.  The two header regions
+                    // (<= 256 bytes each: literals header + tree extent + jump table; sequence count, modes and
+                    // the three normalized-count headers) are staged in LDS first, so that lane 0's byte-wise
+                    // parsing does not pay an HBM round trip per byte.
+                    for (uint32_t k = tid; k < bsize && k < 256; k += kWG) S.stage[k] = blk[k];
+                    __syncthreads();
+                    if (tid == 0) {
                         c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = out0;
                         c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0;
-                        parse_literals(blk, bsize);
-                        if (!c.err) parse_seq_header(src + c.seq_off, c.seq_len);
+                        parse_literals(S.stage, bsize);
                     }
                     uint32_t lit_type = 0, nlit = 0, streams = 0, nseq = 0, seq_len = 0;
                     uint64_t lit_off = 0, seq_off = 0;
                     WG_SNAPSHOT(err = c.err; lit_type = c.lit_type; nlit = c.nlit; streams = c.streams; lit_off = c.lit_off;
-                                nseq = c.nseq; seq_off = c.seq_off; seq_len = c.seq_len);
+                                seq_off = c.seq_off; seq_len = c.seq_len);
+                    if (err) break;
+                    for (uint32_t k = tid; k < seq_len && k < 256; k += kWG) S.stage[256 + k] = src[seq_off + k];
+                    __syncthreads();
+                    if (tid == 0) parse_seq_header(S.stage + 256, seq_len);
+                    WG_SNAPSHOT(err = c.err; nseq = c.nseq; seq_off = c.seq_off; seq_len = c.seq_len);
                     if (err) break;
                     STAMP(1);
                     const uint8_t* const lit = lit_type == 0 ? src + lit_off : lit_buf;
