@@ -68,7 +68,7 @@ struct __attribute__((aligned(16))) Shared {
     uint64_t ml[512];
     uint64_t of[256];
     uint8_t ring[kRingBytes + 16];
-    uint8_t stage[2048 + 16]; // K5 staging buffer (kStage)
+    uint8_t stage[2 * (2048 + 16)]; // K5 staging: the run being assembled and the previous run (kStage each)
     uint4 planA[4][64];       // plan ring (kPlanRing chunks): {ll, ml, off, output offset inside the chunk}
     uint32_t planB[4][64];    //   literal index of each sequence
     uint32_t plan_hdr[4][4];  //   per chunk: bytes, sequences
@@ -784,22 +784,35 @@ __device__ __forceinline__ uint32_t rep_eval(const RepOp& f, int j, uint32_t r0,
     return src == 3 ? (uint32_t)v : in + (uint32_t)v;
 }
 
-// copy n (<= 64) bytes with 8-byte accesses and an exact 4/2/1 tail; all loads are issued before the stores
+// copy n (<= 64) bytes with 8-byte accesses and an exact 4/2/1 tail; all loads are issued before the stores.
+// The two halves are separate so that several copies can have their loads in flight together.
+struct ShortRegs { uint64_t v[8]; uint32_t t4, t2, t1; };
+template <class LD>
+__device__ __forceinline__ void short_load(uint32_t n, LD ld, ShortRegs& r) {
+    const uint32_t q = n >> 3;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) r.v[j] = j < q ? ld.u64(j * 8) : 0;
+    const uint32_t t = q * 8;
+    r.t4 = 0; r.t2 = 0; r.t1 = 0;
+    if (n & 4) r.t4 = ld.u32(t);
+    if (n & 2) r.t2 = ld.u16(t + (n & 4));
+    if (n & 1) r.t1 = ld.u8(t + (n & 6));
+}
+template <class ST>
+__device__ __forceinline__ void short_store(uint32_t n, ST st, const ShortRegs& r) {
+    const uint32_t q = n >> 3;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) if (j < q) st.u64(j * 8, r.v[j]);
+    const uint32_t t = q * 8;
+    if (n & 4) st.u32(t, r.t4);
+    if (n & 2) st.u16(t + (n & 4), r.t2);
+    if (n & 1) st.u8(t + (n & 6), r.t1);
+}
 template <class LD, class ST>
 __device__ __forceinline__ void copy_short(uint32_t n, LD ld, ST st) {
-    uint64_t v[8];
-    uint32_t q = n >> 3;
-#pragma unroll
-    for (uint32_t j = 0; j < 8; j++) v[j] = j < q ? ld.u64(j * 8) : 0;
-    uint32_t t = q * 8, t4 = 0, t2 = 0, t1 = 0;
-    if (n & 4) { t4 = ld.u32(t); }
-    if (n & 2) { t2 = ld.u16(t + (n & 4)); }
-    if (n & 1) { t1 = ld.u8(t + (n & 6)); }
-#pragma unroll
-    for (uint32_t j = 0; j < 8; j++) if (j < q) st.u64(j * 8, v[j]);
-    if (n & 4) st.u32(t, t4);
-    if (n & 2) st.u16(t + (n & 4), t2);
-    if (n & 1) st.u8(t + (n & 6), t1);
+    ShortRegs r;
+    short_load(n, ld, r);
+    short_store(n, st, r);
 }
 struct GlobalLd {
     const uint8_t* p;
@@ -948,9 +961,10 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
     uint8_t* const dst = cx.dst;
     const uint8_t* const lit = cx.lit;
-    uint8_t* const stage = S.stage;
     uint64_t opos = *opos_io;
     uint32_t chunk = 0;
+    uint32_t cur = 0, prevT = 0; // staging buffer in use; length of the previous run
+    bool prev_valid = false;     // the other staging buffer holds the run that ends where this one starts
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         { // wait for the plan of this chunk
             uint32_t pg = 0;
@@ -1000,6 +1014,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 } else if (o >= m) wave_copy(d, d - o, m, lane);
                 else wave_pattern(d, o, m, lane);
                 wg_fence();
+                prev_valid = false;
                 a++;
                 continue;
             }
@@ -1009,18 +1024,29 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             const uint32_t T = __builtin_amdgcn_readlane(incl_t, b - 1) - base_t;
             const bool act = (uint32_t)lane >= a && (uint32_t)lane < b;
             const uint32_t rel_out = ex_t - base_t, rel_m = rel_out + ll;
-            // literals: HBM -> LDS
-            if (act && ll) copy_short(ll, GlobalLd{lit + my_lit}, LdsSt{stage + rel_out});
-            // matches whose whole source lies before the run: HBM -> LDS (earlier flushes must have landed)
+            uint8_t* const sb = S.stage + cur * (kStage + 16);             // this run
+            const uint8_t* const pb = S.stage + (cur ^ 1u) * (kStage + 16); // the previous run, still in LDS
+            // Where a match's source lives.  Relative to the start of this run:
+            //   >= 0                     this run: resolved LDS -> LDS in rounds
+            //   [-prevT, 0)              the previous run: LDS -> LDS at once (its flush may still be in flight)
+            //   < -prevT                 older output: HBM.  Every flush waits for the one before it, so
+            //                            everything older than the previous run has landed.
             const int64_t rel_src = (int64_t)rel_m - (int64_t)off;
             const bool plain = off >= ml; // source and destination do not overlap
-            wg_fence();
-            if (lane == 0) __atomic_store_n(&S.c.exec_pos, run_pos, __ATOMIC_RELAXED); // everything before this run has landed
-            bool pending = act && ml > 0;
-            if (pending && plain && rel_src + (int64_t)ml <= 0) {
-                copy_short(ml, GlobalLd{dst + run_pos + rel_src}, LdsSt{stage + rel_m});
-                pending = false;
+            const bool has = act && ml > 0;
+            const bool before = has && plain && rel_src + (int64_t)ml <= 0;
+            const int64_t pdist = -rel_src;
+            const bool from_prev = before && prev_valid && pdist <= (int64_t)prevT;
+            const bool from_hbm = before && !from_prev && (!prev_valid || pdist - (int64_t)ml >= (int64_t)prevT);
+            { // one HBM round trip for the literals and the old matches of the whole run
+                ShortRegs A, B;
+                if (act && ll) short_load(ll, GlobalLd{lit + my_lit}, A);
+                if (from_hbm) short_load(ml, GlobalLd{dst + run_pos + rel_src}, B);
+                if (from_prev) copy_short(ml, LdsLd{pb + (prevT - (uint32_t)pdist)}, LdsSt{sb + rel_m});
+                if (act && ll) short_store(ll, LdsSt{sb + rel_out}, A);
+                if (from_hbm) short_store(ml, LdsSt{sb + rel_m}, B);
             }
+            bool pending = has && !from_prev && !from_hbm;
             // the rest in rounds, LDS -> LDS
             const uint32_t span = ml < off ? ml : off;
             uint64_t pm = __ballot(pending);
@@ -1029,15 +1055,16 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 const int64_t hwm = (int64_t)__builtin_amdgcn_readlane(rel_m, first);
                 const bool ready = pending && rel_src + (int64_t)span <= hwm;
                 if (ready) {
-                    if (plain && rel_src >= 0) copy_short(ml, LdsLd{stage + rel_src}, LdsSt{stage + rel_m});
-                    else { // overlapping match, or a source that straddles the start of the run
+                    if (plain && rel_src >= 0) copy_short(ml, LdsLd{sb + rel_src}, LdsSt{sb + rel_m});
+                    else { // overlapping match, or a source that straddles a boundary: byte by byte, three-way source
                         uint32_t idx = 0;
                         for (uint32_t k = 0; k < ml; k++) {
                             const int64_t p = rel_src + idx;
-                            uint8_t bv; // two typed loads: hipcc 7.2 miscompiles a load through a pointer selected between HBM and LDS
-                            if (p < 0) bv = *(const __attribute__((address_space(1))) uint8_t*)(dst + run_pos + p);
-                            else bv = *(const __attribute__((address_space(3))) uint8_t*)(stage + p);
-                            stage[rel_m + k] = bv;
+                            uint8_t bv; // typed loads: hipcc 7.2 miscompiles a load through a pointer selected between HBM and LDS
+                            if (p >= 0) bv = *(const __attribute__((address_space(3))) uint8_t*)(sb + p);
+                            else if (prev_valid && -p <= (int64_t)prevT) bv = *(const __attribute__((address_space(3))) uint8_t*)(pb + ((int64_t)prevT + p));
+                            else bv = *(const __attribute__((address_space(1))) uint8_t*)(dst + run_pos + p);
+                            sb[rel_m + k] = bv;
                             idx++;
                             if (idx == off) idx = 0;
                         }
@@ -1046,18 +1073,21 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 pending = pending && !ready;
                 pm = __ballot(pending);
             }
-            // flush the run: LDS -> HBM, 16 bytes per lane
+            // flush the run: LDS -> HBM, 16 bytes per lane.  First wait for the previous flush.
+            wg_fence();
+            if (lane == 0) __atomic_store_n(&S.c.exec_pos, run_pos, __ATOMIC_RELAXED); // everything before this run has landed
             {
                 uint8_t* g = dst + run_pos;
                 for (uint32_t k = (uint32_t)lane * 16; k < T; k += 1024) {
                     if (k + 16 <= T) {
-                        uint4 v = *reinterpret_cast<const uint4*>(stage + k);
+                        uint4 v = *reinterpret_cast<const uint4*>(sb + k);
                         __builtin_memcpy(g + k, &v, 16);
                     } else {
-                        for (uint32_t j = k; j < T; j++) g[j] = stage[j];
+                        for (uint32_t j = k; j < T; j++) g[j] = sb[j];
                     }
                 }
             }
+            prev_valid = true; prevT = T; cur ^= 1u;
             a = b;
         }
         opos += chunk_tot;
