@@ -468,6 +468,7 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
     DebugSlot ds;
     HIPCHK(hipMemcpy(&ds, d->debug + slot, sizeof(ds), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out8[i] = ds.stamp[i];
+    for (int i = 0; i < 8; i++) out8[8 + i] = ds.cstamp[i];
     return MZD_OK;
 }
 

@@ -29,6 +29,22 @@
 
 namespace mzd {
 
+// Diagnostic build only: per-phase cycle sums of the workgroup (lane 0), never in the product .so.
+#ifdef MZD_STAMPS
+#define STAMP_DECL uint64_t st_prev = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#define STAMP_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 8; k_++) { a.debug[blockIdx.x].stamp[k_] = st_acc[k_]; a.debug[blockIdx.x].cstamp[k_] = S.cdiag[k_]; } a.debug[blockIdx.x].stamp[2] = S.c.diag_slow; } } while (0)
+#define CSTAMP_DECL uint64_t cs_prev = __builtin_readcyclecounter()
+#define CSTAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); if (lane == 0) S.cdiag[k] += t_ - cs_prev; cs_prev = t_; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH()
+#define CSTAMP_DECL
+#define CSTAMP(k)
+#endif
+
+
 // ------------------------------------------------------------------------------------ LDS
 constexpr int kRingBytes = 8192; // sequence-bitstream ring: 8 chunks of 1 KiB (+16 mirrored bytes)
 constexpr int kChunk = 1024;
@@ -62,16 +78,19 @@ struct Ctl {
 };
 
 struct __attribute__((aligned(16))) Shared {
+    uint8_t ring[kRingBytes + 16]; // first: at LDS offset 0 the walker's window address needs no base add
     // FSE decode entries, 8 bytes: low dword = byte offset of the next state's entry before the
     // fresh bits are added (8 * nextStateBase); high dword = nbBits | (extra+nbBits) << 8 | symbol << 16 | extra << 24
     uint64_t ll[512];
     uint64_t ml[512];
     uint64_t of[256];
-    uint8_t ring[kRingBytes + 16];
     uint8_t stage[2 * (2048 + 16)]; // K5 staging: the run being assembled and the previous run (kStage each)
     uint4 planA[4][64];       // plan ring (kPlanRing chunks): {ll, ml, off, output offset inside the chunk}
     uint32_t planB[4][64];    //   literal index of each sequence
     uint32_t plan_hdr[4][4];  //   per chunk: bytes, sequences
+#ifdef MZD_STAMPS
+    uint64_t cdiag[8];
+#endif
     uint16_t huf[2048]; // sym | len << 8
     int16_t norm[3][64];
     uint16_t next[3][64];
@@ -604,7 +623,7 @@ __device__ __forceinline__ uint64_t ring_read64(uint32_t e) {
     return v;
 }
 
-// walk record: x = LL state offset | ML state offset << 12 ; y = g-bit position | OF state offset << 21
+// walk record: x = LL state offset | ML state offset << 12 ; y = (g-bit position - 32) | OF state offset << 21
 //   (state offsets are byte offsets into the tables: 8 * state)
 constexpr uint32_t kWalkBatch = 32; // sequences between two ring checks (<= 89 bits each)
 
@@ -665,6 +684,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
             }
         }
         const uint32_t stop = i + kWalkBatch < nupd ? i + kWalkBatch : nupd;
+        uint32_t Gm = G - 32; // the loop carries the read head minus 32 (saves an add per sequence)
         // One step of the chain.  CAREFUL = false is the hot form: no branch at all; it only notes (in
         // `bad`) that some sequence had more bits than its window holds (long extra-bit fields: about
         // one sequence in thousands).  The batch is then redone with CAREFUL = true, which moves the
@@ -675,18 +695,18 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
             __builtin_memcpy(&eL, tL + vL, 8);
             __builtin_memcpy(&eM, tM + vM, 8);
             __builtin_memcpy(&eO, tO + vO, 8);
-            // window: the 8 ring bytes at the 4-byte aligned address whose 64 bits end at or above the
-            // read head (two aligned dwords; an unaligned 8-byte LDS read costs ~40 cycles more)
-            const uint32_t u = G - 33;
+            // window: the 8 ring bytes at the 4-byte aligned address whose 64 bits end above the read head
+            // (two aligned dwords; an unaligned 8-byte LDS read costs ~40 cycles more)
+            const uint32_t u = Gm; // read head - 32
             uint32_t ra = (u >> 3) & (kRingBytes - 4);
             uint64_t X;
             __builtin_memcpy(&X, &S.ring[ra], 8);
-            *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(G | (vO << 21)) << 32);
+            *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(Gm | (vO << 21)) << 32);
             woff += 8;
             asm volatile("" : "+v"(X)); // keep all four LDS reads in flight together
             const uint32_t hL = (uint32_t)(eL >> 32), hM = (uint32_t)(eM >> 32), hO = (uint32_t)(eO >> 32);
             const uint32_t total = ((hL + hM + hO) >> 8) & 0xFF;
-            uint32_t av = (u & 31) + 33; // bits of the window below the read head: 33..64
+            uint32_t av = (u & 31) | 32; // bits of the window below the read head: 32..63
             if (decltype(careful)::value) {
                 while (__builtin_amdgcn_ballot_w64(total > av) != 0) {
                     ra = (ra - 4) & (kRingBytes - 4);
@@ -697,24 +717,24 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
                 bad |= __builtin_amdgcn_ballot_w64(total > av);
             }
             // fresh state bits sit at the bottom of what this sequence consumes: OF lowest, then ML, then LL
-            const uint32_t oO = av - total;
-            const uint32_t oM = oO + hO; // only the low 6 bits matter (nbBits lives in [5:0])
-            const uint32_t oL = oM + hM;
-            const uint32_t bO = __builtin_amdgcn_ubfe((uint32_t)(X >> (oO & 63)), 0, hO);
-            const uint32_t bM = __builtin_amdgcn_ubfe((uint32_t)(X >> (oM & 63)), 0, hM);
-            const uint32_t bL = __builtin_amdgcn_ubfe((uint32_t)(X >> (oL & 63)), 0, hL);
+            // (at most 26 bits together: one 64-bit shift, then 32-bit field extracts)
+            const uint32_t Y = (uint32_t)(X >> ((av - total) & 63));
+            const uint32_t bO = __builtin_amdgcn_ubfe(Y, 0, hO);           // width = nbBits, the low bits of the entry
+            const uint32_t bM = __builtin_amdgcn_ubfe(Y, hO, hM);          // offset nbO (low 5 bits)
+            const uint32_t bL = __builtin_amdgcn_ubfe(Y, hO + hM, hL);     // offset nbO + nbM
             vO = (uint32_t)eO + (bO << 3);
             vM = (uint32_t)eM + (bM << 3);
             vL = (uint32_t)eL + (bL << 3);
-            G -= total;
+            Gm -= total;
         };
-        const uint32_t sL = vL, sM = vM, sO = vO, sG = G, sW = woff, i0 = i;
+        const uint32_t sL = vL, sM = vM, sO = vO, sG = Gm, sW = woff, i0 = i;
         bad = 0;
         for (; i < stop; i++) step(std::false_type{});
         if (__builtin_expect(bad != 0, 0)) {
-            vL = sL; vM = sM; vO = sO; G = sG; woff = sW;
+            vL = sL; vM = sM; vO = sO; Gm = sG; woff = sW;
             for (i = i0; i < stop; i++) step(std::true_type{});
         }
+        G = Gm + 32;
         if ((int32_t)(G - Gzero) < 0) return MZD_E_CORRUPT; // over-read
         // publish the batch BEFORE this one: all but the newest kWalkBatch stores have landed
         asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -726,7 +746,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         __builtin_memcpy(&eL, tL + vL, 8);
         __builtin_memcpy(&eM, tM + vM, 8);
         __builtin_memcpy(&eO, tO + vO, 8);
-        *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(G | (vO << 21)) << 32);
+        *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = (uint64_t)(vL | (vM << 12)) | ((uint64_t)((G - 32) | (vO << 21)) << 32);
         uint32_t extra = (uint32_t)(eL >> 56) + (uint32_t)(eM >> 56) + (uint32_t)(eO >> 56);
         if (G - Gzero != extra) return MZD_E_CORRUPT; // the bitstream must be consumed exactly
     }
@@ -884,7 +904,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
             const uint32_t bias = 16 + (uint32_t)((uintptr_t)cx.seq_sp & 15);
             const uint8_t* gbase = cx.seq_sp - bias;
             uint2 w = cx.walk[i];
-            uint32_t vL = w.x & 0xFFF, vM = w.x >> 12, vO = w.y >> 21, G = w.y & 0x1FFFFF;
+            uint32_t vL = w.x & 0xFFF, vM = w.x >> 12, vO = w.y >> 21, G = (w.y & 0x1FFFFF) + 32; // records carry the read head - 32
             uint32_t hL = (uint32_t)(S.ll[vL >> 3] >> 32), hM = (uint32_t)(S.ml[vM >> 3] >> 32), hO = (uint32_t)(S.of[vO >> 3] >> 32);
             uint32_t cL = (hL >> 16) & 0xFF, cM = (hM >> 16) & 0xFF, cO = (hO >> 16) & 0xFF;
             uint32_t xL = hL >> 24, xM = hM >> 24, xO = hO >> 24;
@@ -965,6 +985,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     uint32_t chunk = 0;
     uint32_t cur = 0, prevT = 0; // staging buffer in use; length of the previous run
     bool prev_valid = false;     // the other staging buffer holds the run that ends where this one starts
+    CSTAMP_DECL;
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         { // wait for the plan of this chunk
             uint32_t pg = 0;
@@ -976,6 +997,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             if ((pg & ~kPlanFin) <= chunk) return MZD_E_CORRUPT; // the planner failed and posted the error
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
+        CSTAMP(0);
         const uint32_t slot = chunk & (kPlanRing - 1);
         const uint4 pe = S.planA[slot][lane];
         const uint32_t my_lit = S.planB[slot][lane];
@@ -1038,6 +1060,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             const int64_t pdist = -rel_src;
             const bool from_prev = before && prev_valid && pdist <= (int64_t)prevT;
             const bool from_hbm = before && !from_prev && (!prev_valid || pdist - (int64_t)ml >= (int64_t)prevT);
+            CSTAMP(1);
             { // one HBM round trip for the literals and the old matches of the whole run
                 ShortRegs A, B;
                 if (act && ll) short_load(ll, GlobalLd{lit + my_lit}, A);
@@ -1047,6 +1070,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 if (from_hbm) short_store(ml, LdsSt{sb + rel_m}, B);
             }
             bool pending = has && !from_prev && !from_hbm;
+            CSTAMP(2);
             // the rest in rounds, LDS -> LDS
             const uint32_t span = ml < off ? ml : off;
             uint64_t pm = __ballot(pending);
@@ -1073,8 +1097,10 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 pending = pending && !ready;
                 pm = __ballot(pending);
             }
+            CSTAMP(3);
             // flush the run: LDS -> HBM, 16 bytes per lane.  First wait for the previous flush.
             wg_fence();
+            CSTAMP(4);
             if (lane == 0) __atomic_store_n(&S.c.exec_pos, run_pos, __ATOMIC_RELAXED); // everything before this run has landed
             {
                 uint8_t* g = dst + run_pos;
@@ -1088,6 +1114,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 }
             }
             prev_valid = true; prevT = T; cur ^= 1u;
+            CSTAMP(5);
             a = b;
         }
         opos += chunk_tot;
@@ -1347,16 +1374,6 @@ __device__ __noinline__ void build_tables_wave(int lane) {
 // next step rewrites it, and all 256 lanes always take the same branch.
 #define WG_SNAPSHOT(...) do { __syncthreads(); __VA_ARGS__; __syncthreads(); } while (0)
 
-// Diagnostic build only: per-phase cycle sums of the workgroup (lane 0), never in the product .so.
-#ifdef MZD_STAMPS
-#define STAMP_DECL uint64_t st_prev = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define STAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
-#define STAMP_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 8; k_++) a.debug[blockIdx.x].stamp[k_] = st_acc[k_]; a.debug[blockIdx.x].stamp[2] = S.c.diag_slow; } } while (0)
-#else
-#define STAMP_DECL
-#define STAMP(k)
-#define STAMP_FLUSH()
-#endif
 
 __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1377,6 +1394,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
         const uint32_t job_dict = a.jobs[j].dict;
         if (tid == 0) {
             c.pos = 0; c.out = 0; c.err = 0; c.action = 0; c.diag_slow = 0;
+#ifdef MZD_STAMPS
+            for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = 0;
+#endif
             if (j == 0 && a.job_slot0) *a.job_slot0 = blockIdx.x;
             if (job_dict > a.ndicts) c.err = MZD_E_DICT;
         }

@@ -13,10 +13,14 @@ srcs = [cp.comp_file(i).tobytes() for i in range(n)]
 for rep in range(2):
     res = mzd.decode_batch(srcs, [size] * n)
 assert all(st == 0 for st, _ in res)
-st = (C.c_uint64 * 8)()
+st = (C.c_uint64 * 16)()
 api.lib().mzd_debug_stamps(0, st)
 names = ["hdr", "K1 weights+parse", "(count) walker slow-window iterations", "K2 literals+seqhdr", "K3 tables", "K4 seq decode", "K5 execute", "K7 xxh64"]
-tot = sum(st)
+tot = sum(st[:8])
 print("kernel ms", mzd.last_kernel_ms(0), "files", n)
-for nm, v in zip(names, st):
+for nm, v in zip(names, st[:8]):
     print("%-22s %10d cycles %5.1f%%" % (nm, v, 100.0 * v / max(tot, 1)))
+cn = ["wait plan", "classify/setup", "HBM lit+old loads -> LDS", "rounds LDS->LDS", "wait previous flush", "flush stores issue", "-", "-"]
+print("copier wavefront:")
+for nm, v in zip(cn, st[8:]):
+    print("   %-26s %10d cycles" % (nm, v))
