@@ -22,7 +22,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstring>
 #include <type_traits>
+
+#include <rocprim/warp/warp_scan.hpp>
 
 #include "../../include/mzd.h"
 #include "mzd_device.h"
@@ -85,6 +88,7 @@ struct __attribute__((aligned(16))) Shared {
     uint64_t ml[512];
     uint64_t of[256];
     uint8_t stage[2 * (2048 + 16)]; // K5 staging: the run being assembled and the previous run (kStage each)
+    uint32_t ll_base[36], ml_base[53]; // code -> base value (copied once from constant memory)
     uint4 planA[4][64];       // plan ring (kPlanRing chunks): {ll, ml, off, output offset inside the chunk}
     uint32_t planB[4][64];    //   literal index of each sequence
     uint32_t plan_hdr[4][4];  //   per chunk: bytes, sequences
@@ -149,6 +153,10 @@ __device__ const int16_t OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1,
 // also ends when an error is posted, and is bounded.
 __device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void flag_store(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+// first error wins: a wavefront that merely gave up because another one failed must not overwrite the cause
+__device__ __forceinline__ void post_err(int32_t* err, int rc) {
+    if (rc) { int32_t expected = 0; __atomic_compare_exchange_n(err, &expected, rc, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); }
+}
 __device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want, const int32_t* err) {
     for (uint32_t it = 0; it < (1u << 24); it++) {
         if (flag_load(p) >= want) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
@@ -362,13 +370,14 @@ __device__ __noinline__ void fill_huf_table(int first, int stride) {
 }
 
 // ------------------------------------------------------------------------------------ K2
+// wave-wide inclusive scans on the DPP path (row_shr / row_bcast: no LDS traffic, no ds_bpermute latency)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
+    (void)lane;
+    using WS = rocprim::warp_scan<uint32_t, 64>;
+    WS::storage_type* st = nullptr; // the DPP implementation keeps no state in LDS
+    uint32_t r;
+    WS().inclusive_scan(v, r, *st, rocprim::plus<uint32_t>());
+    return r;
 }
 
 // One Huffman stream decoded by the 64 lanes of a wavefront (A.4).
@@ -483,12 +492,12 @@ __device__ __noinline__ void wave_pattern(uint8_t* d, uint32_t off, uint32_t n, 
 
 // ------------------------------------------------------------------------------------ K3 (wave-parallel)
 __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= d && t > v) v = t;
-    }
-    return v;
+    (void)lane;
+    using WS = rocprim::warp_scan<uint32_t, 64>;
+    WS::storage_type* st = nullptr;
+    uint32_t r;
+    WS().inclusive_scan(v, r, *st, rocprim::maximum<uint32_t>());
+    return r;
 }
 
 // FSE decode table (A.3) built by the 64 lanes of one wavefront; same result as build_seq_table.
@@ -878,40 +887,71 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
     const uint64_t block_start = opos;
     uint32_t lpos = 0;
     uint32_t r0 = __builtin_amdgcn_readfirstlane(rep[0]), r1 = __builtin_amdgcn_readfirstlane(rep[1]), r2 = __builtin_amdgcn_readfirstlane(rep[2]);
+    // The walk records and the extra bits live in HBM (the walker may be arbitrarily far ahead, e.g. while
+    // the literals are still being decoded).  Their latency is taken off this wavefront's critical path
+    // by a two-stage software pipeline: while chunk k is planned, the records of chunk k+2 and the bit
+    // windows of chunk k+1 are in flight.
+    const uint32_t bias = 16 + (uint32_t)((uintptr_t)cx.seq_sp & 15);
+    const uint8_t* const gbase = cx.seq_sp - bias;
+    auto wait_walker = [&](uint32_t need) -> bool { // true when sequences [0, need) are recorded
+        if (need > nseq) need = nseq;
+        uint32_t pg = 0;
+        for (uint32_t it = 0; it < (1u << 24); it++) {
+            pg = flag_load(cx.prog);
+            if ((pg & ~kWalkFin) >= need || (pg & kWalkFin)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return (pg & ~kWalkFin) >= need;
+    };
+    struct Win { uint32_t hL, hM, hO, G; uint64_t bO, bM, bL; }; // entry words + raw 8-byte windows of one sequence
+    auto load_rec = [&](uint32_t idx) -> uint2 { return idx < nseq ? cx.walk[idx] : make_uint2(0, 0); };
+    auto issue_bits = [&](uint2 w, bool live, Win& o) {
+        const uint32_t vL = w.x & 0xFFF, vM = w.x >> 12, vO = w.y >> 21;
+        o.G = (w.y & 0x1FFFFF) + 32; // records carry the read head - 32
+        o.hL = (uint32_t)(S.ll[vL >> 3] >> 32); o.hM = (uint32_t)(S.ml[vM >> 3] >> 32); o.hO = (uint32_t)(S.of[vO >> 3] >> 32);
+        o.bO = 0; o.bM = 0; o.bL = 0;
+        if (live) {
+            const uint32_t xM = o.hM >> 24, xO = o.hO >> 24, xL = o.hL >> 24;
+            const uint32_t tO = o.G - xO, tM = tO - xM, tL = tM - xL; // bottoms of the three fields
+            o.bO = ldu64(gbase + (tO >> 3)); o.bM = ldu64(gbase + (tM >> 3)); o.bL = ldu64(gbase + (tL >> 3));
+        }
+    };
+    if (!wait_walker(128)) return MZD_E_CORRUPT;
+    uint2 recA = load_rec((uint32_t)lane), recB = load_rec(64 + (uint32_t)lane); // chunks 0 and 1
+    Win win;
+    issue_bits(recA, (uint32_t)lane < nseq, win);
     uint32_t chunk = 0;
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
         const uint32_t i = base + (uint32_t)lane;
         const bool valid = (uint32_t)lane < cnt;
-        { // the walker must be past this chunk, and the copier must have freed the ring slot
-            const uint32_t need = base + cnt;
-            uint32_t pg = 0;
-            for (uint32_t it = 0; it < (1u << 24); it++) {
-                pg = flag_load(cx.prog);
-                if ((pg & ~kWalkFin) >= need || (pg & kWalkFin)) break;
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if ((pg & ~kWalkFin) < need) return MZD_E_CORRUPT; // the walker failed (it posted the error) or never got there
+        // stage 1: records of chunk k+2, bit windows of chunk k+1 (recB arrived an iteration ago)
+        if (!wait_walker(base + 192)) return MZD_E_CORRUPT; // the walker failed (it posted the error) or never got there
+        const uint2 recC = load_rec(base + 128 + (uint32_t)lane);
+        Win next;
+        issue_bits(recB, base + 64 + (uint32_t)lane < nseq, next);
+        { // the copier must have freed the ring slot
             for (uint32_t it = 0; it < (1u << 24); it++) {
                 if (chunk - flag_load(&S.c.copy_prog) < (uint32_t)kPlanRing) break;
                 if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
                 __builtin_amdgcn_s_sleep(4);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
+        // stage 2: fields of chunk k from the windows issued an iteration ago
         uint32_t ll = 0, ml = 0, ofv = 4;
         if (valid) {
-            const uint32_t bias = 16 + (uint32_t)((uintptr_t)cx.seq_sp & 15);
-            const uint8_t* gbase = cx.seq_sp - bias;
-            uint2 w = cx.walk[i];
-            uint32_t vL = w.x & 0xFFF, vM = w.x >> 12, vO = w.y >> 21, G = (w.y & 0x1FFFFF) + 32; // records carry the read head - 32
-            uint32_t hL = (uint32_t)(S.ll[vL >> 3] >> 32), hM = (uint32_t)(S.ml[vM >> 3] >> 32), hO = (uint32_t)(S.of[vO >> 3] >> 32);
-            uint32_t cL = (hL >> 16) & 0xFF, cM = (hM >> 16) & 0xFF, cO = (hO >> 16) & 0xFF;
-            uint32_t xL = hL >> 24, xM = hM >> 24, xO = hO >> 24;
-            ofv = (1u << cO) + stream_bits(gbase, G, xO);
-            ml = ML_BASE[cM] + stream_bits(gbase, G - xO, xM);
-            ll = LL_BASE[cL] + stream_bits(gbase, G - xO - xM, xL);
+            const uint32_t cL = (win.hL >> 16) & 0xFF, cM = (win.hM >> 16) & 0xFF, cO = (win.hO >> 16) & 0xFF;
+            const uint32_t xL = win.hL >> 24, xM = win.hM >> 24, xO = win.hO >> 24;
+            const uint32_t tO = win.G - xO, tM = tO - xM, tL = tM - xL;
+            const uint32_t vO = xO ? (uint32_t)(win.bO >> (tO & 7)) & (uint32_t)((1ull << xO) - 1) : 0u;
+            const uint32_t vM = xM ? (uint32_t)(win.bM >> (tM & 7)) & (uint32_t)((1ull << xM) - 1) : 0u;
+            const uint32_t vL = xL ? (uint32_t)(win.bL >> (tL & 7)) & (uint32_t)((1ull << xL) - 1) : 0u;
+            ofv = (1u << cO) + vO;
+            ml = S.ml_base[cM] + vM;
+            ll = S.ll_base[cL] + vL;
         }
+        win = next; recB = recC;
         // ---- repeat offsets
         uint32_t off;
         {
@@ -922,12 +962,11 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
             else if (idx == 1) { op.s = 1 | (0 << 2) | (2 << 4); op.v0 = 0; op.v1 = 0; op.v2 = 0; }
             else if (idx == 2) { op.s = 2 | (0 << 2) | (1 << 4); op.v0 = 0; op.v1 = 0; op.v2 = 0; }
             else { op.s = 0 | (0 << 2) | (1 << 4); op.v0 = -1; op.v1 = 0; op.v2 = 0; }
-            RepOp acc = op; // inclusive scan: acc = op_lane o ... o op_0
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                RepOp f;
-                f.s = __shfl_up(acc.s, d); f.v0 = __shfl_up(acc.v0, d); f.v1 = __shfl_up(acc.v1, d); f.v2 = __shfl_up(acc.v2, d);
-                if (lane >= d) acc = rep_compose(acc, f);
+            RepOp acc; // inclusive scan: acc = op_lane o ... o op_0 (DPP path)
+            {
+                using WR = rocprim::warp_scan<RepOp, 64>;
+                WR::storage_type* st = nullptr;
+                WR().inclusive_scan(op, acc, *st, [](const RepOp& earlier, const RepOp& later) { return rep_compose(later, earlier); });
             }
             RepOp before; // exclusive
             before.s = __shfl_up(acc.s, 1); before.v0 = __shfl_up(acc.v0, 1); before.v1 = __shfl_up(acc.v1, 1); before.v2 = __shfl_up(acc.v2, 1);
@@ -1381,6 +1420,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
     uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
     uint2* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
     Ctl& c = S.c;
+    if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
+    if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
 
     for (;;) {
         if (tid == 0) c.job = atomicAdd(a.counter, 1u);
@@ -1488,7 +1529,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             int rc = walk_sequences_wave(src + seq_off, seq_len, nseq, walk, &c.walk_prog, lane);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) {
-                                if (rc) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
+                                post_err(&c.err, rc);
                                 c.fse_valid = 1;
                                 flag_store(&c.walk_prog, rc ? kWalkFin : (nseq | kWalkFin)); // a failed walk publishes nothing
                             }
@@ -1503,7 +1544,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) {
-                                if (rc && !__atomic_load_n(&c.err, __ATOMIC_RELAXED)) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
+                                post_err(&c.err, rc);
                                 flag_store(&c.plan_prog, flag_load(&c.plan_prog) | kPlanFin);
                             }
                         }
@@ -1512,7 +1553,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         if (lit_type == 2) { // K1: weights by one lane, table by 128
                             if (tid == 64) {
                                 int used = read_huf_weights(blk + c.huf_tree_off, c.huf_tree_len);
-                                if (used <= 0) __atomic_store_n(&c.err, MZD_E_CORRUPT, __ATOMIC_RELAXED);
+                                if (used <= 0) post_err(&c.err, MZD_E_CORRUPT);
                                 else c.huf_valid = 1;
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                 flag_store(&c.huf_ready, 1);
@@ -1534,7 +1575,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) {
-                            if (rc) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
+                            post_err(&c.err, rc);
                             __atomic_fetch_add(&c.lit_done, 1u, __ATOMIC_RELAXED);
                         }
                         STAMP(3);
@@ -1547,7 +1588,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) {
-                                if (rc && !__atomic_load_n(&c.err, __ATOMIC_RELAXED)) __atomic_store_n(&c.err, rc, __ATOMIC_RELAXED);
+                                post_err(&c.err, rc);
                                 flag_store(&c.exec_done, 1);
                                 c.out = opos; c.pos = pos0 + bsize;
                                 if (a.debug) {
