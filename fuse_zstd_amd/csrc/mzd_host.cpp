@@ -469,7 +469,7 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
     HIPCHK(hipMemcpy(&ds, d->debug + slot, sizeof(ds), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out8[i] = ds.stamp[i];
     for (int i = 0; i < 8; i++) out8[8 + i] = ds.cstamp[i];
-    for (int i = 0; i < 4; i++) out8[16 + i] = ds.tfin[i];
+    for (int i = 0; i < 6; i++) out8[16 + i] = ds.tfin[i];
     return MZD_OK;
 }
 

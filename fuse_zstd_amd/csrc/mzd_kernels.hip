@@ -32,6 +32,16 @@
 
 namespace mzd {
 
+#if defined(MZD_STAMPS) || defined(MZD_TFIN)
+#define TFIN(k) do { if (lane == 0) S.tfin[k] = __builtin_readcyclecounter() - S.tstart; } while (0)
+#define TSTART() do { if (tid == 0) S.tstart = __builtin_readcyclecounter(); } while (0)
+#define TFIN_FLUSH() do { if (tid == 0 && a.debug) for (int k_ = 0; k_ < 6; k_++) a.debug[blockIdx.x].tfin[k_] = S.tfin[k_]; } while (0)
+#else
+#define TFIN(k)
+#define TSTART()
+#define TFIN_FLUSH()
+#endif
+
 // Diagnostic build only: per-phase cycle sums of the workgroup (lane 0), never in the product .so.
 #ifdef MZD_STAMPS
 #define STAMP_DECL uint64_t st_prev = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -39,6 +49,8 @@ namespace mzd {
 #define STAMP_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 8; k_++) { a.debug[blockIdx.x].stamp[k_] = st_acc[k_]; a.debug[blockIdx.x].cstamp[k_] = S.cdiag[k_]; } a.debug[blockIdx.x].stamp[2] = S.c.diag_slow; } } while (0)
 #define CSTAMP_DECL uint64_t cs_prev = __builtin_readcyclecounter()
 #define CSTAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); if (lane == 0) S.cdiag[k] += t_ - cs_prev; cs_prev = t_; } while (0)
+#if 0
+#endif
 #else
 #define STAMP_DECL
 #define STAMP(k)
@@ -89,11 +101,11 @@ struct __attribute__((aligned(16))) Shared {
     uint64_t of[256];
     uint8_t stage[2 * (2048 + 16)]; // K5 staging: the run being assembled and the previous run (kStage each)
     uint32_t ll_base[36], ml_base[53]; // code -> base value (copied once from constant memory)
-    uint4 planA[4][64];       // plan ring (kPlanRing chunks): {ll, ml, off, output offset inside the chunk}
-    uint32_t planB[4][64];    //   literal index of each sequence
-    uint32_t plan_hdr[4][4];  //   per chunk: bytes, sequences
 #ifdef MZD_STAMPS
     uint64_t cdiag[8];
+#endif
+#if defined(MZD_STAMPS) || defined(MZD_TFIN)
+    uint64_t tstart, tfin[6]; // block start; finish of walker / copier / hasher / planner; literals ready; tables ready
 #endif
     uint16_t huf[2048]; // sym | len << 8
     int16_t norm[3][64];
@@ -865,7 +877,6 @@ struct LdsSt {
     __device__ __forceinline__ void u8(uint32_t o, uint32_t v) const { p[o] = (uint8_t)v; }
 };
 
-constexpr int kPlanRing = 4; // chunks of 64 planned sequences buffered between the planner and the copier
 constexpr uint32_t kPlanFin = 0x80000000u;
 
 struct PlanCtx { // what the planning wavefront needs
@@ -880,8 +891,7 @@ struct PlanCtx { // what the planning wavefront needs
 
 // K4(b) + the bookkeeping half of K5, by one wavefront, 64 sequences per step (lane = sequence):
 // field conversion from the walk records, repeat offsets, positions, validation.  The result goes
-// to the plan ring in LDS: per sequence {ll, ml, off, output offset inside the chunk} + literal index,
-// per chunk {bytes, literal bytes, sequences}.  Returns 0 or an error.
+// to the plan array in HBM: per sequence {ll, ml, off, output offset inside the chunk}.  Returns 0 or an error.
 __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanCtx& cx, uint64_t opos, uint32_t* rep, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
     const uint64_t block_start = opos;
@@ -926,18 +936,14 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
         const uint32_t i = base + (uint32_t)lane;
         const bool valid = (uint32_t)lane < cnt;
+        // everything this wavefront stored an iteration ago has landed: chunk k-1 of the plan is public
+        wg_fence();
+        if (lane == 0) flag_store(&S.c.plan_prog, chunk);
         // stage 1: records of chunk k+2, bit windows of chunk k+1 (recB arrived an iteration ago)
         if (!wait_walker(base + 192)) return MZD_E_CORRUPT; // the walker failed (it posted the error) or never got there
         const uint2 recC = load_rec(base + 128 + (uint32_t)lane);
         Win next;
         issue_bits(recB, base + 64 + (uint32_t)lane < nseq, next);
-        { // the copier must have freed the ring slot
-            for (uint32_t it = 0; it < (1u << 24); it++) {
-                if (chunk - flag_load(&S.c.copy_prog) < (uint32_t)kPlanRing) break;
-                if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
-                __builtin_amdgcn_s_sleep(4);
-            }
-        }
         // stage 2: fields of chunk k from the windows issued an iteration ago
         uint32_t ll = 0, ml = 0, ofv = 4;
         if (valid) {
@@ -976,7 +982,6 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
             else off = idx == 0 ? b0 : (idx == 1 ? b1 : (idx == 2 ? b2 : b0 - 1));
             uint32_t e0 = rep_eval(acc, 0, r0, r1, r2), e1 = rep_eval(acc, 1, r0, r1, r2), e2 = rep_eval(acc, 2, r0, r1, r2);
             r0 = __builtin_amdgcn_readlane(e0, 63); r1 = __builtin_amdgcn_readlane(e1, 63); r2 = __builtin_amdgcn_readlane(e2, 63);
-            if (valid) seqs[i] = make_uint4(ll, ml, off, 0); // the resolved triple (mzd_debug_last_block / phase tests)
         }
         // ---- positions and validation
         const uint32_t tot = ll + ml;
@@ -989,23 +994,22 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint64_t mdst = opos + ex_t + ll;
         const uint64_t avail = (mdst - cx.frame_start) + cx.dict_len;
         if (__any(valid && (off == 0 || off > avail))) return MZD_E_CORRUPT;
-        const uint32_t slot = chunk & (kPlanRing - 1);
-        S.planA[slot][lane] = make_uint4(ll, ml, off, ex_t);
-        S.planB[slot][lane] = lpos + (incl_l - ll);
-        if (lane == 0) { S.plan_hdr[slot][0] = chunk_tot; S.plan_hdr[slot][1] = cnt; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) flag_store(&S.c.plan_prog, chunk + 1);
+        // the plan of this sequence: {ll, ml, resolved offset, output offset inside the chunk} -> HBM (unbounded, so the
+        // planner never waits for the copier, which may still be decoding literals); also what mzd_debug_last_block shows
+        if (valid) seqs[i] = make_uint4(ll, ml, off, ex_t);
         opos += chunk_tot;
         lpos += chunk_lit;
     }
     const uint32_t rest = cx.nlit - lpos;
     if (rest > cx.cap - opos) return MZD_E_DSTSIZE;
     if ((opos - block_start) + rest > kBlockMax) return MZD_E_CORRUPT;
-    if (lane == 0) { rep[0] = r0; rep[1] = r1; rep[2] = r2; S.c.plan_lit_used = lpos; }
+    wg_fence();
+    if (lane == 0) { rep[0] = r0; rep[1] = r1; rep[2] = r2; S.c.plan_lit_used = lpos; flag_store(&S.c.plan_prog, chunk); }
     return 0;
 }
 
 struct CopyCtx {
+    const uint4* plan;       // the block's plan (HBM): {ll, ml, off, output offset inside the chunk} per sequence
     uint8_t* dst;            // the file's output buffer
     uint64_t frame_start;    // offset of the current frame's first byte in dst
     const uint8_t* dict;     // dictionary content (logically just before frame_start) or null
@@ -1025,27 +1029,38 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     uint32_t cur = 0, prevT = 0; // staging buffer in use; length of the previous run
     bool prev_valid = false;     // the other staging buffer holds the run that ends where this one starts
     CSTAMP_DECL;
-    for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
-        { // wait for the plan of this chunk
-            uint32_t pg = 0;
-            for (uint32_t it = 0; it < (1u << 24); it++) {
-                pg = flag_load(&S.c.plan_prog);
-                if ((pg & ~kPlanFin) > chunk || (pg & kPlanFin)) break;
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if ((pg & ~kPlanFin) <= chunk) return MZD_E_CORRUPT; // the planner failed and posted the error
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t lpos = 0;
+    auto wait_plan = [&](uint32_t nchunks_needed) -> bool { // true when that many chunks are planned
+        uint32_t pg = 0;
+        for (uint32_t it = 0; it < (1u << 24); it++) {
+            pg = flag_load(&S.c.plan_prog);
+            if ((pg & ~kPlanFin) >= nchunks_needed || (pg & kPlanFin)) break;
+            __builtin_amdgcn_s_sleep(4);
         }
-        CSTAMP(0);
-        const uint32_t slot = chunk & (kPlanRing - 1);
-        const uint4 pe = S.planA[slot][lane];
-        const uint32_t my_lit = S.planB[slot][lane];
-        const uint32_t chunk_tot = S.plan_hdr[slot][0], cnt = S.plan_hdr[slot][1];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the reads above are done: the slot may be refilled
-        if (lane == 0) flag_store(&S.c.copy_prog, chunk + 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return (pg & ~kPlanFin) >= nchunks_needed;
+    };
+    const uint32_t nchunks = (nseq + 63) / 64;
+    uint4 pe_next = make_uint4(0, 0, 0, 0);
+    if (nseq) {
+        if (!wait_plan(1)) return MZD_E_CORRUPT; // the planner failed and posted the error
+        if ((uint32_t)lane < nseq) pe_next = cx.plan[lane];
+    }
+    for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
+        const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
+        const uint4 pe = pe_next; // loaded an iteration ago
+        if (chunk + 1 < nchunks) { // prefetch the next chunk's plan
+            if (!wait_plan(chunk + 2)) return MZD_E_CORRUPT;
+            const uint32_t j = base + 64 + (uint32_t)lane;
+            pe_next = j < nseq ? cx.plan[j] : make_uint4(0, 0, 0, 0);
+        }
         const bool valid = (uint32_t)lane < cnt;
         const uint32_t ll = valid ? pe.x : 0, ml = valid ? pe.y : 0, off = pe.z, ex_t = pe.w;
         const uint32_t incl_t = ex_t + ll + ml;
+        const uint32_t chunk_tot = __builtin_amdgcn_readlane(incl_t, cnt - 1);
+        const uint32_t incl_l = wave_incl_scan(ll, lane);
+        const uint32_t my_lit = lpos + (incl_l - ll);
+        lpos += __builtin_amdgcn_readlane(incl_l, 63);
         const uint64_t mdst = opos + ex_t + ll; // absolute match destination
         const bool in_dict = valid && off > mdst - cx.frame_start;
         const bool islong = valid && (ll > kShort || ml > kShort || in_dict);
@@ -1159,7 +1174,6 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         opos += chunk_tot;
     }
     // the literals after the last sequence: the planner has validated them once it is finished
-    uint32_t lpos = 0;
     if (nseq) {
         for (uint32_t it = 0; it < (1u << 24); it++) {
             if (flag_load(&S.c.plan_prog) & kPlanFin) break;
@@ -1167,7 +1181,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
-        lpos = __atomic_load_n(&S.c.plan_lit_used, __ATOMIC_RELAXED);
+        if (lpos != __atomic_load_n(&S.c.plan_lit_used, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
     } else {
         if (cx.nlit > kBlockMax) return MZD_E_CORRUPT;
     }
@@ -1496,6 +1510,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     // (<= 256 bytes each: literals header + tree extent + jump table; sequence count, modes and
                     // the three normalized-count headers) are staged in LDS first, so that lane 0's byte-wise
                     // parsing does not pay an HBM round trip per byte.
+                    TSTART();
                     for (uint32_t k = tid; k < bsize && k < 256; k += kWG) S.stage[k] = blk[k];
                     __syncthreads();
                     if (tid == 0) {
@@ -1526,6 +1541,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) flag_store(&c.tables_ready, 1);
                             STAMP(4);
+                            TFIN(5);
                             int rc = walk_sequences_wave(src + seq_off, seq_len, nseq, walk, &c.walk_prog, lane);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) {
@@ -1534,6 +1550,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                                 flag_store(&c.walk_prog, rc ? kWalkFin : (nseq | kWalkFin)); // a failed walk publishes nothing
                             }
                             STAMP(5);
+                            TFIN(0);
                         }
                     } else if (wave == 3) {
                         if (nseq) {
@@ -1547,6 +1564,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                                 post_err(&c.err, rc);
                                 flag_store(&c.plan_prog, flag_load(&c.plan_prog) | kPlanFin);
                             }
+                            TFIN(3);
                         }
                     } else {
                         int rc = 0;
@@ -1579,11 +1597,12 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             __atomic_fetch_add(&c.lit_done, 1u, __ATOMIC_RELAXED);
                         }
                         STAMP(3);
+                        if (wave == 1) TFIN(4);
                         if (wave == 1) { // the copying half of K5
                             uint64_t opos = out0;
                             rc = MZD_E_CORRUPT;
                             if (spin_ge(&c.lit_done, 2, &c.err)) {
-                                CopyCtx cx{dst, c.frame_out0, c.dict_content, c.dict_content_len, lit, nlit};
+                                CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit, nlit};
                                 rc = copy_wave(nseq, cx, &opos, lane);
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1597,6 +1616,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                                 }
                             }
                             STAMP(6);
+                            TFIN(1);
                         } else if (hashing) { // wave 2, K7: hash behind the copier while it works
                             const uint8_t* fp = dst + c.frame_out0;
                             for (uint32_t it = 0; it < (1u << 24); it++) {
@@ -1609,6 +1629,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                                 else __builtin_amdgcn_s_sleep(8);
                                 if (fin) break;
                             }
+                            TFIN(2);
                         }
                     }
                 }
@@ -1643,6 +1664,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
         }
         if (tid == 0) { a.jobs[j].out_len = c.out; a.jobs[j].status = c.err; }
         STAMP_FLUSH();
+        TFIN_FLUSH();
         __syncthreads();
     }
 }

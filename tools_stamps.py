@@ -2,7 +2,7 @@
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fuse_zstd_amd.api as api
-api._SO = os.path.join(os.path.dirname(api._SO), "libmzd_diag.so")
+api._SO = os.path.join(os.path.dirname(api._SO), os.environ.get("MZD_DIAG_SO", "libmzd_diag.so"))
 import fuse_zstd_amd as mzd, corpus
 mzd.init()
 kind = sys.argv[1] if len(sys.argv) > 1 else "json"
@@ -13,7 +13,7 @@ srcs = [cp.comp_file(i).tobytes() for i in range(n)]
 for rep in range(2):
     res = mzd.decode_batch(srcs, [size] * n)
 assert all(st == 0 for st, _ in res)
-st = (C.c_uint64 * 16)()
+st = (C.c_uint64 * 24)()
 api.lib().mzd_debug_stamps(0, st)
 names = ["hdr", "K1 weights+parse", "(count) walker slow-window iterations", "K2 literals+seqhdr", "K3 tables", "K4 seq decode", "K5 execute", "K7 xxh64"]
 tot = sum(st[:8])
@@ -21,6 +21,7 @@ print("kernel ms", mzd.last_kernel_ms(0), "files", n)
 for nm, v in zip(names, st[:8]):
     print("%-22s %10d cycles %5.1f%%" % (nm, v, 100.0 * v / max(tot, 1)))
 cn = ["wait plan", "classify/setup", "HBM lit+old loads -> LDS", "rounds LDS->LDS", "wait previous flush", "flush stores issue", "-", "-"]
+print("cycles after block start: tables ready %d, literals ready %d, walker done %d, planner done %d, copier done %d, hasher done %d" % (st[21], st[20], st[16], st[19], st[17], st[18]))
 print("copier wavefront:")
 for nm, v in zip(cn, st[8:]):
     print("   %-26s %10d cycles" % (nm, v))
