@@ -99,7 +99,7 @@ struct __attribute__((aligned(16))) Shared {
     uint64_t ll[512];
     uint64_t ml[512];
     uint64_t of[256];
-    uint8_t stage[2 * (2048 + 16)]; // K5 staging: the run being assembled and the previous run (kStage each)
+    uint8_t stage[3 * (2048 + 16)]; // K5 staging: the run being assembled and the two before it (kStage each)
     uint32_t ll_base[36], ml_base[53]; // code -> base value (copied once from constant memory)
 #ifdef MZD_STAMPS
     uint64_t cdiag[8];
@@ -401,44 +401,57 @@ __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint
     if (sl == 0) return MZD_E_CORRUPT;
     uint32_t last = sp[sl - 1];
     if (last == 0) return MZD_E_CORRUPT;
-    const uint32_t nbits = (sl - 1) * 8 + (uint32_t)hibit(last);
+    const int32_t nbits = (int32_t)((sl - 1) * 8 + (uint32_t)hibit(last));
     const uint32_t mask = (1u << L) - 1;
-    uint32_t C = (nbits + 63) / 64;
+    int32_t C = (nbits + 63) / 64;
     if (C < 32) C = 32;
-    uint32_t q0 = (uint32_t)lane * C, q1 = q0 + C;
+    int32_t q0 = lane * C, q1 = q0 + C;
     if (q0 > nbits) q0 = nbits;
     if (q1 > nbits) q1 = nbits;
     if (lane == 63) q1 = nbits;
 
-    auto peek = [&](uint32_t pos) -> uint32_t {
-        uint32_t rem = nbits - pos;
-        if (rem >= L) { uint32_t lo = rem - L; return (ldu32(sp + (lo >> 3)) >> (lo & 7)) & mask; }
-        return ((ldu32(sp) & ((1u << rem) - 1)) << (L - rem)) & mask;
-    };
-    auto span = [&](uint32_t from, uint32_t& cnt) -> uint32_t {
-        uint32_t pos = from, c = 0;
-        while (pos < q1) { uint32_t l = tab[peek(pos)] >> 8; pos += l ? l : 1u; c++; }
+    // Each lane reads its part of the stream through a 64-bit register window over stream bits [wb, wb+64),
+    // wb a multiple of 32, refilled one dword at a time from a dword that was loaded one refill earlier:
+    // one HBM access per ~4 symbols instead of one per symbol, and never waited for.
+    // Dwords below the stream start read as zero (bits below bit 0 of a backward stream are zero).
+    auto dword = [&](int32_t d) -> uint32_t { return d < 0 ? 0u : ldu32(sp + (uint32_t)d * 4); }; // may over-read <= 3 bytes (input padding)
+    auto walk = [&](int32_t from, uint32_t& cnt, uint8_t* dst) -> int32_t {
+        int32_t rem = nbits - from; // bits below the read point
+        const int32_t lim = nbits - q1;
+        int32_t wb = (rem - (int32_t)L) & ~31; // <= rem - L, may be negative
+        uint32_t hi = dword((wb >> 5) + 1), lo = dword(wb >> 5), nx = dword((wb >> 5) - 1);
+        uint32_t c = 0;
+        while (rem > lim) {
+            const uint64_t W = ((uint64_t)hi << 32) | lo;
+            const uint32_t e = tab[(uint32_t)(W >> (uint32_t)(rem - (int32_t)L - wb)) & mask];
+            const uint32_t l = e >> 8;
+            if (dst) dst[c] = (uint8_t)e;
+            c++;
+            rem -= (int32_t)(l ? l : 1u);
+            if (rem - (int32_t)L < wb) { // slide the window down one dword
+                hi = lo; lo = nx; wb -= 32;
+                nx = dword((wb >> 5) - 1);
+            }
+        }
         cnt = c;
-        return pos;
+        return nbits - rem;
     };
-    uint32_t start = q0, cnt = 0;
-    uint32_t exitp = span(start, cnt);
+    int32_t start = q0;
+    uint32_t cnt = 0;
+    int32_t exitp = walk(start, cnt, nullptr);
     for (int round = 0; round < 64; round++) {
-        uint32_t pe = __shfl_up(exitp, 1);
-        uint32_t ns = lane == 0 ? 0u : pe;
+        int32_t pe = __shfl_up(exitp, 1);
+        int32_t ns = lane == 0 ? 0 : pe;
         bool changed = ns != start;
         if (!__any(changed)) break;
-        if (changed) { start = ns; exitp = span(start, cnt); }
+        if (changed) { start = ns; exitp = walk(start, cnt, nullptr); }
     }
     uint32_t incl = wave_incl_scan(cnt, lane);
-    uint32_t total = __shfl(incl, 63), endp = __shfl(exitp, 63);
+    uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    int32_t endp = __builtin_amdgcn_readlane(exitp, 63);
     if (total != nsym || endp != nbits) return MZD_E_CORRUPT;
-    uint32_t o = incl - cnt, pos = start;
-    while (pos < q1) {
-        uint32_t e = tab[peek(pos)];
-        out[o++] = (uint8_t)e;
-        pos += (e >> 8) ? (e >> 8) : 1u;
-    }
+    uint32_t dummy;
+    walk(start, dummy, out + (incl - cnt));
     return 0;
 }
 
@@ -1018,17 +1031,40 @@ struct CopyCtx {
     uint32_t nlit;
 };
 
-// The copying half of K5, by one wavefront, one planned chunk of 64 sequences at a time.  It publishes the
-// finished output position in S.c.exec_pos for the hashing wavefront.
+// The copying half of K5, by one wavefront.  It publishes the finished output position in S.c.exec_pos
+// for the hashing wavefront.
+//
+// Unit of work: a RUN = consecutive short sequences (<= kShort literal bytes and match bytes each) whose
+// output fits one LDS staging buffer (kStage bytes); long sequences are copied straight to HBM by all
+// 64 lanes.  A run is assembled in LDS and flushed with coalesced 16-byte stores.  Where a match's
+// source lives, relative to the run being assembled:
+//     inside the run ............ resolved LDS -> LDS in rounds (ready when the source lies below the
+//                                 output of the first unfinished sequence)
+//     in the previous two runs .. their staging buffers are still in LDS (three buffers rotate), so
+//                                 it never matters whether their flushes have landed
+//     older ..................... HBM.  Every flush first waits for the flush before it, hence all
+//                                 output older than the previous two runs has landed.
+// The HBM reads of a run (its literals and its old matches) are issued one run AHEAD (software
+// pipeline: prepare(run k+1), then finish(run k)), so their latency hides behind the LDS work.
+struct RunRegs { // one lane's share of a prepared run
+    uint32_t ll, ml, off, rel_out;  // ll = ml = 0 on lanes outside the run
+    int32_t rel_src;                // match source relative to the run start
+    uint32_t kind;                  // 0 none, 1 rounds, 2 previous run, 3 run before that, 4 HBM (prefetched), 5 HBM (big, loaded at finish)
+    uint32_t srcpos;                // kind 2/3: byte offset inside that staging buffer
+    uint64_t l0, l1, l2, h0, h1, h2;
+    uint32_t lt4, lt2, lt1, ht4, ht2, ht1;
+    uint32_t my_lit;
+};
+struct RunInfo { // wave-uniform
+    uint64_t run_pos; uint32_t T, buf; bool bigl; uint32_t nlmax;
+    bool v1, v2; uint32_t T1, T2, buf1, buf2; // the two runs before it
+};
+
 __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint64_t* opos_io, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
     uint8_t* const dst = cx.dst;
     const uint8_t* const lit = cx.lit;
     uint64_t opos = *opos_io;
-    uint32_t chunk = 0;
-    uint32_t cur = 0, prevT = 0; // staging buffer in use; length of the previous run
-    bool prev_valid = false;     // the other staging buffer holds the run that ends where this one starts
-    CSTAMP_DECL;
     uint32_t lpos = 0;
     auto wait_plan = [&](uint32_t nchunks_needed) -> bool { // true when that many chunks are planned
         uint32_t pg = 0;
@@ -1040,12 +1076,98 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return (pg & ~kPlanFin) >= nchunks_needed;
     };
+    auto stagebuf = [&](uint32_t k) -> uint8_t* { return S.stage + k * (kStage + 16); };
     const uint32_t nchunks = (nseq + 63) / 64;
+
+    // history: the two staged runs before the one being prepared (h1 most recent)
+    bool v1 = false, v2 = false;
+    uint32_t T1 = 0, T2 = 0, runno = 0;
+    RunRegs R;  RunInfo RI;  bool haveR = false; // the prepared, unfinished run
+    R.ll = R.ml = 0; R.kind = 0;
+
+    // finish a prepared run: LDS stores of the prefetched bytes, LDS -> LDS copies, rounds, flush
+    auto finish = [&](RunRegs& r, const RunInfo& ri) {
+        uint8_t* const sb = stagebuf(ri.buf);
+        const uint8_t* const b1 = stagebuf(ri.buf1);
+        const uint8_t* const b2 = stagebuf(ri.buf2);
+        { // literals
+            const LdsSt sl{sb + r.rel_out};
+            if (ri.bigl) { if (r.ll) copy_short(r.ll, GlobalLd{lit + r.my_lit}, sl); }
+            else if (ri.nlmax) {
+                const uint32_t q = r.ll >> 3, t = q * 8;
+                if (q > 0) sl.u64(0, r.l0);
+                if (q > 1) sl.u64(8, r.l1);
+                if (q > 2) sl.u64(16, r.l2);
+                if (r.ll & 4) sl.u32(t, r.lt4);
+                if (r.ll & 2) sl.u16(t + (r.ll & 4), r.lt2);
+                if (r.ll & 1) sl.u8(t + (r.ll & 6), r.lt1);
+            }
+        }
+        const uint32_t rel_m = r.rel_out + r.ll;
+        { // old matches: prefetched from HBM, or from the two previous runs' buffers
+            const LdsSt sh{sb + rel_m};
+            if (r.kind == 4) {
+                const uint32_t q = r.ml >> 3, t = q * 8;
+                if (q > 0) sh.u64(0, r.h0);
+                if (q > 1) sh.u64(8, r.h1);
+                if (q > 2) sh.u64(16, r.h2);
+                if (r.ml & 4) sh.u32(t, r.ht4);
+                if (r.ml & 2) sh.u16(t + (r.ml & 4), r.ht2);
+                if (r.ml & 1) sh.u8(t + (r.ml & 6), r.ht1);
+            }
+            if (__any(r.kind == 5)) { if (r.kind == 5) copy_short(r.ml, GlobalLd{dst + ri.run_pos + r.rel_src}, sh); }
+            if (__any(r.kind == 2 || r.kind == 3)) {
+                if (r.kind == 2) copy_short(r.ml, LdsLd{b1 + r.srcpos}, sh);
+                if (r.kind == 3) copy_short(r.ml, LdsLd{b2 + r.srcpos}, sh);
+            }
+        }
+        // the rest in rounds, LDS -> LDS
+        bool pending = r.kind == 1;
+        const uint32_t span = r.ml < r.off ? r.ml : r.off;
+        const bool plain = r.off >= r.ml;
+        uint64_t pm = __ballot(pending);
+        while (pm) {
+            const int first = __builtin_ctzll(pm);
+            const int32_t hwm = (int32_t)__builtin_amdgcn_readlane(rel_m, first);
+            const bool ready = pending && r.rel_src + (int32_t)span <= hwm;
+            const bool fast = ready && plain && r.rel_src >= 0;
+            if (__any(fast)) { if (fast) copy_short(r.ml, LdsLd{sb + r.rel_src}, LdsSt{sb + rel_m}); }
+            if (ready && !fast) { // overlapping match, or a source that straddles a boundary: byte by byte
+                uint32_t idx = 0;
+                for (uint32_t k = 0; k < r.ml; k++) {
+                    const int32_t p = r.rel_src + (int32_t)idx;
+                    const int32_t d = -p;
+                    uint8_t bv; // typed loads: hipcc 7.2 miscompiles a load through a pointer selected between HBM and LDS
+                    if (p >= 0) bv = *(const __attribute__((address_space(3))) uint8_t*)(sb + p);
+                    else if (ri.v1 && d <= (int32_t)ri.T1) bv = *(const __attribute__((address_space(3))) uint8_t*)(b1 + ((int32_t)ri.T1 - d));
+                    else if (ri.v1 && ri.v2 && d <= (int32_t)(ri.T1 + ri.T2)) bv = *(const __attribute__((address_space(3))) uint8_t*)(b2 + ((int32_t)(ri.T1 + ri.T2) - d));
+                    else bv = *(const __attribute__((address_space(1))) uint8_t*)(dst + ri.run_pos + p);
+                    sb[rel_m + k] = bv;
+                    idx++;
+                    if (idx == r.off) idx = 0;
+                }
+            }
+            pending = pending && !ready;
+            pm = __ballot(pending);
+        }
+        // flush: LDS -> HBM, 16 bytes per lane.  First wait for the previous flush (and whatever else is in flight).
+        wg_fence();
+        if (lane == 0) __atomic_store_n(&S.c.exec_pos, ri.run_pos, __ATOMIC_RELAXED); // everything before this run has landed
+        uint8_t* g = dst + ri.run_pos;
+        for (uint32_t k = (uint32_t)lane * 16; k + 16 <= ri.T; k += 1024) {
+            uint4 v = *reinterpret_cast<const uint4*>(sb + k);
+            __builtin_memcpy(g + k, &v, 16);
+        }
+        const uint32_t tail0 = ri.T & ~15u; // the last partial 16 bytes: one byte per lane
+        if (tail0 + (uint32_t)lane < ri.T) g[tail0 + lane] = sb[tail0 + lane];
+    };
+
     uint4 pe_next = make_uint4(0, 0, 0, 0);
     if (nseq) {
         if (!wait_plan(1)) return MZD_E_CORRUPT; // the planner failed and posted the error
         if ((uint32_t)lane < nseq) pe_next = cx.plan[lane];
     }
+    uint32_t chunk = 0;
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
         const uint4 pe = pe_next; // loaded an iteration ago
@@ -1064,13 +1186,14 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         const uint64_t mdst = opos + ex_t + ll; // absolute match destination
         const bool in_dict = valid && off > mdst - cx.frame_start;
         const bool islong = valid && (ll > kShort || ml > kShort || in_dict);
+        const uint64_t longmask = __ballot(islong);
 
-        // runs of short sequences through LDS, long ones directly
         uint32_t a = 0;
         while (a < cnt) {
             const uint32_t base_t = __builtin_amdgcn_readlane(ex_t, a);
             const uint64_t run_pos = opos + base_t; // absolute output position of lane a's literals
-            if ((__ballot(islong) >> a) & 1) {
+            if ((longmask >> a) & 1) { // a long sequence: drain the pipeline, then all 64 lanes copy it straight to HBM
+                if (haveR) { finish(R, RI); haveR = false; }
                 const uint32_t l = __builtin_amdgcn_readlane(ll, a), m = __builtin_amdgcn_readlane(ml, a);
                 const uint32_t o = __builtin_amdgcn_readlane(off, a), lp = __builtin_amdgcn_readlane(my_lit, a);
                 wg_fence(); // earlier flushes are visible
@@ -1090,89 +1213,69 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 } else if (o >= m) wave_copy(d, d - o, m, lane);
                 else wave_pattern(d, o, m, lane);
                 wg_fence();
-                prev_valid = false;
+                v1 = v2 = false;
                 a++;
                 continue;
             }
-            // run [a, b): short sequences whose bytes fit the staging buffer
+            // ---- prepare run [a, b): classify, issue its HBM loads
             const uint64_t stop = __ballot(valid && (uint32_t)lane > a && (islong || incl_t - base_t > kStage));
             const uint32_t b = stop ? (uint32_t)__builtin_ctzll(stop) : cnt;
-            const uint32_t T = __builtin_amdgcn_readlane(incl_t, b - 1) - base_t;
+            RunRegs N; RunInfo NI;
+            NI.run_pos = run_pos;
+            NI.T = __builtin_amdgcn_readlane(incl_t, b - 1) - base_t;
+            NI.buf = runno % 3; NI.buf1 = (runno + 2) % 3; NI.buf2 = (runno + 1) % 3;
+            NI.v1 = v1; NI.v2 = v2; NI.T1 = T1; NI.T2 = T2;
             const bool act = (uint32_t)lane >= a && (uint32_t)lane < b;
-            const uint32_t rel_out = ex_t - base_t, rel_m = rel_out + ll;
-            uint8_t* const sb = S.stage + cur * (kStage + 16);             // this run
-            const uint8_t* const pb = S.stage + (cur ^ 1u) * (kStage + 16); // the previous run, still in LDS
-            // Where a match's source lives.  Relative to the start of this run:
-            //   >= 0                     this run: resolved LDS -> LDS in rounds
-            //   [-prevT, 0)              the previous run: LDS -> LDS at once (its flush may still be in flight)
-            //   < -prevT                 older output: HBM.  Every flush waits for the one before it, so
-            //                            everything older than the previous run has landed.
-            const int64_t rel_src = (int64_t)rel_m - (int64_t)off;
-            const bool plain = off >= ml; // source and destination do not overlap
-            const bool has = act && ml > 0;
-            const bool before = has && plain && rel_src + (int64_t)ml <= 0;
-            const int64_t pdist = -rel_src;
-            const bool from_prev = before && prev_valid && pdist <= (int64_t)prevT;
-            const bool from_hbm = before && !from_prev && (!prev_valid || pdist - (int64_t)ml >= (int64_t)prevT);
-            CSTAMP(1);
-            { // one HBM round trip for the literals and the old matches of the whole run
-                ShortRegs A, B;
-                if (act && ll) short_load(ll, GlobalLd{lit + my_lit}, A);
-                if (from_hbm) short_load(ml, GlobalLd{dst + run_pos + rel_src}, B);
-                if (from_prev) copy_short(ml, LdsLd{pb + (prevT - (uint32_t)pdist)}, LdsSt{sb + rel_m});
-                if (act && ll) short_store(ll, LdsSt{sb + rel_out}, A);
-                if (from_hbm) short_store(ml, LdsSt{sb + rel_m}, B);
+            N.ll = act ? ll : 0; N.ml = act ? ml : 0; N.off = off; N.rel_out = ex_t - base_t; N.my_lit = my_lit;
+            const uint32_t rel_m = N.rel_out + N.ll;
+            N.rel_src = (int32_t)rel_m - (int32_t)off; // off < 2^31 (validated against the window by the planner)
+            N.kind = 0; N.srcpos = 0;
+            if (N.ml) {
+                const bool plain = off >= N.ml;
+                const bool before = plain && N.rel_src + (int32_t)N.ml <= 0;
+                const int32_t pd = -N.rel_src;       // distance of the source start before the run start
+                const int32_t pe_ = pd - (int32_t)N.ml; // distance of the source end before the run start (>= 0 when `before`)
+                const int32_t lim1 = v1 ? (int32_t)T1 : 0, lim2 = lim1 + ((v1 && v2) ? (int32_t)T2 : 0);
+                if (!before) N.kind = 1;
+                else if (v1 && pd <= lim1) { N.kind = 2; N.srcpos = (uint32_t)(lim1 - pd); }
+                else if (v1 && v2 && pe_ >= lim1 && pd <= lim2) { N.kind = 3; N.srcpos = (uint32_t)(lim2 - pd); }
+                else if (pe_ >= lim2) N.kind = N.ml > 31 ? 5 : 4;
+                else N.kind = 1; // straddles a run boundary: byte path in the rounds
             }
-            bool pending = has && !from_prev && !from_hbm;
-            CSTAMP(2);
-            // the rest in rounds, LDS -> LDS
-            const uint32_t span = ml < off ? ml : off;
-            uint64_t pm = __ballot(pending);
-            while (pm) {
-                const int first = __builtin_ctzll(pm);
-                const int64_t hwm = (int64_t)__builtin_amdgcn_readlane(rel_m, first);
-                const bool ready = pending && rel_src + (int64_t)span <= hwm;
-                if (ready) {
-                    if (plain && rel_src >= 0) copy_short(ml, LdsLd{sb + rel_src}, LdsSt{sb + rel_m});
-                    else { // overlapping match, or a source that straddles a boundary: byte by byte, three-way source
-                        uint32_t idx = 0;
-                        for (uint32_t k = 0; k < ml; k++) {
-                            const int64_t p = rel_src + idx;
-                            uint8_t bv; // typed loads: hipcc 7.2 miscompiles a load through a pointer selected between HBM and LDS
-                            if (p >= 0) bv = *(const __attribute__((address_space(3))) uint8_t*)(sb + p);
-                            else if (prev_valid && -p <= (int64_t)prevT) bv = *(const __attribute__((address_space(3))) uint8_t*)(pb + ((int64_t)prevT + p));
-                            else bv = *(const __attribute__((address_space(1))) uint8_t*)(dst + run_pos + p);
-                            sb[rel_m + k] = bv;
-                            idx++;
-                            if (idx == off) idx = 0;
-                        }
-                    }
-                }
-                pending = pending && !ready;
-                pm = __ballot(pending);
+            NI.nlmax = __any(N.ll != 0) ? 1u : 0u;
+            NI.bigl = __any(N.ll > 31);
+            N.l0 = N.l1 = N.l2 = N.h0 = N.h1 = N.h2 = 0; N.lt4 = N.lt2 = N.lt1 = N.ht4 = N.ht2 = N.ht1 = 0;
+            if (!NI.bigl && NI.nlmax) {
+                const GlobalLd gl{lit + my_lit};
+                const uint32_t q = N.ll >> 3, t = q * 8;
+                if (q > 0) N.l0 = gl.u64(0);
+                if (q > 1) N.l1 = gl.u64(8);
+                if (q > 2) N.l2 = gl.u64(16);
+                if (N.ll & 4) N.lt4 = gl.u32(t);
+                if (N.ll & 2) N.lt2 = gl.u16(t + (N.ll & 4));
+                if (N.ll & 1) N.lt1 = gl.u8(t + (N.ll & 6));
             }
-            CSTAMP(3);
-            // flush the run: LDS -> HBM, 16 bytes per lane.  First wait for the previous flush.
-            wg_fence();
-            CSTAMP(4);
-            if (lane == 0) __atomic_store_n(&S.c.exec_pos, run_pos, __ATOMIC_RELAXED); // everything before this run has landed
-            {
-                uint8_t* g = dst + run_pos;
-                for (uint32_t k = (uint32_t)lane * 16; k < T; k += 1024) {
-                    if (k + 16 <= T) {
-                        uint4 v = *reinterpret_cast<const uint4*>(sb + k);
-                        __builtin_memcpy(g + k, &v, 16);
-                    } else {
-                        for (uint32_t j = k; j < T; j++) g[j] = sb[j];
-                    }
+            if (__any(N.kind == 4)) {
+                if (N.kind == 4) {
+                    const GlobalLd gh{dst + run_pos + N.rel_src};
+                    const uint32_t q = N.ml >> 3, t = q * 8;
+                    if (q > 0) N.h0 = gh.u64(0);
+                    if (q > 1) N.h1 = gh.u64(8);
+                    if (q > 2) N.h2 = gh.u64(16);
+                    if (N.ml & 4) N.ht4 = gh.u32(t);
+                    if (N.ml & 2) N.ht2 = gh.u16(t + (N.ml & 4));
+                    if (N.ml & 1) N.ht1 = gh.u8(t + (N.ml & 6));
                 }
             }
-            prev_valid = true; prevT = T; cur ^= 1u;
-            CSTAMP(5);
+            // ---- finish the run prepared one step ago while these loads are in flight
+            if (haveR) finish(R, RI);
+            R = N; RI = NI; haveR = true;
+            v2 = v1; T2 = T1; v1 = true; T1 = NI.T; runno++;
             a = b;
         }
         opos += chunk_tot;
     }
+    if (haveR) finish(R, RI);
     // the literals after the last sequence: the planner has validated them once it is finished
     if (nseq) {
         for (uint32_t it = 0; it < (1u << 24); it++) {
@@ -1568,9 +1671,13 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         }
                     } else {
                         int rc = 0;
-                        if (lit_type == 2) { // K1: weights by one lane, table by 128
+                        if (lit_type == 2) { // K1: weights by one lane (from an LDS copy of the tree description), table by 128
+                            if (wave == 1) {
+                                const uint32_t tl = c.huf_tree_len; // <= 129 bytes
+                                for (uint32_t k = (uint32_t)lane; k < tl + 8; k += 64) S.stage[1024 + k] = k < tl ? blk[c.huf_tree_off + k] : 0;
+                            }
                             if (tid == 64) {
-                                int used = read_huf_weights(blk + c.huf_tree_off, c.huf_tree_len);
+                                int used = read_huf_weights(S.stage + 1024, c.huf_tree_len);
                                 if (used <= 0) post_err(&c.err, MZD_E_CORRUPT);
                                 else c.huf_valid = 1;
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1586,9 +1693,10 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             uint32_t w = (uint32_t)src[lit_off] * 0x01010101u;
                             for (uint32_t k = (uint32_t)(tid - 64) * 16; k < nlit; k += 128 * 16)
                                 *reinterpret_cast<uint4*>(lit_buf + k) = make_uint4(w, w, w, w); // lit_buf has slack past nlit
-                        } else if (lit_type >= 2 && !failed) { // K2: wave 1 takes streams 0 and 1, wave 2 streams 2 and 3
+                        } else if (lit_type >= 2 && !failed) { // K2: wave 1 (the copier-to-be) takes stream 0, wave 2 streams 1, 2 and 3
                             const uint32_t hl = c.huf_log;
-                            for (uint32_t st = (uint32_t)(wave - 1) * 2; st < (uint32_t)(wave - 1) * 2 + 2 && st < streams && !rc; st++)
+                            const uint32_t s0 = wave == 1 ? 0 : 1, s1 = wave == 1 ? 1 : 4;
+                            for (uint32_t st = s0; st < s1 && st < streams && !rc; st++)
                                 rc = huf_stream_wave(blk + c.s_off[st], c.s_len[st], lit_buf + c.s_out[st], c.s_n[st], S.huf, hl, lane);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
