@@ -156,7 +156,7 @@ class LibZstd:
                                                  C.POINTER(C.c_uint64)]
                 L.zref_time_oneshot_mt.restype = C.c_double
                 L.zref_time_oneshot_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p,
-                                                   C.c_void_p, C.c_uint, C.POINTER(C.c_uint64)]
+                                                   C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint64)]
         return cls._ok
 
     @staticmethod

@@ -190,7 +190,7 @@ double zref_time_stream8k(const uint8_t* blob, const uint64_t* offs, const uint6
 }
 
 typedef struct {
-    const uint8_t* blob; const uint64_t* offs; const uint64_t* sizes; unsigned nfiles;
+    const uint8_t* blob; const uint64_t* offs; const uint64_t* sizes; unsigned nfiles, ntasks;
     uint8_t* out; const uint64_t* out_offs; const uint64_t* out_caps;
     volatile unsigned* next; uint64_t bytes; int fail;
 } mt_arg;
@@ -199,8 +199,9 @@ static void* mt_worker(void* v) {
     mt_arg* a = (mt_arg*)v;
     void* d = p_createDCtx();
     for (;;) {
-        unsigned i = __sync_fetch_and_add(a->next, 1);
-        if (i >= a->nfiles) break;
+        unsigned t = __sync_fetch_and_add(a->next, 1);
+        if (t >= a->ntasks) break;
+        unsigned i = t % a->nfiles; /* pass number = t / nfiles */
         size_t r = p_decompressDCtx(d, a->out + a->out_offs[i], (size_t)a->out_caps[i], a->blob + a->offs[i], (size_t)a->sizes[i]);
         if (p_isError(r)) { a->fail = 1; break; }
         a->bytes += r;
@@ -209,16 +210,19 @@ static void* mt_worker(void* v) {
     return NULL;
 }
 
-/* B2: nthreads workers, one file per task, reused DCtx per thread, one-shot decode into out[]. */
+/* B2: nthreads workers created ONCE, `passes` passes over the files (one file per task, reused DCtx per
+ * thread, one-shot decode into out[]).  Returns seconds; *bytes = decompressed bytes of all passes. */
 double zref_time_oneshot_mt(const uint8_t* blob, const uint64_t* offs, const uint64_t* sizes, unsigned nfiles,
-                            uint8_t* out, const uint64_t* out_offs, const uint64_t* out_caps, unsigned nthreads, uint64_t* bytes) {
+                            uint8_t* out, const uint64_t* out_offs, const uint64_t* out_caps, unsigned nthreads, unsigned passes,
+                            uint64_t* bytes) {
     if (nthreads < 1) nthreads = 1;
-    if (nthreads > 256) nthreads = 256;
-    pthread_t th[256]; mt_arg args[256];
+    if (nthreads > 512) nthreads = 512;
+    if (passes < 1) passes = 1;
+    pthread_t th[512]; static mt_arg args[512];
     volatile unsigned next = 0;
     double t0 = now_s();
     for (unsigned t = 0; t < nthreads; t++) {
-        mt_arg a = {blob, offs, sizes, nfiles, out, out_offs, out_caps, &next, 0, 0};
+        mt_arg a = {blob, offs, sizes, nfiles, nfiles * passes, out, out_offs, out_caps, &next, 0, 0};
         args[t] = a;
         pthread_create(&th[t], NULL, mt_worker, &args[t]);
     }

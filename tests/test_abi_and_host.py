@@ -1,0 +1,100 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/mzd.h declares; host-side
+logic that needs no GPU (frame-header walk, error strings, argument checks, no-GPU behaviour)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import fuse_zstd_amd as mzd
+import oracle
+from tests import golden_util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VECS = golden_util.load_manifest()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    mzd.build()
+    return mzd.lib()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    header = open(os.path.join(ROOT, "include", "mzd.h")).read()
+    declared = set(re.findall(r"\b(mzd_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mzd_job", "mzd_batch", "mzd_fs"}
+    assert declared == set(mzd.EXPORTS), declared ^ set(mzd.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_header_cites_the_reference_boundary():
+    header = open(os.path.join(ROOT, "include", "mzd.h")).read()
+    for cite in ("src/main.rs:463-467", "src/main.rs:451-493", "src/file.rs", "src/main.rs:467"):
+        assert cite in header or cite.replace("src/main.rs:451-493", ":451-493") in header
+
+
+@pytest.mark.parametrize("v", [v for v in VECS if v.ok and v.dict is None], ids=lambda v: v.name)
+def test_content_size_matches_oracle(lib, v):
+    got = mzd.content_size(v.comp)
+    want = oracle.content_size(v.comp)
+    assert got == want
+    assert got in (v.out_len, mzd.CONTENTSIZE_UNKNOWN)
+
+
+def test_content_size_malformed(lib):
+    assert mzd.content_size(b"\x01\x02\x03\x04\x05\x06") == mzd.CONTENTSIZE_ERROR
+    assert mzd.content_size(b"\x28\xb5\x2f") == mzd.CONTENTSIZE_ERROR
+    assert mzd.content_size(b"") == 0
+    good = next(x for x in VECS if x.name == "json_4k").comp
+    assert mzd.content_size(good[:-5]) == mzd.CONTENTSIZE_ERROR  # truncated inside the frame
+
+
+def test_error_strings_and_codes(lib):
+    for code in range(0, -10, -1):
+        assert mzd.strerror(code) and mzd.strerror(code) != "unknown error"
+    # same numbering as the oracle's classes (tests compare them directly)
+    assert (mzd.E_CORRUPT, mzd.E_TRUNCATED, mzd.E_CHECKSUM, mzd.E_DSTSIZE, mzd.E_UNSUPPORTED, mzd.E_BADMAGIC, mzd.E_DICT) == \
+           (oracle.E_CORRUPT, oracle.E_TRUNCATED, oracle.E_CHECKSUM, oracle.E_DSTSIZE, oracle.E_UNSUPPORTED, oracle.E_BADMAGIC, oracle.E_DICT)
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a machine without a GPU")
+def test_no_gpu_fails_loudly_never_falls_back(lib):
+    """Without a GPU the product path must refuse, not decode on the CPU."""
+    with pytest.raises(mzd.MzdError) as e:
+        mzd.init()
+    assert e.value.code == mzd.E_DEVICE
+    assert mzd.device_count() == 0
+    good = next(x for x in VECS if x.name == "json_4k")
+    buf = C.create_string_buffer(good.out_len)
+    n = C.c_size_t(0)
+    assert lib.mzd_decode(good.comp, len(good.comp), buf, good.out_len, C.byref(n)) == mzd.E_DEVICE
+    fs = mzd.ZstdFS()
+    with pytest.raises(OSError):  # open() maps every decode failure to EFAULT (reference src/main.rs:467)
+        fs.open(1, 0, good.comp)
+    fs.close()
+
+
+def test_product_never_links_the_oracle():
+    """The product library must not reference anything under oracle/ (it is test infrastructure)."""
+    import subprocess
+    so = os.path.join(ROOT, "fuse_zstd_amd", "libmzd.so")
+    syms = subprocess.check_output(["nm", "-D", so]).decode()
+    assert "ozs_" not in syms and "zref_" not in syms
+    deps = subprocess.check_output(["ldd", so]).decode()
+    assert "liboracle" not in deps and "libzstd" not in deps
+    for f in ("mzd_host.cpp", "mzd_kernels.hip", "mzd_device.h"):
+        text = open(os.path.join(ROOT, "fuse_zstd_amd", "csrc", f)).read()
+        assert "oracle/" not in text and "zstd_oracle" not in text
+    for f in ("api.py", "__init__.py"):
+        text = open(os.path.join(ROOT, "fuse_zstd_amd", f)).read()
+        assert "import oracle" not in text and "from oracle" not in text

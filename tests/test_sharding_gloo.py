@@ -1,0 +1,61 @@
+"""CPU suite: the N > 1 path of bench.py -- files dealt round-robin over ranks (file i -> rank i mod N),
+no data-path collective, aggregation with all_reduce/all_gather -- on 2 gloo ranks."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["MZD_ROOT"])
+import numpy as np
+import torch, torch.distributed as dist
+import bench, corpus, oracle
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+nfiles = 6
+for workload in ("cfg2", "cfg4lu"):
+    kind, cfg_id, kind_mod, desc = bench.WORKLOADS[workload]
+    sizes = [min(s, 40000) for s in bench.file_sizes(workload, nfiles, rank, world)]
+    cp = corpus.build_corpus(kind, cfg_id, sizes, first_index=rank, stride=world, level=3, kind_mod=kind_mod, nthreads=2)
+    # this rank's files are exactly the global files rank, rank+world, ...
+    for i in range(nfiles):
+        g = rank + i * world
+        assert cp.raw_file(i).tobytes() == corpus.gen(kind, cfg_id, g, sizes[i]), (workload, rank, i)
+        rc, out = oracle.decode(cp.comp_file(i).tobytes(), cap=sizes[i])
+        assert rc == 0 and out == cp.raw_file(i).tobytes()
+    mine = torch.tensor([rank + i * world for i in range(nfiles)], dtype=torch.int64)
+    allidx = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allidx, mine)
+    flat = sorted(int(x) for t in allidx for x in t)
+    assert flat == list(range(nfiles * world)), flat          # disjoint and complete
+    tot = torch.tensor([float(cp.raw_sizes.sum())], dtype=torch.float64)
+    dist.all_reduce(tot)                                        # the only aggregation bench.py needs
+    elapsed = torch.tensor([0.5 + rank], dtype=torch.float64)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)             # MAX over ranks, as the bench contract says
+    assert float(elapsed) == 0.5 + world - 1
+    if rank == 0:
+        print(json.dumps({"workload": workload, "total_bytes": float(tot)}))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(300)
+def test_round_robin_sharding_two_gloo_ranks(tmp_path):
+    import corpus
+    if not corpus.have_zstd():
+        pytest.skip("no libzstd shared object to compress a corpus with")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MZD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(2)]
+    outs = [p.communicate(timeout=280) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se.decode()[-2000:]
+    lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 2
