@@ -198,14 +198,21 @@ typedef struct {
 static void* mt_worker(void* v) {
     mt_arg* a = (mt_arg*)v;
     void* d = p_createDCtx();
+    /* pass 0 decodes into the shared out[] (each file exactly once: used for verification); later passes
+     * decode into a private buffer -- libzstd uses dst as its window, so two threads must never share one */
+    uint64_t maxcap = 0;
+    for (unsigned i = 0; i < a->nfiles; i++) if (a->out_caps[i] > maxcap) maxcap = a->out_caps[i];
+    uint8_t* priv = (uint8_t*)malloc((size_t)maxcap + 64);
     for (;;) {
         unsigned t = __sync_fetch_and_add(a->next, 1);
         if (t >= a->ntasks) break;
         unsigned i = t % a->nfiles; /* pass number = t / nfiles */
-        size_t r = p_decompressDCtx(d, a->out + a->out_offs[i], (size_t)a->out_caps[i], a->blob + a->offs[i], (size_t)a->sizes[i]);
+        uint8_t* dst = t < a->nfiles ? a->out + a->out_offs[i] : priv;
+        size_t r = p_decompressDCtx(d, dst, (size_t)a->out_caps[i], a->blob + a->offs[i], (size_t)a->sizes[i]);
         if (p_isError(r)) { a->fail = 1; break; }
         a->bytes += r;
     }
+    free(priv);
     p_freeDCtx(d);
     return NULL;
 }
