@@ -82,6 +82,7 @@ struct Ctl {
     uint32_t lit_is_raw;
     uint32_t huf_tree_off, huf_tree_len;           // Huffman tree description inside the block
     uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
+    uint32_t next_stream, streams_done;            // Huffman streams are handed out to whichever wavefront is free
     uint32_t tables_ready, plan_prog, copy_prog, plan_lit_used; // walker -> planner -> copier
     uint32_t exec_done;                            // the copying wavefront has finished the block
     uint64_t exec_pos;                             // output bytes complete and visible (published by the executor)
@@ -445,6 +446,9 @@ __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint
         bool changed = ns != start;
         if (!__any(changed)) break;
         if (changed) { start = ns; exitp = walk(start, cnt, nullptr); }
+#ifdef MZD_STAMPS
+        if (lane == 0) atomicAdd(&S.c.diag_slow, 1u); // diagnostic: synchronisation rounds
+#endif
     }
     uint32_t incl = wave_incl_scan(cnt, lane);
     uint32_t total = __builtin_amdgcn_readlane(incl, 63);
@@ -1618,6 +1622,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     __syncthreads();
                     if (tid == 0) {
                         c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = out0;
+                        c.next_stream = 0; c.streams_done = 0;
                         c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0;
                         parse_literals(S.stage, bsize);
                     }
@@ -1633,6 +1638,27 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     if (err) break;
                     STAMP(1);
                     const uint8_t* const lit = lit_type == 0 ? src + lit_off : lit_buf;
+                    // K2 worker: take Huffman streams from the block's queue until none is left
+                    auto huf_streams = [&]() {
+                        const uint32_t hl = c.huf_log;
+                        for (;;) {
+                            // every lane takes part (lanes != 0 add 0): no divergent region around the returning atomic
+                            uint32_t st = __atomic_fetch_add(&c.next_stream, lane == 0 ? 1u : 0u, __ATOMIC_RELAXED);
+                            st = (uint32_t)__builtin_amdgcn_readfirstlane(st);
+                            if (st >= streams || st >= 4) break;
+                            int r = 0;
+                            if (!__atomic_load_n(&c.err, __ATOMIC_RELAXED))
+                                r = huf_stream_wave(blk + c.s_off[st], c.s_len[st], lit_buf + c.s_out[st], c.s_n[st], S.huf, hl, lane);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) { post_err(&c.err, r); __atomic_fetch_add(&c.streams_done, 1u, __ATOMIC_RELAXED); }
+                        }
+                    };
+                    // wavefronts 0 and 3 have nothing else to do in a block without sequences: they decode literals too
+                    auto huf_helper = [&]() {
+                        if (lit_type < 2 || nseq) return;
+                        if (lit_type == 2 && !spin_ge(&c.huf_fill, 2, &c.err)) return;
+                        huf_streams();
+                    };
                     // ---- the block pipeline, one role per wavefront:
                     //   wave 0  K3 tables, K4a serial state walk
                     //   wave 1  K1/K2 literals (streams 0,1), then the copying half of K5
@@ -1655,7 +1681,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             STAMP(5);
                             TFIN(0);
                         }
+                        huf_helper();
                     } else if (wave == 3) {
+                        huf_helper();
                         if (nseq) {
                             int rc = MZD_E_CORRUPT;
                             if (spin_ge(&c.tables_ready, 1, &c.err)) {
@@ -1693,11 +1721,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             uint32_t w = (uint32_t)src[lit_off] * 0x01010101u;
                             for (uint32_t k = (uint32_t)(tid - 64) * 16; k < nlit; k += 128 * 16)
                                 *reinterpret_cast<uint4*>(lit_buf + k) = make_uint4(w, w, w, w); // lit_buf has slack past nlit
-                        } else if (lit_type >= 2 && !failed) { // K2: wave 1 (the copier-to-be) takes stream 0, wave 2 streams 1, 2 and 3
-                            const uint32_t hl = c.huf_log;
-                            const uint32_t s0 = wave == 1 ? 0 : 1, s1 = wave == 1 ? 1 : 4;
-                            for (uint32_t st = s0; st < s1 && st < streams && !rc; st++)
-                                rc = huf_stream_wave(blk + c.s_off[st], c.s_len[st], lit_buf + c.s_out[st], c.s_n[st], S.huf, hl, lane);
+                        } else if (lit_type >= 2 && !failed) { // K2
+                            huf_streams();
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) {
@@ -1709,7 +1734,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         if (wave == 1) { // the copying half of K5
                             uint64_t opos = out0;
                             rc = MZD_E_CORRUPT;
-                            if (spin_ge(&c.lit_done, 2, &c.err)) {
+                            if (spin_ge(&c.lit_done, 2, &c.err) && (lit_type < 2 || spin_ge(&c.streams_done, streams, &c.err))) {
                                 CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit, nlit};
                                 rc = copy_wave(nseq, cx, &opos, lane);
                             }
