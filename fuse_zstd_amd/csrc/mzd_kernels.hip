@@ -279,9 +279,23 @@ __device__ void rle_seq_table(uint64_t* tab, uint32_t s, int kind) { tab[0] = pa
 
 // ------------------------------------------------------------------------------------ K1
 // Huffman tree description (A.4) -> S.weights[0..nw), S.c.huf_log.  Lane 0.  Returns bytes used or < 0.
-__device__ __noinline__ int read_huf_weights(const uint8_t* src, uint32_t n) {
+template <class LD>
+__device__ __forceinline__ int read_huf_weights_t(LD ld, uint32_t n) {
     if (n < 1) return MZD_E_CORRUPT;
-    uint32_t hb = src[0], nw = 0;
+    auto byte_at = [&](uint32_t o) -> uint32_t { return (uint32_t)(ld(o) & 0xFF); };
+    // bits [bitpos, bitpos+nb) of the little-endian integer made of bytes [base, base+len); indices < 0 read as 0; nb <= 16
+    auto take = [&](uint32_t base, uint32_t len, int32_t bitpos, int nb) -> uint32_t {
+        if (nb == 0) return 0u;
+        int32_t neg = 0;
+        if (bitpos < 0) { neg = -bitpos; if (neg >= nb) return 0u; nb -= neg; bitpos = 0; }
+        uint32_t byte = (uint32_t)bitpos >> 3;
+        if (byte >= len) return 0u;
+        uint64_t v = ld(base + byte);
+        uint32_t avail = len - byte;
+        if (avail < 8) v &= (1ull << (avail * 8)) - 1;
+        return (uint32_t)((v >> (bitpos & 7)) & ((1u << nb) - 1)) << neg;
+    };
+    uint32_t hb = byte_at(0), nw = 0;
     int used;
     uint8_t* w = S.weights;
     if (hb >= 128) {
@@ -289,19 +303,19 @@ __device__ __noinline__ int read_huf_weights(const uint8_t* src, uint32_t n) {
         uint32_t bytes = (nw + 1) / 2;
         if (1 + bytes > n) return MZD_E_CORRUPT;
         for (uint32_t i = 0; i < nw; i++) {
-            uint32_t b = src[1 + i / 2];
+            uint32_t b = byte_at(1 + i / 2);
             w[i] = (uint8_t)((i & 1) ? (b & 15) : (b >> 4));
         }
         used = 1 + (int)bytes;
     } else {
         if (hb < 1 || 1 + hb > n) return MZD_E_CORRUPT;
-        const uint8_t* p = src + 1;
         uint32_t nsym, log;
-        int hdr = read_ncount(p, hb, 6, 255, S.wnorm, &nsym, &log);
+        struct Shift { LD ld; uint32_t o; __device__ __forceinline__ uint64_t operator()(uint32_t k) const { return ld(o + k); } };
+        int hdr = read_ncount_t(Shift{ld, 1}, hb, 6, 255, S.wnorm, &nsym, &log);
         if (hdr <= 0) return MZD_E_CORRUPT;
         // tiny FSE table (<= 64 entries) built in place
         uint32_t size = 1u << log, high = size;
-        uint16_t* next = (uint16_t*)(void*)S.stage; // the executor's staging buffer is idle until the literals exist
+        uint16_t* next = (uint16_t*)(void*)S.stage; // the copier's staging buffer is idle until the literals exist
         for (uint32_t s = 0; s < nsym; s++)
             if (S.wnorm[s] == -1) { high--; S.wtab[high] = s; next[s] = 1; }
         uint32_t step = (size >> 1) + (size >> 3) + 3, pos = 0, mask = size - 1;
@@ -321,21 +335,22 @@ __device__ __noinline__ int read_huf_weights(const uint8_t* src, uint32_t n) {
             S.wtab[i] = s | (nb << 8) | (((d << nb) - size) << 16);
         }
         if ((uint32_t)hdr >= hb) return MZD_E_CORRUPT;
-        const uint8_t* bs = p + hdr;
-        uint32_t bl = hb - (uint32_t)hdr;
-        if (bs[bl - 1] == 0) return MZD_E_CORRUPT;
-        int32_t bpos = (int32_t)(bl - 1) * 8 + hibit(bs[bl - 1]);
-        bpos -= (int32_t)log; uint32_t s1 = bits_at(bs, bl, bpos, (int)log);
-        bpos -= (int32_t)log; uint32_t s2 = bits_at(bs, bl, bpos, (int)log);
+        const uint32_t bs = 1 + (uint32_t)hdr; // offset of the weight bitstream
+        const uint32_t bl = hb - (uint32_t)hdr;
+        const uint32_t lastb = byte_at(bs + bl - 1);
+        if (lastb == 0) return MZD_E_CORRUPT;
+        int32_t bpos = (int32_t)(bl - 1) * 8 + hibit(lastb);
+        bpos -= (int32_t)log; uint32_t s1 = take(bs, bl, bpos, (int)log);
+        bpos -= (int32_t)log; uint32_t s2 = take(bs, bl, bpos, (int)log);
         int ok = 0;
         for (;;) { // two interleaved states; ends when the stream is over-read
             if (nw > 253) break;
             uint32_t e = S.wtab[s1];
-            w[nw++] = (uint8_t)e; int nb = (e >> 8) & 0xFF; bpos -= nb; s1 = (e >> 16) + bits_at(bs, bl, bpos, nb);
+            w[nw++] = (uint8_t)e; int nb = (e >> 8) & 0xFF; bpos -= nb; s1 = (e >> 16) + take(bs, bl, bpos, nb);
             if (bpos < 0) { w[nw++] = (uint8_t)S.wtab[s2]; ok = 1; break; }
             if (nw > 253) break;
             e = S.wtab[s2];
-            w[nw++] = (uint8_t)e; nb = (e >> 8) & 0xFF; bpos -= nb; s2 = (e >> 16) + bits_at(bs, bl, bpos, nb);
+            w[nw++] = (uint8_t)e; nb = (e >> 8) & 0xFF; bpos -= nb; s2 = (e >> 16) + take(bs, bl, bpos, nb);
             if (bpos < 0) { w[nw++] = (uint8_t)S.wtab[s1]; ok = 1; break; }
         }
         if (!ok) return MZD_E_CORRUPT;
@@ -366,6 +381,9 @@ __device__ __noinline__ int read_huf_weights(const uint8_t* src, uint32_t n) {
     S.c.huf_log = maxbits;
     return used;
 }
+__device__ __noinline__ int read_huf_weights(const uint8_t* src, uint32_t n) { return read_huf_weights_t(HbmBytes{src}, n); }               // dictionary (HBM)
+__device__ __noinline__ int read_huf_weights_staged(uint32_t stage_off, uint32_t n) { return read_huf_weights_t(StageBytes{stage_off}, n); } // a block's tree, staged in LDS
+
 
 // Canonical table fill by all 256 lanes: lane s owns symbol s.
 __device__ __noinline__ void fill_huf_table(int first, int stride) {
@@ -393,69 +411,97 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     return r;
 }
 
-// One Huffman stream decoded by the 64 lanes of a wavefront (A.4).
-// Lane k starts at bit k*C of the stream (a guess for k > 0); lanes then re-start from
-// their predecessor's exit position until the chain is consistent (Huffman codes
-// self-synchronise, so this takes a couple of rounds), a scan of the symbol counts gives
-// the output offsets, and a last pass writes.  Returns 0 or an error.
-__device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, const uint16_t* tab, uint32_t L, int lane) {
+// One Huffman stream decoded by the 64 lanes of a wavefront (A.4), ~2 KiB of stream at a time:
+//   * the segment is staged in LDS with coalesced 16-byte loads (`seg`, 2 KiB + 64 bytes, private to the wavefront);
+//   * lane k starts at bit k*C of the segment (a guess for k > 0); lanes then re-start from their
+//     predecessor's exit position until the chain is consistent (Huffman codes self-synchronise, so this
+//     takes a round or two); lane 0's start is exact: it is where the previous segment ended;
+//   * a DPP scan of the symbol counts gives the output offsets, and a last pass writes.
+// Every lane reads through a 64-bit register window refilled a dword at a time from LDS.
+constexpr int32_t kSegBits = 64 * 248; // 31 bytes per lane: lane windows fall into different LDS banks
+
+__device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int lane) {
     if (sl == 0) return MZD_E_CORRUPT;
     uint32_t last = sp[sl - 1];
     if (last == 0) return MZD_E_CORRUPT;
     const int32_t nbits = (int32_t)((sl - 1) * 8 + (uint32_t)hibit(last));
     const uint32_t mask = (1u << L) - 1;
-    int32_t C = (nbits + 63) / 64;
-    if (C < 32) C = 32;
-    int32_t q0 = lane * C, q1 = q0 + C;
-    if (q0 > nbits) q0 = nbits;
-    if (q1 > nbits) q1 = nbits;
-    if (lane == 63) q1 = nbits;
-
-    // Each lane reads its part of the stream through a 64-bit register window over stream bits [wb, wb+64),
-    // wb a multiple of 32, refilled one dword at a time from a dword that was loaded one refill earlier:
-    // one HBM access per ~4 symbols instead of one per symbol, and never waited for.
-    // Dwords below the stream start read as zero (bits below bit 0 of a backward stream are zero).
-    auto dword = [&](int32_t d) -> uint32_t { return d < 0 ? 0u : ldu32(sp + (uint32_t)d * 4); }; // may over-read <= 3 bytes (input padding)
-    auto walk = [&](int32_t from, uint32_t& cnt, uint8_t* dst) -> int32_t {
-        int32_t rem = nbits - from; // bits below the read point
-        const int32_t lim = nbits - q1;
-        int32_t wb = (rem - (int32_t)L) & ~31; // <= rem - L, may be negative
-        uint32_t hi = dword((wb >> 5) + 1), lo = dword(wb >> 5), nx = dword((wb >> 5) - 1);
-        uint32_t c = 0;
-        while (rem > lim) {
-            const uint64_t W = ((uint64_t)hi << 32) | lo;
-            const uint32_t e = tab[(uint32_t)(W >> (uint32_t)(rem - (int32_t)L - wb)) & mask];
-            const uint32_t l = e >> 8;
-            if (dst) dst[c] = (uint8_t)e;
-            c++;
-            rem -= (int32_t)(l ? l : 1u);
-            if (rem - (int32_t)L < wb) { // slide the window down one dword
-                hi = lo; lo = nx; wb -= 32;
-                nx = dword((wb >> 5) - 1);
-            }
+    const uint16_t* const tab = S.huf;
+    int32_t pos = 0;        // bits consumed so far (wave-uniform, exact)
+    uint32_t done = 0;      // symbols written so far
+    while (pos < nbits) {
+        const int32_t s0 = pos, s1 = pos + kSegBits < nbits ? pos + kSegBits : nbits;
+        // stage stream bytes [blo, bhi): everything the segment can touch (16 bits of slack below it)
+        int32_t lowbit = nbits - s1 - 16;
+        const uint32_t blo = lowbit > 0 ? ((uint32_t)lowbit >> 3) & ~3u : 0u;
+        const uint32_t bhi = (uint32_t)((nbits - s0) + 7) >> 3; // <= sl
+        for (uint32_t o = (uint32_t)lane * 16; blo + o < bhi; o += 1024) {
+            uint4 v;
+            __builtin_memcpy(&v, sp + blo + o, 16); // may over-read <= 15 bytes past the stream (input padding)
+            *reinterpret_cast<uint4*>(seg + o) = v;
         }
-        cnt = c;
-        return nbits - rem;
-    };
-    int32_t start = q0;
-    uint32_t cnt = 0;
-    int32_t exitp = walk(start, cnt, nullptr);
-    for (int round = 0; round < 64; round++) {
-        int32_t pe = __shfl_up(exitp, 1);
-        int32_t ns = lane == 0 ? 0 : pe;
-        bool changed = ns != start;
-        if (!__any(changed)) break;
-        if (changed) { start = ns; exitp = walk(start, cnt, nullptr); }
+        int32_t C = (s1 - s0 + 63) / 64;
+        if (C < 32) C = 32;
+        int32_t q0 = s0 + lane * C, q1 = q0 + C;
+        if (q0 > s1) q0 = s1;
+        if (q1 > s1) q1 = s1;
+        if (lane == 63) q1 = s1;
+        // stream dword d (bits [32d, 32d+32)); below the stream start everything reads as zero
+        auto dword = [&](int32_t d) -> uint32_t {
+            if (d < 0) return 0u;
+            uint32_t v;
+            __builtin_memcpy(&v, seg + ((uint32_t)d * 4 - blo), 4);
+            return v;
+        };
+        auto walk = [&](int32_t from, uint32_t& cnt, uint8_t* dst) -> int32_t {
+            int32_t rem = nbits - from; // bits below the read point
+            const int32_t lim = nbits - q1;
+            int32_t wb = (rem - (int32_t)L) & ~31; // <= rem - L, may be negative
+            uint32_t hi = dword((wb >> 5) + 1), lo = dword(wb >> 5), nx = dword((wb >> 5) - 1);
+            uint32_t c = 0;
+            uint64_t acc = 0; // the write pass packs 8 symbols per HBM store (byte stores cost a sector write each)
+            while (rem > lim) {
+                const uint64_t W = ((uint64_t)hi << 32) | lo;
+                const uint32_t e = tab[(uint32_t)(W >> (uint32_t)(rem - (int32_t)L - wb)) & mask];
+                const uint32_t l = e >> 8;
+                if (dst) {
+                    acc |= (uint64_t)(e & 0xFF) << ((c & 7) * 8);
+                    if ((c & 7) == 7) { __builtin_memcpy(dst + (c & ~7u), &acc, 8); acc = 0; }
+                }
+                c++;
+                rem -= (int32_t)(l ? l : 1u);
+                if (rem - (int32_t)L < wb) { // slide the window down one dword
+                    hi = lo; lo = nx; wb -= 32;
+                    nx = dword((wb >> 5) - 1);
+                }
+            }
+            if (dst) for (uint32_t k = c & ~7u; k < c; k++) { dst[k] = (uint8_t)acc; acc >>= 8; }
+            cnt = c;
+            return nbits - rem;
+        };
+        int32_t start = q0;
+        uint32_t cnt = 0;
+        int32_t exitp = walk(start, cnt, nullptr);
+        for (int round = 0; round < 64; round++) {
+            int32_t pe = __shfl_up(exitp, 1);
+            int32_t ns = lane == 0 ? s0 : pe;
+            bool changed = ns != start;
+            if (!__any(changed)) break;
+            if (changed) { start = ns; exitp = walk(start, cnt, nullptr); }
 #ifdef MZD_STAMPS
-        if (lane == 0) atomicAdd(&S.c.diag_slow, 1u); // diagnostic: synchronisation rounds
+            if (lane == 0) atomicAdd(&S.c.diag_slow, 1u); // diagnostic: synchronisation rounds
 #endif
+        }
+        const uint32_t incl = wave_incl_scan(cnt, lane);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        const int32_t endp = __builtin_amdgcn_readlane(exitp, 63);
+        if (done + total > nsym || endp > nbits) return MZD_E_CORRUPT; // never write past this stream's share of the literals
+        uint32_t dummy;
+        walk(start, dummy, out + done + (incl - cnt));
+        done += total;
+        pos = endp;
     }
-    uint32_t incl = wave_incl_scan(cnt, lane);
-    uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-    int32_t endp = __builtin_amdgcn_readlane(exitp, 63);
-    if (total != nsym || endp != nbits) return MZD_E_CORRUPT;
-    uint32_t dummy;
-    walk(start, dummy, out + (incl - cnt));
+    if (done != nsym) return MZD_E_CORRUPT; // pos == nbits here: the stream was consumed exactly
     return 0;
 }
 
@@ -1200,10 +1246,9 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 if (haveR) { finish(R, RI); haveR = false; }
                 const uint32_t l = __builtin_amdgcn_readlane(ll, a), m = __builtin_amdgcn_readlane(ml, a);
                 const uint32_t o = __builtin_amdgcn_readlane(off, a), lp = __builtin_amdgcn_readlane(my_lit, a);
-                wg_fence(); // earlier flushes are visible
-                if (lane == 0) __atomic_store_n(&S.c.exec_pos, run_pos, __ATOMIC_RELAXED);
-                wave_copy(dst + run_pos, lit + lp, l, lane);
-                wg_fence();
+                wave_copy(dst + run_pos, lit + lp, l, lane); // literals do not depend on earlier output: no fence in front
+                wg_fence();                                   // everything so far (flushes and these literals) has landed
+                if (lane == 0) __atomic_store_n(&S.c.exec_pos, run_pos + l, __ATOMIC_RELAXED);
                 uint8_t* d = dst + run_pos + l;
                 const uint64_t have = run_pos + l - cx.frame_start;
                 if (o > have) { // starts inside the dictionary: owner lane, sequential semantics
@@ -1216,8 +1261,8 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                     }
                 } else if (o >= m) wave_copy(d, d - o, m, lane);
                 else wave_pattern(d, o, m, lane);
-                wg_fence();
-                v1 = v2 = false;
+                if (m) wg_fence();
+                v1 = v2 = false; // nothing older is in LDS any more; all of it has landed in HBM
                 a++;
                 continue;
             }
@@ -1639,6 +1684,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     STAMP(1);
                     const uint8_t* const lit = lit_type == 0 ? src + lit_off : lit_buf;
                     // K2 worker: take Huffman streams from the block's queue until none is left
+                    // 2 KiB of LDS per decoding wavefront, borrowed from buffers that are idle while literals decode: the
+                    // copier's staging buffers (waves 1, 2); the walker's ring (waves 0, 3: they decode after the walk)
+                    uint8_t* const hseg = wave == 1 ? S.stage + 2064 : (wave == 2 ? S.stage + 2 * 2064 : (wave == 0 ? S.ring : S.ring + 4096));
                     auto huf_streams = [&]() {
                         const uint32_t hl = c.huf_log;
                         for (;;) {
@@ -1648,14 +1696,14 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             if (st >= streams || st >= 4) break;
                             int r = 0;
                             if (!__atomic_load_n(&c.err, __ATOMIC_RELAXED))
-                                r = huf_stream_wave(blk + c.s_off[st], c.s_len[st], lit_buf + c.s_out[st], c.s_n[st], S.huf, hl, lane);
+                                r = huf_stream_wave(blk + c.s_off[st], c.s_len[st], lit_buf + c.s_out[st], c.s_n[st], hl, hseg, lane);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) { post_err(&c.err, r); __atomic_fetch_add(&c.streams_done, 1u, __ATOMIC_RELAXED); }
                         }
                     };
-                    // wavefronts 0 and 3 have nothing else to do in a block without sequences: they decode literals too
+                    // wavefronts 0 and 3 decode literals too once their own role is over (at once in a block without sequences)
                     auto huf_helper = [&]() {
-                        if (lit_type < 2 || nseq) return;
+                        if (lit_type < 2) return;
                         if (lit_type == 2 && !spin_ge(&c.huf_fill, 2, &c.err)) return;
                         huf_streams();
                     };
@@ -1683,7 +1731,6 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         }
                         huf_helper();
                     } else if (wave == 3) {
-                        huf_helper();
                         if (nseq) {
                             int rc = MZD_E_CORRUPT;
                             if (spin_ge(&c.tables_ready, 1, &c.err)) {
@@ -1697,6 +1744,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             }
                             TFIN(3);
                         }
+                        huf_helper(); // the ring (its staging area) is free: the walker has finished before the planner does
                     } else {
                         int rc = 0;
                         if (lit_type == 2) { // K1: weights by one lane (from an LDS copy of the tree description), table by 128
@@ -1705,16 +1753,22 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                                 for (uint32_t k = (uint32_t)lane; k < tl + 8; k += 64) S.stage[1024 + k] = k < tl ? blk[c.huf_tree_off + k] : 0;
                             }
                             if (tid == 64) {
-                                int used = read_huf_weights(S.stage + 1024, c.huf_tree_len);
+                                int used = read_huf_weights_staged(1024, c.huf_tree_len);
                                 if (used <= 0) post_err(&c.err, MZD_E_CORRUPT);
                                 else c.huf_valid = 1;
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                 flag_store(&c.huf_ready, 1);
+#ifdef MZD_STAMPS
+                                S.cdiag[0] = __builtin_readcyclecounter() - S.tstart; // diagnostic: weights decoded
+#endif
                             }
                             if (spin_ge(&c.huf_ready, 1, &c.err)) fill_huf_table(tid - 64, 128);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) __atomic_fetch_add(&c.huf_fill, 1u, __ATOMIC_RELAXED);
                             spin_ge(&c.huf_fill, 2, &c.err);
+#ifdef MZD_STAMPS
+                            if (tid == 64) S.cdiag[1] = __builtin_readcyclecounter() - S.tstart; // diagnostic: table filled
+#endif
                         }
                         const bool failed = __atomic_load_n(&c.err, __ATOMIC_RELAXED) != 0;
                         if (lit_type == 1) { // RLE literals
