@@ -1719,7 +1719,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             if (lane == 0) flag_store(&c.tables_ready, 1);
                             STAMP(4);
                             TFIN(5);
+                            __builtin_amdgcn_s_setprio(3); // the chain is the critical path: win issue arbitration on this SIMD
                             int rc = walk_sequences_wave(src + seq_off, seq_len, nseq, walk, &c.walk_prog, lane);
+                            __builtin_amdgcn_s_setprio(0);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) {
                                 post_err(&c.err, rc);
@@ -1735,7 +1737,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             int rc = MZD_E_CORRUPT;
                             if (spin_ge(&c.tables_ready, 1, &c.err)) {
                                 PlanCtx px{walk, src + seq_off, &c.walk_prog, c.frame_out0, cap, c.dict_content_len, nlit};
+                                __builtin_amdgcn_s_setprio(1);
                                 rc = plan_wave(seqs, nseq, px, out0, c.rep, lane);
+                                __builtin_amdgcn_s_setprio(0);
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) {
@@ -1790,7 +1794,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             rc = MZD_E_CORRUPT;
                             if (spin_ge(&c.lit_done, 2, &c.err) && (lit_type < 2 || spin_ge(&c.streams_done, streams, &c.err))) {
                                 CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit, nlit};
+                                __builtin_amdgcn_s_setprio(2); // second on the critical path, behind the walker
                                 rc = copy_wave(nseq, cx, &opos, lane);
+                                __builtin_amdgcn_s_setprio(0);
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) {
