@@ -188,17 +188,24 @@ def main():
         torch.cuda.synchronize(dev)
 
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in evs:  # torch creates the HIP event on first record: do that outside the timed region
+        a.record(stream); b.record(stream)
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
         evs[k][0].record(stream)
         batch.launch(sp)
         evs[k][1].record(stream)
+    t_sub = time.perf_counter()
     fence()
     t1 = time.perf_counter()
     batch.collect(sp)
     elapsed = t1 - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(args.steps, 1)
+    span_ms = evs[0][0].elapsed_time(evs[-1][1])  # first launch start -> last launch end, on the GPU's clock
+    if os.environ.get("MZD_BENCH_GAPS"):
+        gaps = [evs[k][1].elapsed_time(evs[k + 1][0]) for k in range(args.steps - 1)]
+        sys.stderr.write("wall %.3f ms (submit loop %.3f ms), gpu span %.3f ms, gaps(ms) %s\n" % (elapsed * 1e3, (t_sub - t0) * 1e3, span_ms, " ".join("%.3f" % g for g in gaps)))
     last_ms = mzd.last_kernel_ms(0)
 
     if world > 1:

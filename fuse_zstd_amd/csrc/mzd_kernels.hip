@@ -724,7 +724,6 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
     }
     uint32_t woff = 0; // byte offset of the next record (a VGPR next to a scalar base: cheapest store form)
     asm volatile("" : "+v"(woff));
-    uint64_t bad = 0;
     if (sl == 0) return MZD_E_CORRUPT;
     uint32_t last = sp[sl - 1];
     if (last == 0) return MZD_E_CORRUPT;
@@ -769,8 +768,9 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         }
         const uint32_t stop = i + kWalkBatch < nupd ? i + kWalkBatch : nupd;
         uint32_t Gm = G - 32; // the loop carries the read head minus 32 (saves an add per sequence)
+        int32_t slack = 64;   // minimum over the batch of (window bits - bits needed)
         // One step of the chain.  CAREFUL = false is the hot form: no branch at all; it only notes (in
-        // `bad`) that some sequence had more bits than its window holds (long extra-bit fields: about
+        // `slack`) that some sequence had more bits than its window holds (long extra-bit fields: about
         // one sequence in thousands).  The batch is then redone with CAREFUL = true, which moves the
         // window down a dword at a time.  (A branch on freshly loaded LDS data costs ~35 cycles per
         // sequence on a lone wavefront; micro-benchmarked.)
@@ -798,7 +798,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
                     av += 32;
                 }
             } else {
-                bad |= __builtin_amdgcn_ballot_w64(total > av);
+                slack = min((int32_t)(av - total), slack); // goes negative when a sequence does not fit its window
             }
             // fresh state bits sit at the bottom of what this sequence consumes: OF lowest, then ML, then LL
             // (at most 26 bits together: one 64-bit shift, then 32-bit field extracts)
@@ -812,9 +812,10 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
             Gm -= total;
         };
         const uint32_t sL = vL, sM = vM, sO = vO, sG = Gm, sW = woff, i0 = i;
-        bad = 0;
+        slack = 64;
+        for (; i + 4 <= stop; i += 4) { step(std::false_type{}); step(std::false_type{}); step(std::false_type{}); step(std::false_type{}); }
         for (; i < stop; i++) step(std::false_type{});
-        if (__builtin_expect(bad != 0, 0)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(slack < 0) != 0, 0)) {
             vL = sL; vM = sM; vO = sO; Gm = sG; woff = sW;
             for (i = i0; i < stop; i++) step(std::true_type{});
         }
