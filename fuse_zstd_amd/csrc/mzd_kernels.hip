@@ -82,7 +82,7 @@ struct Ctl {
     uint32_t lit_is_raw;
     uint32_t huf_tree_off, huf_tree_len;           // Huffman tree description inside the block
     uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
-    uint32_t next_stream, streams_done;            // Huffman streams are handed out to whichever wavefront is free
+    uint32_t next_stream, streams_done, streams_mask; // Huffman streams are handed out to whichever wavefront is free; mask: bit k = stream k decoded
     uint32_t tables_ready, plan_prog, copy_prog, plan_lit_used; // walker -> planner -> copier
     uint32_t exec_done;                            // the copying wavefront has finished the block
     uint64_t exec_pos;                             // output bytes complete and visible (published by the executor)
@@ -101,6 +101,7 @@ struct __attribute__((aligned(16))) Shared {
     uint64_t ml[512];
     uint64_t of[256];
     uint8_t stage[3 * (2048 + 16)]; // K5 staging: the run being assembled and the two before it (kStage each)
+    uint8_t hseg2[2048 + 64];       // Huffman stream segment of wavefront 2 (it still decodes while the copier already uses `stage`)
     uint32_t ll_base[36], ml_base[53]; // code -> base value (copied once from constant memory)
 #ifdef MZD_STAMPS
     uint64_t cdiag[8];
@@ -865,73 +866,49 @@ typedef __attribute__((address_space(3))) uint8_t* lds_p;
 
 struct RepOp { uint32_t s; int32_t v0, v1, v2; }; // s: 2 bits per slot (0..2 input slot, 3 constant)
 __device__ __forceinline__ uint32_t rep_src(uint32_t s, int j) { return (s >> (2 * j)) & 3; }
-// result = g applied after f
-__device__ __forceinline__ RepOp rep_compose(const RepOp& g, const RepOp& f) {
+// result = g applied after f.  All selects work on values pinned in registers: left to itself the
+// compiler turns "pick one of three struct fields" into an indexed load from a stack copy of the
+// struct, i.e. three dependent scratch-memory round trips per scan step.
+__device__ __forceinline__ int32_t sel3(uint32_t k, int32_t a0, int32_t a1, int32_t a2) {
+    int32_t r = k == 1 ? a1 : a2;
+    return k == 0 ? a0 : r;
+}
+__device__ __forceinline__ RepOp rep_compose(RepOp g, RepOp f) {
+    asm volatile("" : "+v"(f.s), "+v"(f.v0), "+v"(f.v1), "+v"(f.v2));
+    asm volatile("" : "+v"(g.s), "+v"(g.v0), "+v"(g.v1), "+v"(g.v2));
     RepOp r;
-    r.s = 0;
-    int32_t gv[3] = {g.v0, g.v1, g.v2}, rv[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        uint32_t gs = rep_src(g.s, j);
-        uint32_t fs = gs == 0 ? rep_src(f.s, 0) : (gs == 1 ? rep_src(f.s, 1) : rep_src(f.s, 2));
-        int32_t fv = gs == 0 ? f.v0 : (gs == 1 ? f.v1 : f.v2);
-        uint32_t ns = gs == 3 ? 3u : fs;
-        rv[j] = gs == 3 ? gv[j] : fv + gv[j];
-        r.s |= ns << (2 * j);
-    }
-    r.v0 = rv[0]; r.v1 = rv[1]; r.v2 = rv[2];
+    const uint32_t g0 = g.s & 3, g1 = (g.s >> 2) & 3, g2 = (g.s >> 4) & 3;
+    const uint32_t s0 = g0 == 3 ? 3u : (f.s >> (2 * g0)) & 3;
+    const uint32_t s1 = g1 == 3 ? 3u : (f.s >> (2 * g1)) & 3;
+    const uint32_t s2 = g2 == 3 ? 3u : (f.s >> (2 * g2)) & 3;
+    r.s = s0 | (s1 << 2) | (s2 << 4);
+    r.v0 = g.v0 + (g0 == 3 ? 0 : sel3(g0, f.v0, f.v1, f.v2));
+    r.v1 = g.v1 + (g1 == 3 ? 0 : sel3(g1, f.v0, f.v1, f.v2));
+    r.v2 = g.v2 + (g2 == 3 ? 0 : sel3(g2, f.v0, f.v1, f.v2));
     return r;
 }
-__device__ __forceinline__ uint32_t rep_eval(const RepOp& f, int j, uint32_t r0, uint32_t r1, uint32_t r2) {
-    uint32_t src = rep_src(f.s, j);
-    int32_t v = j == 0 ? f.v0 : (j == 1 ? f.v1 : f.v2);
-    uint32_t in = src == 0 ? r0 : (src == 1 ? r1 : r2);
-    return src == 3 ? (uint32_t)v : in + (uint32_t)v;
+__device__ __forceinline__ uint32_t rep_eval(RepOp f, int j, uint32_t r0, uint32_t r1, uint32_t r2) {
+    asm volatile("" : "+v"(f.s), "+v"(f.v0), "+v"(f.v1), "+v"(f.v2));
+    const uint32_t src = rep_src(f.s, j);
+    const int32_t v = j == 0 ? f.v0 : (j == 1 ? f.v1 : f.v2);
+    const uint32_t in = (uint32_t)sel3(src, (int32_t)r0, (int32_t)r1, (int32_t)r2);
+    return (src == 3 ? 0u : in) + (uint32_t)v;
 }
 
-// copy n (<= 64) bytes with 8-byte accesses and an exact 4/2/1 tail; all loads are issued before the stores.
-// The two halves are separate so that several copies can have their loads in flight together.
-struct ShortRegs { uint64_t v[8]; uint32_t t4, t2, t1; };
-template <class LD>
-__device__ __forceinline__ void short_load(uint32_t n, LD ld, ShortRegs& r) {
-    const uint32_t q = n >> 3;
-#pragma unroll
-    for (uint32_t j = 0; j < 8; j++) r.v[j] = j < q ? ld.u64(j * 8) : 0;
-    const uint32_t t = q * 8;
-    r.t4 = 0; r.t2 = 0; r.t1 = 0;
-    if (n & 4) r.t4 = ld.u32(t);
-    if (n & 2) r.t2 = ld.u16(t + (n & 4));
-    if (n & 1) r.t1 = ld.u8(t + (n & 6));
-}
-template <class ST>
-__device__ __forceinline__ void short_store(uint32_t n, ST st, const ShortRegs& r) {
-    const uint32_t q = n >> 3;
-#pragma unroll
-    for (uint32_t j = 0; j < 8; j++) if (j < q) st.u64(j * 8, r.v[j]);
-    const uint32_t t = q * 8;
-    if (n & 4) st.u32(t, r.t4);
-    if (n & 2) st.u16(t + (n & 4), r.t2);
-    if (n & 1) st.u8(t + (n & 6), r.t1);
-}
-template <class LD, class ST>
-__device__ __forceinline__ void copy_short(uint32_t n, LD ld, ST st) {
-    ShortRegs r;
-    short_load(n, ld, r);
-    short_store(n, st, r);
-}
+// Per-lane copies of n (<= 64) bytes, 8 bytes at a time plus one (over-reading) 8-byte tail word stored
+// as exact 4/2/1 pieces.  On a SIMD machine every step costs issue slots whether or not a lane takes
+// part, so the chunk loops stop at the longest copy in the wavefront (wave-uniform `__any` exits:
+// typical matches are 4..24 bytes, typical literal runs 0..8).  Loads and stores are separate halves so
+// that a run's HBM loads can be issued a whole pipeline step before they are needed.  All sources may be
+// read up to 7 bytes past their end (LDS: always in bounds; literals and frame bytes: padded buffers).
+typedef const __attribute__((address_space(1))) uint8_t* gcptr;
 struct GlobalLd {
     const uint8_t* p;
-    __device__ __forceinline__ uint64_t u64(uint32_t o) const { uint64_t v; __builtin_memcpy(&v, p + o, 8); return v; }
-    __device__ __forceinline__ uint32_t u32(uint32_t o) const { uint32_t v; __builtin_memcpy(&v, p + o, 4); return v; }
-    __device__ __forceinline__ uint32_t u16(uint32_t o) const { uint16_t v; __builtin_memcpy(&v, p + o, 2); return v; }
-    __device__ __forceinline__ uint32_t u8(uint32_t o) const { return p[o]; }
+    __device__ __forceinline__ uint64_t u64(uint32_t o) const { uint64_t v; __builtin_memcpy(&v, (gcptr)(p + o), 8); return v; }
 };
 struct LdsLd {
     const uint8_t* p;
     __device__ __forceinline__ uint64_t u64(uint32_t o) const { uint64_t v; __builtin_memcpy(&v, p + o, 8); return v; }
-    __device__ __forceinline__ uint32_t u32(uint32_t o) const { uint32_t v; __builtin_memcpy(&v, p + o, 4); return v; }
-    __device__ __forceinline__ uint32_t u16(uint32_t o) const { uint16_t v; __builtin_memcpy(&v, p + o, 2); return v; }
-    __device__ __forceinline__ uint32_t u8(uint32_t o) const { return p[o]; }
 };
 struct LdsSt {
     uint8_t* p;
@@ -940,6 +917,35 @@ struct LdsSt {
     __device__ __forceinline__ void u16(uint32_t o, uint32_t v) const { uint16_t w = (uint16_t)v; __builtin_memcpy(p + o, &w, 2); }
     __device__ __forceinline__ void u8(uint32_t o, uint32_t v) const { p[o] = (uint8_t)v; }
 };
+template <int NQ> struct CopyRegs { uint64_t v[NQ]; uint64_t tl; }; // NQ full 8-byte chunks + the tail word
+template <int NQ, class LD>
+__device__ __forceinline__ void regs_load(uint32_t n, LD ld, CopyRegs<NQ>& r) { // n <= 8 * NQ + 7; n = 0 on idle lanes
+    const uint32_t q = n >> 3;
+#pragma unroll
+    for (uint32_t j = 0; j < (uint32_t)NQ; j++) {
+        if (!__any(j < q)) break;
+        if (j < q) r.v[j] = ld.u64(j * 8);
+    }
+    if (n & 7) r.tl = ld.u64(q * 8);
+}
+template <int NQ, class ST>
+__device__ __forceinline__ void regs_store(uint32_t n, ST st, const CopyRegs<NQ>& r) {
+    const uint32_t q = n >> 3, t = q * 8;
+#pragma unroll
+    for (uint32_t j = 0; j < (uint32_t)NQ; j++) {
+        if (!__any(j < q)) break;
+        if (j < q) st.u64(j * 8, r.v[j]);
+    }
+    if (n & 4) st.u32(t, (uint32_t)r.tl);
+    if (n & 2) st.u16(t + (n & 4), (uint32_t)(r.tl >> ((n & 4) * 8)));
+    if (n & 1) st.u8(t + (n & 6), (uint32_t)(r.tl >> ((n & 6) * 8)));
+}
+template <class LD, class ST>
+__device__ __forceinline__ void copy_short(uint32_t n, LD ld, ST st) { // n <= 64 (n == 64: eight chunks, no tail)
+    CopyRegs<8> r;
+    regs_load<8>(n, ld, r);
+    regs_store<8>(n, st, r);
+}
 
 constexpr uint32_t kPlanFin = 0x80000000u;
 
@@ -1080,6 +1086,8 @@ struct CopyCtx {
     uint32_t dict_len;
     const uint8_t* lit;      // literal buffer of the block
     uint32_t nlit;
+    uint64_t cap;            // capacity of dst
+    uint32_t lit_streams;    // Huffman streams the literals arrive in (0: all literals are there from the start)
 };
 
 // The copying half of K5, by one wavefront.  It publishes the finished output position in S.c.exec_pos
@@ -1100,14 +1108,15 @@ struct CopyCtx {
 struct RunRegs { // one lane's share of a prepared run
     uint32_t ll, ml, off, rel_out;  // ll = ml = 0 on lanes outside the run
     int32_t rel_src;                // match source relative to the run start
-    uint32_t kind;                  // 0 none, 1 rounds, 2 previous run, 3 run before that, 4 HBM (prefetched), 5 HBM (big, loaded at finish)
-    uint32_t srcpos;                // kind 2/3: byte offset inside that staging buffer
-    uint64_t l0, l1, l2, h0, h1, h2;
-    uint32_t lt4, lt2, lt1, ht4, ht2, ht1;
+    uint32_t kind;                  // 0 none, 1 LDS (this run or the two before it), 4 HBM (prefetched), 5 HBM (> 31 bytes, loaded at finish)
+    uint32_t src_lds;               // kind 1, plain copy: byte offset of the source inside S.stage
+    int32_t ready_at;               // kind 1: run-relative output position that must be complete first (INT32_MIN: nothing)
+    bool bytewise;                  // kind 1: overlapping match or a source that straddles buffers: byte by byte
+    CopyRegs<3> lit, old;           // prefetched literals / old match bytes (<= 31 each)
     uint32_t my_lit;
 };
 struct RunInfo { // wave-uniform
-    uint64_t run_pos; uint32_t T, buf; bool bigl; uint32_t nlmax;
+    uint64_t run_pos; uint32_t T, buf; bool bigl;
     bool v1, v2; uint32_t T1, T2, buf1, buf2; // the two runs before it
 };
 
@@ -1117,6 +1126,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     const uint8_t* const lit = cx.lit;
     uint64_t opos = *opos_io;
     uint32_t lpos = 0;
+    CSTAMP_DECL;
     auto wait_plan = [&](uint32_t nchunks_needed) -> bool { // true when that many chunks are planned
         uint32_t pg = 0;
         for (uint32_t it = 0; it < (1u << 24); it++) {
@@ -1127,7 +1137,22 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return (pg & ~kPlanFin) >= nchunks_needed;
     };
-    auto stagebuf = [&](uint32_t k) -> uint8_t* { return S.stage + k * (kStage + 16); };
+    // literals become available stream by stream (in order: stream k fills [s_out[k], s_out[k] + s_n[k]))
+    uint32_t lit_avail = cx.lit_streams ? 0u : cx.nlit;
+    auto wait_lits = [&](uint32_t need) -> bool {
+        if (need <= lit_avail) return true;
+        for (uint32_t it = 0; it < (1u << 24); it++) {
+            const uint32_t m = flag_load(&S.c.streams_mask);
+            const uint32_t k = (uint32_t)__builtin_ctz(~m); // first stream not decoded yet
+            lit_avail = k >= cx.lit_streams ? cx.nlit : S.c.s_out[k];
+            if (need <= lit_avail) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
+            if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return false;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        return false;
+    };
+    constexpr uint32_t kBufStride = kStage + 16;
+    auto stagebuf = [&](uint32_t k) -> uint8_t* { return S.stage + k * kBufStride; };
     const uint32_t nchunks = (nseq + 63) / 64;
 
     // history: the two staged runs before the one being prepared (h1 most recent)
@@ -1136,73 +1161,54 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     RunRegs R;  RunInfo RI;  bool haveR = false; // the prepared, unfinished run
     R.ll = R.ml = 0; R.kind = 0;
 
-    // finish a prepared run: LDS stores of the prefetched bytes, LDS -> LDS copies, rounds, flush
+    // finish a prepared run: LDS stores of the prefetched bytes, LDS -> LDS copies in rounds, flush
     auto finish = [&](RunRegs& r, const RunInfo& ri) {
         uint8_t* const sb = stagebuf(ri.buf);
         const uint8_t* const b1 = stagebuf(ri.buf1);
         const uint8_t* const b2 = stagebuf(ri.buf2);
-        { // literals
-            const LdsSt sl{sb + r.rel_out};
-            if (ri.bigl) { if (r.ll) copy_short(r.ll, GlobalLd{lit + r.my_lit}, sl); }
-            else if (ri.nlmax) {
-                const uint32_t q = r.ll >> 3, t = q * 8;
-                if (q > 0) sl.u64(0, r.l0);
-                if (q > 1) sl.u64(8, r.l1);
-                if (q > 2) sl.u64(16, r.l2);
-                if (r.ll & 4) sl.u32(t, r.lt4);
-                if (r.ll & 2) sl.u16(t + (r.ll & 4), r.lt2);
-                if (r.ll & 1) sl.u8(t + (r.ll & 6), r.lt1);
-            }
-        }
+        CSTAMP(2);
         const uint32_t rel_m = r.rel_out + r.ll;
-        { // old matches: prefetched from HBM, or from the two previous runs' buffers
-            const LdsSt sh{sb + rel_m};
-            if (r.kind == 4) {
-                const uint32_t q = r.ml >> 3, t = q * 8;
-                if (q > 0) sh.u64(0, r.h0);
-                if (q > 1) sh.u64(8, r.h1);
-                if (q > 2) sh.u64(16, r.h2);
-                if (r.ml & 4) sh.u32(t, r.ht4);
-                if (r.ml & 2) sh.u16(t + (r.ml & 4), r.ht2);
-                if (r.ml & 1) sh.u8(t + (r.ml & 6), r.ht1);
-            }
-            if (__any(r.kind == 5)) { if (r.kind == 5) copy_short(r.ml, GlobalLd{dst + ri.run_pos + r.rel_src}, sh); }
-            if (__any(r.kind == 2 || r.kind == 3)) {
-                if (r.kind == 2) copy_short(r.ml, LdsLd{b1 + r.srcpos}, sh);
-                if (r.kind == 3) copy_short(r.ml, LdsLd{b2 + r.srcpos}, sh);
-            }
-        }
-        // the rest in rounds, LDS -> LDS
+        // literals and old matches: prefetched from HBM a pipeline step ago
+        if (ri.bigl) copy_short(r.ll, GlobalLd{lit + r.my_lit}, LdsSt{sb + r.rel_out});
+        else regs_store<3>(r.ll, LdsSt{sb + r.rel_out}, r.lit);
+        regs_store<3>(r.kind == 4 ? r.ml : 0u, LdsSt{sb + rel_m}, r.old);
+        CSTAMP(3);
+        if (__any(r.kind == 5)) copy_short(r.kind == 5 ? r.ml : 0u, GlobalLd{dst + ri.run_pos + r.rel_src}, LdsSt{sb + rel_m});
+        CSTAMP(4);
+        // everything whose source is in LDS, in rounds: a copy may start once the output below `ready_at` is complete,
+        // and the output is complete up to the match of the first sequence that is still pending
         bool pending = r.kind == 1;
-        const uint32_t span = r.ml < r.off ? r.ml : r.off;
-        const bool plain = r.off >= r.ml;
         uint64_t pm = __ballot(pending);
         while (pm) {
             const int first = __builtin_ctzll(pm);
             const int32_t hwm = (int32_t)__builtin_amdgcn_readlane(rel_m, first);
-            const bool ready = pending && r.rel_src + (int32_t)span <= hwm;
-            const bool fast = ready && plain && r.rel_src >= 0;
-            if (__any(fast)) { if (fast) copy_short(r.ml, LdsLd{sb + r.rel_src}, LdsSt{sb + rel_m}); }
-            if (ready && !fast) { // overlapping match, or a source that straddles a boundary: byte by byte
-                uint32_t idx = 0;
-                for (uint32_t k = 0; k < r.ml; k++) {
-                    const int32_t p = r.rel_src + (int32_t)idx;
-                    const int32_t d = -p;
-                    uint8_t bv; // typed loads: hipcc 7.2 miscompiles a load through a pointer selected between HBM and LDS
-                    if (p >= 0) bv = *(const __attribute__((address_space(3))) uint8_t*)(sb + p);
-                    else if (ri.v1 && d <= (int32_t)ri.T1) bv = *(const __attribute__((address_space(3))) uint8_t*)(b1 + ((int32_t)ri.T1 - d));
-                    else if (ri.v1 && ri.v2 && d <= (int32_t)(ri.T1 + ri.T2)) bv = *(const __attribute__((address_space(3))) uint8_t*)(b2 + ((int32_t)(ri.T1 + ri.T2) - d));
-                    else bv = *(const __attribute__((address_space(1))) uint8_t*)(dst + ri.run_pos + p);
-                    sb[rel_m + k] = bv;
-                    idx++;
-                    if (idx == r.off) idx = 0;
+            const bool ready = pending && r.ready_at <= hwm;
+            const bool fast = ready && !r.bytewise;
+            copy_short(fast ? r.ml : 0u, LdsLd{S.stage + r.src_lds}, LdsSt{sb + rel_m});
+            if (__any(ready && r.bytewise)) {
+                if (ready && r.bytewise) {
+                    uint32_t idx = 0;
+                    for (uint32_t k = 0; k < r.ml; k++) {
+                        const int32_t p = r.rel_src + (int32_t)idx;
+                        const int32_t d = -p;
+                        uint8_t bv; // typed loads: hipcc 7.2 miscompiles a load through a pointer selected between HBM and LDS
+                        if (p >= 0) bv = *(const __attribute__((address_space(3))) uint8_t*)(sb + p);
+                        else if (ri.v1 && d <= (int32_t)ri.T1) bv = *(const __attribute__((address_space(3))) uint8_t*)(b1 + ((int32_t)ri.T1 - d));
+                        else if (ri.v1 && ri.v2 && d <= (int32_t)(ri.T1 + ri.T2)) bv = *(const __attribute__((address_space(3))) uint8_t*)(b2 + ((int32_t)(ri.T1 + ri.T2) - d));
+                        else bv = *(const __attribute__((address_space(1))) uint8_t*)(dst + ri.run_pos + p);
+                        sb[rel_m + k] = bv;
+                        idx++;
+                        if (idx == r.off) idx = 0;
+                    }
                 }
             }
             pending = pending && !ready;
             pm = __ballot(pending);
         }
         // flush: LDS -> HBM, 16 bytes per lane.  First wait for the previous flush (and whatever else is in flight).
+        CSTAMP(5);
         wg_fence();
+        CSTAMP(6);
         if (lane == 0) __atomic_store_n(&S.c.exec_pos, ri.run_pos, __ATOMIC_RELAXED); // everything before this run has landed
         uint8_t* g = dst + ri.run_pos;
         for (uint32_t k = (uint32_t)lane * 16; k + 16 <= ri.T; k += 1024) {
@@ -1211,6 +1217,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         }
         const uint32_t tail0 = ri.T & ~15u; // the last partial 16 bytes: one byte per lane
         if (tail0 + (uint32_t)lane < ri.T) g[tail0 + lane] = sb[tail0 + lane];
+        CSTAMP(7);
     };
 
     uint4 pe_next = make_uint4(0, 0, 0, 0);
@@ -1222,8 +1229,10 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
         const uint4 pe = pe_next; // loaded an iteration ago
+        CSTAMP(1);
         if (chunk + 1 < nchunks) { // prefetch the next chunk's plan
             if (!wait_plan(chunk + 2)) return MZD_E_CORRUPT;
+            CSTAMP(0);
             const uint32_t j = base + 64 + (uint32_t)lane;
             pe_next = j < nseq ? cx.plan[j] : make_uint4(0, 0, 0, 0);
         }
@@ -1234,6 +1243,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         const uint32_t incl_l = wave_incl_scan(ll, lane);
         const uint32_t my_lit = lpos + (incl_l - ll);
         lpos += __builtin_amdgcn_readlane(incl_l, 63);
+        if (!wait_lits(lpos)) return MZD_E_CORRUPT; // a literal stream failed (the error is posted)
         const uint64_t mdst = opos + ex_t + ll; // absolute match destination
         const bool in_dict = valid && off > mdst - cx.frame_start;
         const bool islong = valid && (ll > kShort || ml > kShort || in_dict);
@@ -1279,44 +1289,27 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             N.ll = act ? ll : 0; N.ml = act ? ml : 0; N.off = off; N.rel_out = ex_t - base_t; N.my_lit = my_lit;
             const uint32_t rel_m = N.rel_out + N.ll;
             N.rel_src = (int32_t)rel_m - (int32_t)off; // off < 2^31 (validated against the window by the planner)
-            N.kind = 0; N.srcpos = 0;
+            N.kind = 0; N.src_lds = 0; N.bytewise = false;
+            // a copy from LDS may start once the output below source start + min(ml, off) is complete
+            // (never positive for sources that lie entirely in the two previous runs)
+            N.ready_at = N.rel_src + (int32_t)(N.ml < off ? N.ml : off);
             if (N.ml) {
                 const bool plain = off >= N.ml;
-                const bool before = plain && N.rel_src + (int32_t)N.ml <= 0;
-                const int32_t pd = -N.rel_src;       // distance of the source start before the run start
-                const int32_t pe_ = pd - (int32_t)N.ml; // distance of the source end before the run start (>= 0 when `before`)
+                const int32_t pd = -N.rel_src;          // distance of the source start before the run start
+                const int32_t pe_ = pd - (int32_t)N.ml; // distance of the source end before the run start (>= 0: entirely older)
                 const int32_t lim1 = v1 ? (int32_t)T1 : 0, lim2 = lim1 + ((v1 && v2) ? (int32_t)T2 : 0);
-                if (!before) N.kind = 1;
-                else if (v1 && pd <= lim1) { N.kind = 2; N.srcpos = (uint32_t)(lim1 - pd); }
-                else if (v1 && v2 && pe_ >= lim1 && pd <= lim2) { N.kind = 3; N.srcpos = (uint32_t)(lim2 - pd); }
-                else if (pe_ >= lim2) N.kind = N.ml > 31 ? 5 : 4;
-                else N.kind = 1; // straddles a run boundary: byte path in the rounds
+                N.kind = 1;
+                if (!plain) N.bytewise = true;                                                               // overlapping: replicate byte by byte
+                else if (N.rel_src >= 0) N.src_lds = NI.buf * kBufStride + (uint32_t)N.rel_src;              // inside this run
+                else if (pe_ < 0) N.bytewise = true;                                                         // straddles the run start
+                else if (v1 && pd <= lim1) N.src_lds = NI.buf1 * kBufStride + (uint32_t)(lim1 - pd);         // inside the previous run
+                else if (v1 && v2 && pe_ >= lim1 && pd <= lim2) N.src_lds = NI.buf2 * kBufStride + (uint32_t)(lim2 - pd); // inside the run before it
+                else if (pe_ >= lim2 && run_pos - (uint64_t)pe_ + 8 <= cx.cap) N.kind = N.ml > 31 ? 5 : 4;   // older: HBM (may over-read 7 bytes)
+                else N.bytewise = true;                                                                       // straddles two buffers / ends at the buffer end
             }
-            NI.nlmax = __any(N.ll != 0) ? 1u : 0u;
             NI.bigl = __any(N.ll > 31);
-            N.l0 = N.l1 = N.l2 = N.h0 = N.h1 = N.h2 = 0; N.lt4 = N.lt2 = N.lt1 = N.ht4 = N.ht2 = N.ht1 = 0;
-            if (!NI.bigl && NI.nlmax) {
-                const GlobalLd gl{lit + my_lit};
-                const uint32_t q = N.ll >> 3, t = q * 8;
-                if (q > 0) N.l0 = gl.u64(0);
-                if (q > 1) N.l1 = gl.u64(8);
-                if (q > 2) N.l2 = gl.u64(16);
-                if (N.ll & 4) N.lt4 = gl.u32(t);
-                if (N.ll & 2) N.lt2 = gl.u16(t + (N.ll & 4));
-                if (N.ll & 1) N.lt1 = gl.u8(t + (N.ll & 6));
-            }
-            if (__any(N.kind == 4)) {
-                if (N.kind == 4) {
-                    const GlobalLd gh{dst + run_pos + N.rel_src};
-                    const uint32_t q = N.ml >> 3, t = q * 8;
-                    if (q > 0) N.h0 = gh.u64(0);
-                    if (q > 1) N.h1 = gh.u64(8);
-                    if (q > 2) N.h2 = gh.u64(16);
-                    if (N.ml & 4) N.ht4 = gh.u32(t);
-                    if (N.ml & 2) N.ht2 = gh.u16(t + (N.ml & 4));
-                    if (N.ml & 1) N.ht1 = gh.u8(t + (N.ml & 6));
-                }
-            }
+            if (!NI.bigl) regs_load<3>(N.ll, GlobalLd{lit + my_lit}, N.lit);
+            regs_load<3>(N.kind == 4 ? N.ml : 0u, GlobalLd{dst + run_pos + N.rel_src}, N.old);
             // ---- finish the run prepared one step ago while these loads are in flight
             if (haveR) finish(R, RI);
             R = N; RI = NI; haveR = true;
@@ -1339,6 +1332,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         if (cx.nlit > kBlockMax) return MZD_E_CORRUPT;
     }
     const uint32_t rest = cx.nlit - lpos;
+    if (!wait_lits(cx.nlit)) return MZD_E_CORRUPT;
     wave_copy(dst + opos, lit + lpos, rest, lane);
     opos += rest;
     wg_fence();
@@ -1363,6 +1357,9 @@ __device__ __forceinline__ uint64_t xxh_init(int lane) {
 }
 __device__ __noinline__ void xxh_advance(uint64_t& v, uint64_t& stripes, uint64_t upto, const uint8_t* p, int lane) {
     if (upto <= stripes) return;
+#ifdef MZD_EXP_NOHASH
+    stripes = upto; return;
+#endif
     if (lane < 4) {
         // the accumulator chain is serial; keep 8 stripes of loads in flight ahead of it
         const uint8_t* q = p + lane * 8;
@@ -1668,7 +1665,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     __syncthreads();
                     if (tid == 0) {
                         c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = out0;
-                        c.next_stream = 0; c.streams_done = 0;
+                        c.next_stream = 0; c.streams_done = 0; c.streams_mask = 0;
                         c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0;
                         parse_literals(S.stage, bsize);
                     }
@@ -1687,10 +1684,10 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     // K2 worker: take Huffman streams from the block's queue until none is left
                     // 2 KiB of LDS per decoding wavefront, borrowed from buffers that are idle while literals decode: the
                     // copier's staging buffers (waves 1, 2); the walker's ring (waves 0, 3: they decode after the walk)
-                    uint8_t* const hseg = wave == 1 ? S.stage + 2064 : (wave == 2 ? S.stage + 2 * 2064 : (wave == 0 ? S.ring : S.ring + 4096));
-                    auto huf_streams = [&]() {
+                    uint8_t* const hseg = wave == 1 ? S.stage + 2064 : (wave == 2 ? S.hseg2 : (wave == 0 ? S.ring : S.ring + 4096));
+                    auto huf_streams = [&](uint32_t max_take) {
                         const uint32_t hl = c.huf_log;
-                        for (;;) {
+                        for (uint32_t took = 0; took < max_take; took++) {
                             // every lane takes part (lanes != 0 add 0): no divergent region around the returning atomic
                             uint32_t st = __atomic_fetch_add(&c.next_stream, lane == 0 ? 1u : 0u, __ATOMIC_RELAXED);
                             st = (uint32_t)__builtin_amdgcn_readfirstlane(st);
@@ -1699,14 +1696,14 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             if (!__atomic_load_n(&c.err, __ATOMIC_RELAXED))
                                 r = huf_stream_wave(blk + c.s_off[st], c.s_len[st], lit_buf + c.s_out[st], c.s_n[st], hl, hseg, lane);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                            if (lane == 0) { post_err(&c.err, r); __atomic_fetch_add(&c.streams_done, 1u, __ATOMIC_RELAXED); }
+                            if (lane == 0) { post_err(&c.err, r); __atomic_fetch_or(&c.streams_mask, 1u << st, __ATOMIC_RELAXED); __atomic_fetch_add(&c.streams_done, 1u, __ATOMIC_RELAXED); }
                         }
                     };
                     // wavefronts 0 and 3 decode literals too once their own role is over (at once in a block without sequences)
                     auto huf_helper = [&]() {
                         if (lit_type < 2) return;
                         if (lit_type == 2 && !spin_ge(&c.huf_fill, 2, &c.err)) return;
-                        huf_streams();
+                        huf_streams(4);
                     };
                     // ---- the block pipeline, one role per wavefront:
                     //   wave 0  K3 tables, K4a serial state walk
@@ -1780,8 +1777,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             uint32_t w = (uint32_t)src[lit_off] * 0x01010101u;
                             for (uint32_t k = (uint32_t)(tid - 64) * 16; k < nlit; k += 128 * 16)
                                 *reinterpret_cast<uint4*>(lit_buf + k) = make_uint4(w, w, w, w); // lit_buf has slack past nlit
-                        } else if (lit_type >= 2 && !failed) { // K2
-                            huf_streams();
+                        } else if (lit_type >= 2 && !failed) { // K2: the copying wavefront decodes one stream and then starts
+                            huf_streams(wave == 1 ? 1u : 4u); // copying behind the literals; wavefront 2 (and idle ones) drain the queue
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) {
@@ -1793,8 +1790,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         if (wave == 1) { // the copying half of K5
                             uint64_t opos = out0;
                             rc = MZD_E_CORRUPT;
-                            if (spin_ge(&c.lit_done, 2, &c.err) && (lit_type < 2 || spin_ge(&c.streams_done, streams, &c.err))) {
-                                CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit, nlit};
+                            if (lit_type != 1 || spin_ge(&c.lit_done, 2, &c.err)) { // RLE literals: both halves filled
+                                CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit, nlit, cap, lit_type >= 2 ? streams : 0u};
                                 __builtin_amdgcn_s_setprio(2); // second on the critical path, behind the walker
                                 rc = copy_wave(nseq, cx, &opos, lane);
                                 __builtin_amdgcn_s_setprio(0);
@@ -1847,7 +1844,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     xxh_advance(xv, xstripes, (out_now - fout0) / 32, dst + fout0, lane);
                     uint64_t h = xxh_finish(xv, dst + fout0, out_now - fout0, lane);
                     if (lane == 0) {
+#ifndef MZD_EXP_NOHASH
                         if ((uint32_t)h != ld32(src + pos_now)) c.err = MZD_E_CHECKSUM;
+#endif
                         c.pos = pos_now + 4;
                     }
                     STAMP(7);

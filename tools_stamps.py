@@ -20,7 +20,7 @@ tot = sum(st[:8])
 print("kernel ms", mzd.last_kernel_ms(0), "files", n)
 for nm, v in zip(names, st[:8]):
     print("%-22s %10d cycles %5.1f%%" % (nm, v, 100.0 * v / max(tot, 1)))
-cn = ["wait plan", "classify/setup", "HBM lit+old loads -> LDS", "rounds LDS->LDS", "wait previous flush", "flush stores issue", "-", "-"]
+cn = ["wait plan", "loop top", "chunk setup + classify + issue HBM loads", "lit/old-match regs -> LDS (waits for the loads)", "matches from previous runs (LDS) / big (HBM)", "rounds LDS->LDS", "fence before flush", "flush"]
 print("cycles after block start: tables ready %d, literals ready %d, walker done %d, planner done %d, copier done %d, hasher done %d" % (st[21], st[20], st[16], st[19], st[17], st[18]))
 print("copier wavefront:")
 for nm, v in zip(cn, st[8:]):
