@@ -1112,11 +1112,11 @@ struct RunRegs { // one lane's share of a prepared run
     uint32_t src_lds;               // kind 1, plain copy: byte offset of the source inside S.stage
     int32_t ready_at;               // kind 1: run-relative output position that must be complete first (INT32_MIN: nothing)
     bool bytewise;                  // kind 1: overlapping match or a source that straddles buffers: byte by byte
-    CopyRegs<3> lit, old;           // prefetched literals / old match bytes (<= 31 each)
     uint32_t my_lit;
 };
 struct RunInfo { // wave-uniform
     uint64_t run_pos; uint32_t T, buf; bool bigl;
+    bool par;                                 // which of the two prefetch register sets holds this run's HBM bytes
     bool v1, v2; uint32_t T1, T2, buf1, buf2; // the two runs before it
 };
 
@@ -1160,6 +1160,10 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     uint32_t T1 = 0, T2 = 0, runno = 0;
     RunRegs R;  RunInfo RI;  bool haveR = false; // the prepared, unfinished run
     R.ll = R.ml = 0; R.kind = 0;
+    // The prefetched bytes (literals / old match bytes, <= 31 each per lane) of the run being prepared and of the
+    // run being finished live in two register sets used alternately: handing them over by assignment would
+    // wait for the loads, i.e. put the HBM latency back on the critical path.
+    CopyRegs<3> litA, oldA, litB, oldB;
 
     // finish a prepared run: LDS stores of the prefetched bytes, LDS -> LDS copies in rounds, flush
     auto finish = [&](RunRegs& r, const RunInfo& ri) {
@@ -1170,8 +1174,13 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         const uint32_t rel_m = r.rel_out + r.ll;
         // literals and old matches: prefetched from HBM a pipeline step ago
         if (ri.bigl) copy_short(r.ll, GlobalLd{lit + r.my_lit}, LdsSt{sb + r.rel_out});
-        else regs_store<3>(r.ll, LdsSt{sb + r.rel_out}, r.lit);
-        regs_store<3>(r.kind == 4 ? r.ml : 0u, LdsSt{sb + rel_m}, r.old);
+        if (ri.par) {
+            if (!ri.bigl) regs_store<3>(r.ll, LdsSt{sb + r.rel_out}, litA);
+            regs_store<3>(r.kind == 4 ? r.ml : 0u, LdsSt{sb + rel_m}, oldA);
+        } else {
+            if (!ri.bigl) regs_store<3>(r.ll, LdsSt{sb + r.rel_out}, litB);
+            regs_store<3>(r.kind == 4 ? r.ml : 0u, LdsSt{sb + rel_m}, oldB);
+        }
         CSTAMP(3);
         if (__any(r.kind == 5)) copy_short(r.kind == 5 ? r.ml : 0u, GlobalLd{dst + ri.run_pos + r.rel_src}, LdsSt{sb + rel_m});
         CSTAMP(4);
@@ -1308,8 +1317,14 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 else N.bytewise = true;                                                                       // straddles two buffers / ends at the buffer end
             }
             NI.bigl = __any(N.ll > 31);
-            if (!NI.bigl) regs_load<3>(N.ll, GlobalLd{lit + my_lit}, N.lit);
-            regs_load<3>(N.kind == 4 ? N.ml : 0u, GlobalLd{dst + run_pos + N.rel_src}, N.old);
+            NI.par = (runno & 1) != 0;
+            if (NI.par) {
+                if (!NI.bigl) regs_load<3>(N.ll, GlobalLd{lit + my_lit}, litA);
+                regs_load<3>(N.kind == 4 ? N.ml : 0u, GlobalLd{dst + run_pos + N.rel_src}, oldA);
+            } else {
+                if (!NI.bigl) regs_load<3>(N.ll, GlobalLd{lit + my_lit}, litB);
+                regs_load<3>(N.kind == 4 ? N.ml : 0u, GlobalLd{dst + run_pos + N.rel_src}, oldB);
+            }
             // ---- finish the run prepared one step ago while these loads are in flight
             if (haveR) finish(R, RI);
             R = N; RI = NI; haveR = true;
@@ -1355,25 +1370,51 @@ __device__ __forceinline__ uint64_t xmerge(uint64_t h, uint64_t v) { v = xround(
 __device__ __forceinline__ uint64_t xxh_init(int lane) {
     return lane == 0 ? XP1 + XP2 : (lane == 1 ? XP2 : (lane == 2 ? 0ull : 0ull - XP1));
 }
+// rotl by 31 as two funnel shifts ({lo,hi} >> 1 and {hi,lo} >> 1)
+__device__ __forceinline__ uint64_t rotl64_31(uint64_t x) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    return (uint64_t)__builtin_amdgcn_alignbit(lo, hi, 1) | ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 1) << 32);
+}
+__device__ __forceinline__ uint64_t xround31(uint64_t acc, uint64_t in) { acc += in * XP2; acc = rotl64_31(acc); return acc * XP1; }
 __device__ __noinline__ void xxh_advance(uint64_t& v, uint64_t& stripes, uint64_t upto, const uint8_t* p, int lane) {
     if (upto <= stripes) return;
 #ifdef MZD_EXP_NOHASH
     stripes = upto; return;
 #endif
     if (lane < 4) {
-        // the accumulator chain is serial; keep 8 stripes of loads in flight ahead of it
-        const uint8_t* q = p + lane * 8;
-        uint64_t cur[8], nxt[8];
+        // The accumulator chain is serial (two 64-bit multiplies per stripe); everything else is kept off it: groups
+        // of 8 stripes with no per-stripe bounds checks, the next group's loads in flight while the current one is
+        // absorbed, two register sets used alternately (no hand-over copies).
+        gcptr q = (gcptr)(p + lane * 8 + stripes * 32);
+        uint64_t n = upto - stripes;
+        uint64_t acc = v;
+        uint64_t A[8], B[8];
+        auto load8 = [&](uint64_t (&r)[8]) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) cur[k] = stripes + k < upto ? ldu64(q + (stripes + k) * 32) : 0;
-        for (uint64_t s = stripes; s < upto; s += 8) {
+            for (int k = 0; k < 8; k++) __builtin_memcpy(&r[k], q + k * 32, 8);
+            q += 256; n -= 8;
+        };
+        auto absorb8 = [&](const uint64_t (&r)[8]) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) nxt[k] = s + 8 + k < upto ? ldu64(q + (s + 8 + k) * 32) : 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) if (s + k < upto) v = xround(v, cur[k]);
-#pragma unroll
-            for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+            for (int k = 0; k < 8; k++) acc = xround31(acc, r[k]);
+        };
+        if (n >= 8) {
+            load8(A);
+            for (;;) {
+                if (n < 8) { absorb8(A); break; }
+                load8(B);
+                absorb8(A);
+                if (n < 8) { absorb8(B); break; }
+                load8(A);
+                absorb8(B);
+            }
         }
+        // fewer than 8 stripes left (only at the end of a frame: the follower advances in groups of 8)
+#pragma unroll
+        for (int k = 0; k < 8; k++) if ((uint64_t)k < n) __builtin_memcpy(&A[k], q + k * 32, 8);
+#pragma unroll
+        for (int k = 0; k < 8; k++) if ((uint64_t)k < n) acc = xround31(acc, A[k]);
+        v = acc;
     }
     stripes = upto;
 }
@@ -1814,7 +1855,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                                 const uint32_t fin = flag_load(&c.exec_done);
                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                                 const uint64_t pos = __atomic_load_n(&c.exec_pos, __ATOMIC_RELAXED);
-                                const uint64_t upto = (pos - c.frame_out0) / 32;
+                                uint64_t upto = (pos - c.frame_out0) / 32;
+                                if (!fin) upto = upto >= xstripes + 64 ? xstripes + ((upto - xstripes) & ~7ull) : xstripes; // >= 2 KiB at a time, whole groups of 8 stripes
                                 if (upto > xstripes) xxh_advance(xv, xstripes, upto, fp, lane);
                                 else if (fin || __atomic_load_n(&c.err, __ATOMIC_RELAXED)) break;
                                 else __builtin_amdgcn_s_sleep(8);
