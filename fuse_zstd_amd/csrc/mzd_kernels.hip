@@ -1116,7 +1116,6 @@ struct RunRegs { // one lane's share of a prepared run
 };
 struct RunInfo { // wave-uniform
     uint64_t run_pos; uint32_t T, buf; bool bigl;
-    bool par;                                 // which of the two prefetch register sets holds this run's HBM bytes
     bool v1, v2; uint32_t T1, T2, buf1, buf2; // the two runs before it
 };
 
@@ -1160,28 +1159,28 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     uint32_t T1 = 0, T2 = 0, runno = 0;
     RunRegs R;  RunInfo RI;  bool haveR = false; // the prepared, unfinished run
     R.ll = R.ml = 0; R.kind = 0;
-    // The prefetched bytes (literals / old match bytes, <= 31 each per lane) of the run being prepared and of the
-    // run being finished live in two register sets used alternately: handing them over by assignment would
-    // wait for the loads, i.e. put the HBM latency back on the critical path.
-    CopyRegs<3> litA, oldA, litB, oldB;
+    // The prefetched HBM bytes of a run (its literals and its old match bytes, <= 31 each per lane).  One set is
+    // enough: the loop stores run k's bytes to LDS (finish_regs), THEN issues run k+1's loads into the same
+    // registers, and only then does the long part of run k (rounds, flush), which hides the loads' latency.
+    // (The compiler waits with vmcnt(0) wherever the number of loads in flight depends on control flow, so
+    // nothing else may be outstanding at the point where the registers are consumed.)
+    CopyRegs<3> pfL, pfO;
 
-    // finish a prepared run: LDS stores of the prefetched bytes, LDS -> LDS copies in rounds, flush
-    auto finish = [&](RunRegs& r, const RunInfo& ri) {
+    // finishing a prepared run, part 1: the prefetched bytes (literals, old matches) go to the staging buffer
+    auto finish_regs = [&](RunRegs& r, const RunInfo& ri) {
+        uint8_t* const sb = stagebuf(ri.buf);
+        CSTAMP(2);
+        if (ri.bigl) copy_short(r.ll, GlobalLd{lit + r.my_lit}, LdsSt{sb + r.rel_out});
+        else regs_store<3>(r.ll, LdsSt{sb + r.rel_out}, pfL);
+        regs_store<3>(r.kind == 4 ? r.ml : 0u, LdsSt{sb + r.rel_out + r.ll}, pfO);
+        CSTAMP(3);
+    };
+    // part 2: LDS -> LDS copies in rounds, flush
+    auto finish_rest = [&](RunRegs& r, const RunInfo& ri) {
         uint8_t* const sb = stagebuf(ri.buf);
         const uint8_t* const b1 = stagebuf(ri.buf1);
         const uint8_t* const b2 = stagebuf(ri.buf2);
-        CSTAMP(2);
         const uint32_t rel_m = r.rel_out + r.ll;
-        // literals and old matches: prefetched from HBM a pipeline step ago
-        if (ri.bigl) copy_short(r.ll, GlobalLd{lit + r.my_lit}, LdsSt{sb + r.rel_out});
-        if (ri.par) {
-            if (!ri.bigl) regs_store<3>(r.ll, LdsSt{sb + r.rel_out}, litA);
-            regs_store<3>(r.kind == 4 ? r.ml : 0u, LdsSt{sb + rel_m}, oldA);
-        } else {
-            if (!ri.bigl) regs_store<3>(r.ll, LdsSt{sb + r.rel_out}, litB);
-            regs_store<3>(r.kind == 4 ? r.ml : 0u, LdsSt{sb + rel_m}, oldB);
-        }
-        CSTAMP(3);
         if (__any(r.kind == 5)) copy_short(r.kind == 5 ? r.ml : 0u, GlobalLd{dst + ri.run_pos + r.rel_src}, LdsSt{sb + rel_m});
         CSTAMP(4);
         // everything whose source is in LDS, in rounds: a copy may start once the output below `ready_at` is complete,
@@ -1263,7 +1262,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             const uint32_t base_t = __builtin_amdgcn_readlane(ex_t, a);
             const uint64_t run_pos = opos + base_t; // absolute output position of lane a's literals
             if ((longmask >> a) & 1) { // a long sequence: drain the pipeline, then all 64 lanes copy it straight to HBM
-                if (haveR) { finish(R, RI); haveR = false; }
+                if (haveR) { finish_regs(R, RI); finish_rest(R, RI); haveR = false; }
                 const uint32_t l = __builtin_amdgcn_readlane(ll, a), m = __builtin_amdgcn_readlane(ml, a);
                 const uint32_t o = __builtin_amdgcn_readlane(off, a), lp = __builtin_amdgcn_readlane(my_lit, a);
                 wave_copy(dst + run_pos, lit + lp, l, lane); // literals do not depend on earlier output: no fence in front
@@ -1317,23 +1316,19 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 else N.bytewise = true;                                                                       // straddles two buffers / ends at the buffer end
             }
             NI.bigl = __any(N.ll > 31);
-            NI.par = (runno & 1) != 0;
-            if (NI.par) {
-                if (!NI.bigl) regs_load<3>(N.ll, GlobalLd{lit + my_lit}, litA);
-                regs_load<3>(N.kind == 4 ? N.ml : 0u, GlobalLd{dst + run_pos + N.rel_src}, oldA);
-            } else {
-                if (!NI.bigl) regs_load<3>(N.ll, GlobalLd{lit + my_lit}, litB);
-                regs_load<3>(N.kind == 4 ? N.ml : 0u, GlobalLd{dst + run_pos + N.rel_src}, oldB);
-            }
-            // ---- finish the run prepared one step ago while these loads are in flight
-            if (haveR) finish(R, RI);
+            // ---- the previous run's prefetched bytes leave the registers; this run's loads take their place and
+            //      stay in flight during the long part of the previous run
+            if (haveR) finish_regs(R, RI);
+            if (!NI.bigl) regs_load<3>(N.ll, GlobalLd{lit + my_lit}, pfL);
+            regs_load<3>(N.kind == 4 ? N.ml : 0u, GlobalLd{dst + run_pos + N.rel_src}, pfO);
+            if (haveR) finish_rest(R, RI);
             R = N; RI = NI; haveR = true;
             v2 = v1; T2 = T1; v1 = true; T1 = NI.T; runno++;
             a = b;
         }
         opos += chunk_tot;
     }
-    if (haveR) finish(R, RI);
+    if (haveR) { finish_regs(R, RI); finish_rest(R, RI); }
     // the literals after the last sequence: the planner has validated them once it is finished
     if (nseq) {
         for (uint32_t it = 0; it < (1u << 24); it++) {
