@@ -46,7 +46,8 @@ struct DebugSlot { // what workgroup `slot` last decoded (mzd_debug_last_block)
     uint64_t lit_raw_ptr;
     uint64_t stamp[8]; // diagnostic build only (-DMZD_STAMPS): cycles per phase, summed over blocks
     uint64_t cstamp[8]; // same, for the copying wavefront
-    uint64_t tfin[6];   // -DMZD_TFIN: cycles after block start when walker / copier / hasher / planner finished, literals were ready, tables were ready
+    uint64_t tfin[12];  // (6..11: headers parsed, Huffman weights decoded, Huffman table filled, copier started, spare, spare)
+                        // -DMZD_TFIN: cycles after block start when walker / copier / hasher / planner finished, literals were ready, tables were ready
 };
 
 struct KernelArgs {

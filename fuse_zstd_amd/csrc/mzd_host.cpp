@@ -473,7 +473,7 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
     return MZD_OK;
 }
 
-// Diagnostic: tfin[6] of every workgroup slot (n_slots * 6 values); returns the slot count.
+// Diagnostic: tfin[12] of every workgroup slot (n_slots * 12 values); returns the slot count.
 int mzd_debug_tfin_all(int device, uint64_t* out, int max_slots) {
     Device* d = get_device(device);
     if (!d || !out) return MZD_E_PARAM;
@@ -482,7 +482,7 @@ int mzd_debug_tfin_all(int device, uint64_t* out, int max_slots) {
     int n = std::min<int>((int)d->max_wg, max_slots);
     std::vector<DebugSlot> all((size_t)n);
     HIPCHK(hipMemcpy(all.data(), d->debug, sizeof(DebugSlot) * (size_t)n, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; i++) for (int k = 0; k < 6; k++) out[(size_t)i * 6 + k] = all[(size_t)i].tfin[k];
+    for (int i = 0; i < n; i++) for (int k = 0; k < 12; k++) out[(size_t)i * 12 + k] = all[(size_t)i].tfin[k];
     return n;
 }
 

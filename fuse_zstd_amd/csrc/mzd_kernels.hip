@@ -35,7 +35,7 @@ namespace mzd {
 #if defined(MZD_STAMPS) || defined(MZD_TFIN)
 #define TFIN(k) do { if (lane == 0) S.tfin[k] = __builtin_readcyclecounter() - S.tstart; } while (0)
 #define TSTART() do { if (tid == 0) S.tstart = __builtin_readcyclecounter(); } while (0)
-#define TFIN_FLUSH() do { if (tid == 0 && a.debug) for (int k_ = 0; k_ < 6; k_++) a.debug[blockIdx.x].tfin[k_] = S.tfin[k_]; } while (0)
+#define TFIN_FLUSH() do { if (tid == 0 && a.debug) for (int k_ = 0; k_ < 12; k_++) a.debug[blockIdx.x].tfin[k_] = S.tfin[k_]; } while (0)
 #else
 #define TFIN(k)
 #define TSTART()
@@ -107,7 +107,7 @@ struct __attribute__((aligned(16))) Shared {
     uint64_t cdiag[8];
 #endif
 #if defined(MZD_STAMPS) || defined(MZD_TFIN)
-    uint64_t tstart, tfin[6]; // block start; finish of walker / copier / hasher / planner; literals ready; tables ready
+    uint64_t tstart, tfin[12]; // block start; finish of walker / copier / hasher / planner; literals ready; tables ready
 #endif
     uint16_t huf[2048]; // sym | len << 8
     int16_t norm[3][64];
@@ -115,7 +115,6 @@ struct __attribute__((aligned(16))) Shared {
     int16_t wnorm[256]; // FSE table of the Huffman weights
     uint32_t wtab[64];  // sym | nb << 8 | base << 16
     uint8_t weights[256];
-    uint32_t rank_start[16];
     Ctl c;
 };
 
@@ -341,65 +340,43 @@ __device__ __forceinline__ int read_huf_weights_t(LD ld, uint32_t n) {
         const uint32_t lastb = byte_at(bs + bl - 1);
         if (lastb == 0) return MZD_E_CORRUPT;
         int32_t bpos = (int32_t)(bl - 1) * 8 + hibit(lastb);
-        bpos -= (int32_t)log; uint32_t s1 = take(bs, bl, bpos, (int)log);
-        bpos -= (int32_t)log; uint32_t s2 = take(bs, bl, bpos, (int)log);
+        // the stream is read downwards a few bits at a time: a 64-bit register window, refilled every ~10 symbols
+        uint64_t win = 0; int32_t wbase = 0, wtop = 0; // window = stream bits [wbase, wtop)
+        auto bits = [&](int32_t bp, int nb) -> uint32_t { // stream bits [bp, bp + nb), nb <= 6; bits below 0 read as 0
+            if (nb == 0) return 0u;
+            if (bp < 0) return take(bs, bl, bp, nb);
+            if (bp < wbase || bp + nb > wtop) {
+                int32_t lo = bp + 16 - 64; if (lo < 0) lo = 0; // top of the window >= bp + 9 > bp + nb
+                wbase = lo & ~7; wtop = wbase + 64;
+                const uint32_t byte = (uint32_t)wbase >> 3; // < bl
+                win = ld(bs + byte);
+                const uint32_t avail = bl - byte;
+                if (avail < 8) win &= (1ull << (avail * 8)) - 1;
+            }
+            return (uint32_t)(win >> (bp - wbase)) & ((1u << nb) - 1);
+        };
+        bpos -= (int32_t)log; uint32_t s1 = bits(bpos, (int)log);
+        bpos -= (int32_t)log; uint32_t s2 = bits(bpos, (int)log);
         int ok = 0;
         for (;;) { // two interleaved states; ends when the stream is over-read
             if (nw > 253) break;
             uint32_t e = S.wtab[s1];
-            w[nw++] = (uint8_t)e; int nb = (e >> 8) & 0xFF; bpos -= nb; s1 = (e >> 16) + take(bs, bl, bpos, nb);
+            w[nw++] = (uint8_t)e; int nb = (e >> 8) & 0xFF; bpos -= nb; s1 = (e >> 16) + bits(bpos, nb);
             if (bpos < 0) { w[nw++] = (uint8_t)S.wtab[s2]; ok = 1; break; }
             if (nw > 253) break;
             e = S.wtab[s2];
-            w[nw++] = (uint8_t)e; nb = (e >> 8) & 0xFF; bpos -= nb; s2 = (e >> 16) + take(bs, bl, bpos, nb);
+            w[nw++] = (uint8_t)e; nb = (e >> 8) & 0xFF; bpos -= nb; s2 = (e >> 16) + bits(bpos, nb);
             if (bpos < 0) { w[nw++] = (uint8_t)S.wtab[s1]; ok = 1; break; }
         }
         if (!ok) return MZD_E_CORRUPT;
         used = 1 + (int)hb;
     }
-    uint32_t total = 0, rank[13];
-    for (int r = 0; r < 13; r++) rank[r] = 0;
-    for (uint32_t i = 0; i < nw; i++) {
-        uint32_t x = w[i];
-        if (x > 12) return MZD_E_CORRUPT;
-        rank[x]++;
-        if (x) total += 1u << (x - 1);
-    }
-    if (total == 0) return MZD_E_CORRUPT;
-    uint32_t maxbits = (uint32_t)hibit(total) + 1;
-    if (maxbits > 11) return MZD_E_CORRUPT;
-    uint32_t left = (1u << maxbits) - total;
-    if (left & (left - 1)) return MZD_E_CORRUPT;
-    uint32_t wl = (uint32_t)hibit(left) + 1;
-    w[nw++] = (uint8_t)wl;
-    rank[wl]++;
-    if (rank[1] < 2 || (rank[1] & 1)) return MZD_E_CORRUPT;
-    uint32_t p2 = 0;
-    for (uint32_t r = 1; r <= maxbits; r++) { S.rank_start[r] = p2; p2 += rank[r] << (r - 1); }
-    if (p2 != (1u << maxbits)) return MZD_E_CORRUPT;
-    for (uint32_t i = nw; i < 256; i++) w[i] = 0;
-    S.c.huf_nw = nw;
-    S.c.huf_log = maxbits;
+    S.c.huf_nw = nw; // the implied last weight, the validation and the table come from finish_huf_table_wave
     return used;
 }
 __device__ __noinline__ int read_huf_weights(const uint8_t* src, uint32_t n) { return read_huf_weights_t(HbmBytes{src}, n); }               // dictionary (HBM)
 __device__ __noinline__ int read_huf_weights_staged(uint32_t stage_off, uint32_t n) { return read_huf_weights_t(StageBytes{stage_off}, n); } // a block's tree, staged in LDS
 
-
-// Canonical table fill by all 256 lanes: lane s owns symbol s.
-__device__ __noinline__ void fill_huf_table(int first, int stride) {
-    for (int sym = first; sym < 256; sym += stride) {
-        uint32_t wt = S.weights[sym];
-        if (wt) {
-            uint32_t before = 0;
-            for (int s = 0; s < sym; s++) before += (S.weights[s] == wt);
-            uint32_t cnt = 1u << (wt - 1);
-            uint32_t at = S.rank_start[wt] + before * cnt;
-            uint16_t e = (uint16_t)((uint32_t)sym | ((S.c.huf_log + 1 - wt) << 8));
-            for (uint32_t i = 0; i < cnt; i++) S.huf[at + i] = e;
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------ K2
 // wave-wide inclusive scans on the DPP path (row_shr / row_bcast: no LDS traffic, no ds_bpermute latency)
@@ -410,6 +387,70 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     uint32_t r;
     WS().inclusive_scan(v, r, *st, rocprim::plus<uint32_t>());
     return r;
+}
+
+// Huffman decode table from the explicit weights S.weights[0 .. huf_nw) (A.4), by one wavefront; lane l owns
+// symbols l, l+64, l+128, l+192.  Validates the weights, derives the implied last one, and fills the canonical
+// table: weight 1 (longest codes) first, equal weights in symbol order -- positions come from ballots, not from
+// per-symbol counting loops.  Sets S.c.huf_log.  Returns 0 or MZD_E_CORRUPT.
+__device__ __noinline__ int finish_huf_table_wave(int lane) {
+    uint32_t nw = (uint32_t)__builtin_amdgcn_readfirstlane(S.c.huf_nw);
+    if (nw < 1 || nw > 255) return MZD_E_CORRUPT;
+    uint32_t w[4], tot = 0;
+    bool bad = false;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t sym = (uint32_t)g * 64 + (uint32_t)lane;
+        w[g] = sym < nw ? S.weights[sym] : 0u;
+        if (w[g] > 12) { bad = true; w[g] = 0; }
+        tot += w[g] ? 1u << (w[g] - 1) : 0u;
+    }
+    if (__any(bad)) return MZD_E_CORRUPT;
+    const uint32_t total = __builtin_amdgcn_readlane(wave_incl_scan(tot, lane), 63);
+    if (total == 0) return MZD_E_CORRUPT;
+    const uint32_t maxbits = (uint32_t)hibit(total) + 1;
+    if (maxbits > 11) return MZD_E_CORRUPT;
+    const uint32_t left = (1u << maxbits) - total;
+    if (left & (left - 1)) return MZD_E_CORRUPT;
+    const uint32_t wl = (uint32_t)hibit(left) + 1;
+#pragma unroll
+    for (int g = 0; g < 4; g++) if ((uint32_t)g * 64 + (uint32_t)lane == nw) w[g] = wl; // the implied last symbol
+    nw++;
+    const uint64_t below = (1ull << lane) - 1;
+    uint32_t at[4] = {0, 0, 0, 0}, p2 = 0;
+    for (uint32_t r = 1; r <= maxbits; r++) {
+        uint32_t cnt_r = 0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint64_t m = __ballot(w[g] == r);
+            if (w[g] == r) at[g] = p2 + ((cnt_r + (uint32_t)__builtin_popcountll(m & below)) << (r - 1));
+            cnt_r += (uint32_t)__builtin_popcountll(m);
+        }
+        if (r == 1 && (cnt_r < 2 || (cnt_r & 1))) return MZD_E_CORRUPT;
+        p2 += cnt_r << (r - 1);
+    }
+    if (p2 != (1u << maxbits)) return MZD_E_CORRUPT; // also catches weights above maxbits
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t sym = (uint32_t)g * 64 + (uint32_t)lane;
+        const uint32_t cnt = w[g] ? 1u << (w[g] - 1) : 0u;
+        const uint32_t e = sym | ((maxbits + 1 - w[g]) << 8);
+        if (cnt == 1) S.huf[at[g]] = (uint16_t)e;
+        else if (cnt && cnt < 64) { // aligned to cnt (>= 2): pairs
+            uint32_t* q = reinterpret_cast<uint32_t*>(&S.huf[at[g]]);
+            for (uint32_t i = 0; i < cnt / 2; i++) q[i] = e | (e << 16);
+        }
+        uint64_t big = __ballot(cnt >= 64); // few symbols own most of the table: all 64 lanes fill those together
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            const uint32_t a0 = __builtin_amdgcn_readlane(at[g], src), c0 = __builtin_amdgcn_readlane(cnt, src), e0 = __builtin_amdgcn_readlane(e, src);
+            uint32_t* q = reinterpret_cast<uint32_t*>(&S.huf[a0]);
+            for (uint32_t i = (uint32_t)lane; i < c0 / 2; i += 64) q[i] = e0 | (e0 << 16);
+            big &= big - 1;
+        }
+    }
+    if (lane == 0) { S.c.huf_nw = nw; S.c.huf_log = maxbits; }
+    return 0;
 }
 
 // One Huffman stream decoded by the 64 lanes of a wavefront (A.4), ~2 KiB of stream at a time:
@@ -1716,6 +1757,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     WG_SNAPSHOT(err = c.err; nseq = c.nseq; seq_off = c.seq_off; seq_len = c.seq_len);
                     if (err) break;
                     STAMP(1);
+                    if (wave == 0) TFIN(6);
                     const uint8_t* const lit = lit_type == 0 ? src + lit_off : lit_buf;
                     // K2 worker: take Huffman streams from the block's queue until none is left
                     // 2 KiB of LDS per decoding wavefront, borrowed from buffers that are idle while literals decode: the
@@ -1785,28 +1827,23 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         huf_helper(); // the ring (its staging area) is free: the walker has finished before the planner does
                     } else {
                         int rc = 0;
-                        if (lit_type == 2) { // K1: weights by one lane (from an LDS copy of the tree description), table by 128
+                        if (lit_type == 2) { // K1: the Huffman tree (from an LDS copy of its description), by wavefront 1
                             if (wave == 1) {
                                 const uint32_t tl = c.huf_tree_len; // <= 129 bytes
                                 for (uint32_t k = (uint32_t)lane; k < tl + 8; k += 64) S.stage[1024 + k] = k < tl ? blk[c.huf_tree_off + k] : 0;
                             }
-                            if (tid == 64) {
-                                int used = read_huf_weights_staged(1024, c.huf_tree_len);
-                                if (used <= 0) post_err(&c.err, MZD_E_CORRUPT);
-                                else c.huf_valid = 1;
+                            if (wave == 1) { // weights: serial (lane 0); table: the whole wavefront
+                                int used = 1;
+                                if (lane == 0) used = read_huf_weights_staged(1024, c.huf_tree_len);
+                                used = __builtin_amdgcn_readfirstlane(used);
+                                TFIN(7);
+                                int hr = used <= 0 ? MZD_E_CORRUPT : finish_huf_table_wave(lane);
+                                if (lane == 0) { if (hr) post_err(&c.err, hr); else c.huf_valid = 1; }
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                                flag_store(&c.huf_ready, 1);
-#ifdef MZD_STAMPS
-                                S.cdiag[0] = __builtin_readcyclecounter() - S.tstart; // diagnostic: weights decoded
-#endif
+                                if (lane == 0) flag_store(&c.huf_fill, 2);
+                                TFIN(8);
                             }
-                            if (spin_ge(&c.huf_ready, 1, &c.err)) fill_huf_table(tid - 64, 128);
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                            if (lane == 0) __atomic_fetch_add(&c.huf_fill, 1u, __ATOMIC_RELAXED);
                             spin_ge(&c.huf_fill, 2, &c.err);
-#ifdef MZD_STAMPS
-                            if (tid == 64) S.cdiag[1] = __builtin_readcyclecounter() - S.tstart; // diagnostic: table filled
-#endif
                         }
                         const bool failed = __atomic_load_n(&c.err, __ATOMIC_RELAXED) != 0;
                         if (lit_type == 1) { // RLE literals
@@ -1828,6 +1865,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             rc = MZD_E_CORRUPT;
                             if (lit_type != 1 || spin_ge(&c.lit_done, 2, &c.err)) { // RLE literals: both halves filled
                                 CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit, nlit, cap, lit_type >= 2 ? streams : 0u};
+                                TFIN(9);
                                 __builtin_amdgcn_s_setprio(2); // second on the critical path, behind the walker
                                 rc = copy_wave(nseq, cx, &opos, lane);
                                 __builtin_amdgcn_s_setprio(0);
@@ -1924,8 +1962,9 @@ __global__ __launch_bounds__(kWG) void mzd_dict_kernel(const uint8_t* dict, uint
         return;
     }
     if (c.err) { if (tid == 0) *status = c.err; return; }
-    fill_huf_table(tid, kWG);
+    if (wave == 0) { int hr = finish_huf_table_wave(lane); if (hr && lane == 0) c.err = MZD_E_DICT; }
     __syncthreads();
+    if (c.err) { if (tid == 0) *status = c.err; return; }
     if (tid == 0) {
         const uint8_t* p = dict + pos_after_huf;
         const uint8_t* end = dict + n;

@@ -27,11 +27,11 @@ for nm, v in zip(cn, st[8:]):
     print("   %-26s %10d cycles" % (nm, v))
 
 import numpy as np
-buf = (C.c_uint64 * (6 * 2048))()
+buf = (C.c_uint64 * (12 * 2048))()
 ns = api.lib().mzd_debug_tfin_all(0, buf, 2048)
 if ns > 0:
-    arr = np.frombuffer(buf, dtype=np.uint64)[: ns * 6].reshape(ns, 6).astype(np.float64)
+    arr = np.frombuffer(buf, dtype=np.uint64)[: ns * 12].reshape(ns, 12).astype(np.float64)
     arr = arr[arr[:, 0] > 0][: n]
     if len(arr):
-        names6 = ["walker done", "copier done", "hasher done", "planner done", "literals ready", "tables ready"]
+        names6 = ["walker done", "copier done", "hasher done", "planner done", "first literal stream done (copier wave)", "tables ready", "headers parsed", "Huffman weights decoded", "Huffman table filled", "copier started"]
         print("over %d workgroups (cycles after block start): " % len(arr) + "; ".join("%s mean %.0fK max %.0fK" % (nm, arr[:, k].mean() / 1e3, arr[:, k].max() / 1e3) for k, nm in enumerate(names6)))
