@@ -84,6 +84,7 @@ struct Ctl {
     uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
     uint32_t next_stream, streams_done, streams_mask; // Huffman streams are handed out to whichever wavefront is free; mask: bit k = stream k decoded
     uint32_t tables_ready, plan_prog, copy_prog, plan_lit_used; // walker -> planner -> copier
+    uint32_t seq_parsed;                           // the sequence header is parsed: nseq, seq_off, seq_len, modes are final
     uint32_t exec_done;                            // the copying wavefront has finished the block
     uint64_t exec_pos;                             // output bytes complete and visible (published by the executor)
     uint32_t diag_slow;                            // diagnostic build: walker iterations that needed a lower window
@@ -315,7 +316,7 @@ __device__ __forceinline__ int read_huf_weights_t(LD ld, uint32_t n) {
         if (hdr <= 0) return MZD_E_CORRUPT;
         // tiny FSE table (<= 64 entries) built in place
         uint32_t size = 1u << log, high = size;
-        uint16_t* next = (uint16_t*)(void*)S.stage; // the copier's staging buffer is idle until the literals exist
+        uint16_t* next = (uint16_t*)(void*)(S.stage + 1536); // the copier's staging buffer is idle until the literals exist ([256, 512) holds the sequence header, [1024, 1161) the tree)
         for (uint32_t s = 0; s < nsym; s++)
             if (S.wnorm[s] == -1) { high--; S.wtab[high] = s; next[s] = 1; }
         uint32_t step = (size >> 1) + (size >> 3) + 3, pos = 0, mask = size - 1;
@@ -1592,36 +1593,37 @@ __device__ __noinline__ void parse_literals(const uint8_t* b, uint32_t n) {
     c.seq_len = n - hs - comp;
 }
 
-// sequences section header: nbSeq, modes, table descriptions.  Lane 0.
+// sequences section header: nbSeq, modes, table descriptions.  Lane 0 of the walking wavefront, while other
+// wavefronts already work on the literals (errors are posted first-wins).
 __device__ __noinline__ void parse_seq_header(const uint8_t* b, uint32_t n) {
     Ctl& c = S.c;
-    if (n < 1) { c.err = MZD_E_CORRUPT; return; }
+    if (n < 1) { post_err(&c.err, MZD_E_CORRUPT); return; }
     const uint8_t* p = b;
     const uint8_t* end = b + n;
     uint32_t nseq = *p++;
     if (nseq > 0x7F) {
-        if (nseq == 0xFF) { if (p + 2 > end) { c.err = MZD_E_CORRUPT; return; } nseq = ld16(p) + 0x7F00; p += 2; }
-        else { if (p + 1 > end) { c.err = MZD_E_CORRUPT; return; } nseq = ((nseq - 0x80) << 8) + *p++; }
+        if (nseq == 0xFF) { if (p + 2 > end) { post_err(&c.err, MZD_E_CORRUPT); return; } nseq = ld16(p) + 0x7F00; p += 2; }
+        else { if (p + 1 > end) { post_err(&c.err, MZD_E_CORRUPT); return; } nseq = ((nseq - 0x80) << 8) + *p++; }
     }
     c.nseq = nseq;
-    if (nseq == 0) { if (p != end) c.err = MZD_E_CORRUPT; return; }
-    if (nseq > kMaxSeq - 1 || p + 1 > end) { c.err = MZD_E_CORRUPT; return; }
+    if (nseq == 0) { if (p != end) post_err(&c.err, MZD_E_CORRUPT); return; }
+    if (nseq > kMaxSeq - 1 || p + 1 > end) { post_err(&c.err, MZD_E_CORRUPT); return; }
     uint32_t modes = *p++;
-    if (modes & 3) { c.err = MZD_E_CORRUPT; return; }
+    if (modes & 3) { post_err(&c.err, MZD_E_CORRUPT); return; }
     c.mode[0] = modes >> 6; c.mode[1] = (modes >> 4) & 3; c.mode[2] = (modes >> 2) & 3;
     const int max_log[3] = {9, 8, 9}, max_sym[3] = {35, 31, 52};
     for (int t = 0; t < 3; t++) {
         uint32_t m = c.mode[t];
         if (m == 1) {
-            if (p + 1 > end || *p > max_sym[t]) { c.err = MZD_E_CORRUPT; return; }
+            if (p + 1 > end || *p > max_sym[t]) { post_err(&c.err, MZD_E_CORRUPT); return; }
             c.nsym[t] = *p++; // the symbol itself
         } else if (m == 2) {
             // the header was staged at S.stage + 256 by the caller
             int used = read_ncount_staged(256 + (uint32_t)(p - b), (uint32_t)(end - p), max_log[t], max_sym[t], S.norm[t], &c.nsym[t], &c.al[t]);
-            if (used <= 0) { c.err = MZD_E_CORRUPT; return; }
+            if (used <= 0) { post_err(&c.err, MZD_E_CORRUPT); return; }
             p += used;
         } else if (m == 3) {
-            if (!c.fse_valid) { c.err = MZD_E_CORRUPT; return; }
+            if (!c.fse_valid) { post_err(&c.err, MZD_E_CORRUPT); return; }
         }
     }
     c.seq_off += (uint64_t)(p - b);
@@ -1743,7 +1745,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     if (tid == 0) {
                         c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = out0;
                         c.next_stream = 0; c.streams_done = 0; c.streams_mask = 0;
-                        c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0;
+                        c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.seq_parsed = 0;
                         parse_literals(S.stage, bsize);
                     }
                     uint32_t lit_type = 0, nlit = 0, streams = 0, nseq = 0, seq_len = 0;
@@ -1753,11 +1755,14 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     if (err) break;
                     for (uint32_t k = tid; k < seq_len && k < 256; k += kWG) S.stage[256 + k] = src[seq_off + k];
                     __syncthreads();
-                    if (tid == 0) parse_seq_header(S.stage + 256, seq_len);
-                    WG_SNAPSHOT(err = c.err; nseq = c.nseq; seq_off = c.seq_off; seq_len = c.seq_len);
-                    if (err) break;
                     STAMP(1);
-                    if (wave == 0) TFIN(6);
+                    // The sequence header (three normalized-count descriptions: a serial bit parse) is read by lane 0 of
+                    // the walking wavefront INSIDE the pipeline, so the literal side (Huffman tree, streams) starts at once.
+                    auto get_seq = [&]() -> bool { // nseq / seq_off / seq_len once the header is parsed; false: the block failed
+                        if (!spin_ge(&c.seq_parsed, 1, &c.err) || __atomic_load_n(&c.err, __ATOMIC_RELAXED)) return false;
+                        nseq = c.nseq; seq_off = c.seq_off; seq_len = c.seq_len;
+                        return true;
+                    };
                     const uint8_t* const lit = lit_type == 0 ? src + lit_off : lit_buf;
                     // K2 worker: take Huffman streams from the block's queue until none is left
                     // 2 KiB of LDS per decoding wavefront, borrowed from buffers that are idle while literals decode: the
@@ -1789,7 +1794,11 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     //   wave 2  K2 literals (streams 2,3), then K7 hashing behind the copier
                     //   wave 3  K4b field conversion + repeat offsets + positions (the plan), behind the walker
                     if (wave == 0) {
-                        if (nseq) {
+                        if (lane == 0) parse_seq_header(S.stage + 256, seq_len);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) flag_store(&c.seq_parsed, 1);
+                        TFIN(6);
+                        if (get_seq() && nseq) {
                             build_tables_wave(lane);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) flag_store(&c.tables_ready, 1);
@@ -1809,7 +1818,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         }
                         huf_helper();
                     } else if (wave == 3) {
-                        if (nseq) {
+                        if (get_seq() && nseq) {
                             int rc = MZD_E_CORRUPT;
                             if (spin_ge(&c.tables_ready, 1, &c.err)) {
                                 PlanCtx px{walk, src + seq_off, &c.walk_prog, c.frame_out0, cap, c.dict_content_len, nlit};
@@ -1863,7 +1872,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         if (wave == 1) { // the copying half of K5
                             uint64_t opos = out0;
                             rc = MZD_E_CORRUPT;
-                            if (lit_type != 1 || spin_ge(&c.lit_done, 2, &c.err)) { // RLE literals: both halves filled
+                            if (get_seq() && (lit_type != 1 || spin_ge(&c.lit_done, 2, &c.err))) { // RLE literals: both halves filled
                                 CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit, nlit, cap, lit_type >= 2 ? streams : 0u};
                                 TFIN(9);
                                 __builtin_amdgcn_s_setprio(2); // second on the critical path, behind the walker
