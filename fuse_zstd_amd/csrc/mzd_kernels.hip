@@ -188,14 +188,21 @@ template <class LD>
 __device__ __forceinline__ int read_ncount_t(LD ld, uint32_t n, int max_log, int max_sym, int16_t* norm, uint32_t* nsym_out, uint32_t* log_out) {
     if (n < 1) return MZD_E_CORRUPT;
     const int32_t limit = (int32_t)(n > 4096 ? 4096 : n) * 8;
-    // bits [bit, bit+nb) of the header, zero past its end; nb <= 16
+    // bits [bit, bit+nb) of the header, zero past its end; nb <= 16.  The header is read upwards a few bits at a
+    // time: a 64-bit register window, refilled every ~6 symbols (a lone lane pays ~60 cycles per LDS/HBM read).
+    uint64_t win = 0; int32_t wbase = 0, wtop = 0; // window = header bits [wbase, wtop)
     auto take = [&](int32_t bit, int nb) -> int {
-        uint32_t byte = (uint32_t)bit >> 3;
-        if (byte >= n) return 0;
-        uint64_t v = ld(byte);
-        uint32_t avail = n - byte;
-        if (avail < 8) v &= (1ull << (avail * 8)) - 1;
-        return (int)((v >> (bit & 7)) & ((1u << nb) - 1));
+        if (bit < wbase || bit + nb > wtop) {
+            const uint32_t byte = (uint32_t)bit >> 3;
+            wbase = (int32_t)(byte * 8); wtop = wbase + 64;
+            win = 0;
+            if (byte < n) {
+                win = ld(byte);
+                const uint32_t avail = n - byte;
+                if (avail < 8) win &= (1ull << (avail * 8)) - 1;
+            }
+        }
+        return (int)((win >> (bit - wbase)) & ((1u << nb) - 1));
     };
     int32_t bit = 0;
     int al = 5 + take(bit, 4);
