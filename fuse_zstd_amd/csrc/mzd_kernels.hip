@@ -34,10 +34,12 @@ namespace mzd {
 
 #if defined(MZD_STAMPS) || defined(MZD_TFIN)
 #define TFIN(k) do { if (lane == 0) S.tfin[k] = __builtin_readcyclecounter() - S.tstart; } while (0)
-#define TSTART() do { if (tid == 0) S.tstart = __builtin_readcyclecounter(); } while (0)
+#define TSTART() do { if (tid == 0) { S.tstart = __builtin_readcyclecounter(); S.tfin[10] = 0; S.tfin[11] = 0; } } while (0)
+#define TCOUNT(k, v) do { if (lane == 0) atomicAdd((unsigned long long*)&S.tfin[k], (unsigned long long)(v)); } while (0)
 #define TFIN_FLUSH() do { if (tid == 0 && a.debug) for (int k_ = 0; k_ < 12; k_++) a.debug[blockIdx.x].tfin[k_] = S.tfin[k_]; } while (0)
 #else
 #define TFIN(k)
+#define TCOUNT(k, v)
 #define TSTART()
 #define TFIN_FLUSH()
 #endif
@@ -464,10 +466,14 @@ __device__ __noinline__ int finish_huf_table_wave(int lane) {
 // One Huffman stream decoded by the 64 lanes of a wavefront (A.4), ~2 KiB of stream at a time:
 //   * the segment is staged in LDS with coalesced 16-byte loads (`seg`, 2 KiB + 64 bytes, private to the wavefront);
 //   * lane k starts at bit k*C of the segment (a guess for k > 0); lanes then re-start from their
-//     predecessor's exit position until the chain is consistent (Huffman codes self-synchronise, so this
-//     takes a round or two); lane 0's start is exact: it is where the previous segment ended;
+//     predecessor's exit position until the chain is consistent.  Text-like codes self-synchronise within a
+//     few symbols, so that takes a round or two.  Near-flat codes (noisy samples, already-compressed bytes)
+//     do not: there the truth travels one lane per round -- but a lane can only ever be entered at one of
+//     L bit offsets (a code word straddles its lower boundary by < L bits), so every lane keeps the
+//     results of the offsets it has already walked (12 bits each) and a round normally costs a shuffle and a
+//     lookup, not a walk;
 //   * a DPP scan of the symbol counts gives the output offsets, and a last pass writes.
-// Every lane reads through a 64-bit register window refilled a dword at a time from LDS.
+// A walk reads the stream through a 64-bit window loaded once per five symbols (5 * 11 bits <= 57).
 constexpr int32_t kSegBits = 64 * 248; // 31 bytes per lane: lane windows fall into different LDS banks
 
 __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int lane) {
@@ -481,66 +487,97 @@ __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint
     uint32_t done = 0;      // symbols written so far
     while (pos < nbits) {
         const int32_t s0 = pos, s1 = pos + kSegBits < nbits ? pos + kSegBits : nbits;
-        // stage stream bytes [blo, bhi): everything the segment can touch (16 bits of slack below it)
-        int32_t lowbit = nbits - s1 - 16;
-        const uint32_t blo = lowbit > 0 ? ((uint32_t)lowbit >> 3) & ~3u : 0u;
+        // stage stream bytes [blo - 16, bhi): everything the segment can touch (16 bits of slack below it) behind a
+        // 16-byte prefix, so that a window may start up to 8 bytes below the lowest byte needed; bytes below the
+        // stream start read as zero (bits below bit 0 of a backward stream are zero)
+        const int32_t lowbit = nbits - s1 - 16;
+        const uint32_t blo = lowbit > 0 ? ((uint32_t)lowbit >> 3) & ~15u : 0u;
         const uint32_t bhi = (uint32_t)((nbits - s0) + 7) >> 3; // <= sl
-        for (uint32_t o = (uint32_t)lane * 16; blo + o < bhi; o += 1024) {
-            uint4 v;
-            __builtin_memcpy(&v, sp + blo + o, 16); // may over-read <= 15 bytes past the stream (input padding)
+        for (uint32_t o = (uint32_t)lane * 16; o < bhi - blo + 16; o += 1024) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (blo + o >= 16) __builtin_memcpy(&v, sp + (blo + o - 16), 16); // may over-read <= 15 bytes past the stream (input padding)
             *reinterpret_cast<uint4*>(seg + o) = v;
         }
+        const uint8_t* const seg0 = seg + 16 - blo; // seg0 + j = stream byte j
         int32_t C = (s1 - s0 + 63) / 64;
         if (C < 32) C = 32;
         int32_t q0 = s0 + lane * C, q1 = q0 + C;
         if (q0 > s1) q0 = s1;
         if (q1 > s1) q1 = s1;
         if (lane == 63) q1 = s1;
-        // stream dword d (bits [32d, 32d+32)); below the stream start everything reads as zero
-        auto dword = [&](int32_t d) -> uint32_t {
-            if (d < 0) return 0u;
-            uint32_t v;
-            __builtin_memcpy(&v, seg + ((uint32_t)d * 4 - blo), 4);
-            return v;
-        };
+        const int32_t lim = nbits - q1;
+        // decode from stream position `from` until the lane's upper boundary; returns the exit position
         auto walk = [&](int32_t from, uint32_t& cnt, uint8_t* dst) -> int32_t {
             int32_t rem = nbits - from; // bits below the read point
-            const int32_t lim = nbits - q1;
-            int32_t wb = (rem - (int32_t)L) & ~31; // <= rem - L, may be negative
-            uint32_t hi = dword((wb >> 5) + 1), lo = dword(wb >> 5), nx = dword((wb >> 5) - 1);
             uint32_t c = 0;
             uint64_t acc = 0; // the write pass packs 8 symbols per HBM store (byte stores cost a sector write each)
             while (rem > lim) {
-                const uint64_t W = ((uint64_t)hi << 32) | lo;
-                const uint32_t e = tab[(uint32_t)(W >> (uint32_t)(rem - (int32_t)L - wb)) & mask];
-                const uint32_t l = e >> 8;
-                if (dst) {
-                    acc |= (uint64_t)(e & 0xFF) << ((c & 7) * 8);
-                    if ((c & 7) == 7) { __builtin_memcpy(dst + (c & ~7u), &acc, 8); acc = 0; }
-                }
-                c++;
-                rem -= (int32_t)(l ? l : 1u);
-                if (rem - (int32_t)L < wb) { // slide the window down one dword
-                    hi = lo; lo = nx; wb -= 32;
-                    nx = dword((wb >> 5) - 1);
+                const int32_t bi = (rem - 57) >> 3; // window = stream bytes [bi, bi + 8): the 57..64 bits below the read point
+                uint64_t W;
+                __builtin_memcpy(&W, seg0 + bi, 8);
+                int32_t h = rem - bi * 8;           // read point inside the window
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const bool act = rem > lim;
+                    const uint32_t e = tab[(uint32_t)(W >> (uint32_t)(h - (int32_t)L)) & mask];
+                    uint32_t l = e >> 8;
+                    l = l ? l : 1u;
+                    if (dst && act) {
+                        acc |= (uint64_t)(e & 0xFF) << ((c & 7) * 8);
+                        if ((c & 7) == 7) { __builtin_memcpy(dst + (c & ~7u), &acc, 8); acc = 0; }
+                    }
+                    l = act ? l : 0u;
+                    c += act ? 1u : 0u;
+                    h -= (int32_t)l;
+                    rem -= (int32_t)l;
                 }
             }
             if (dst) for (uint32_t k = c & ~7u; k < c; k++) { dst[k] = (uint8_t)acc; acc >>= 8; }
             cnt = c;
             return nbits - rem;
         };
+        // results of the entry offsets already walked: 12 bits per offset j = start - q0 (0..10):
+        // (exit - q1 + 1) | count << 4; 0 = not walked yet
+        uint64_t m0 = 0, m1 = 0; uint32_t m2 = 0;
+        auto memo_get = [&](uint32_t j) -> uint32_t {
+            const uint64_t w = j < 5 ? m0 : (j < 10 ? m1 : (uint64_t)m2);
+            const uint32_t sh = 12 * (j < 5 ? j : (j < 10 ? j - 5 : 0u));
+            return j <= 10 ? (uint32_t)(w >> sh) & 0xFFFu : 0u;
+        };
+        auto memo_put = [&](uint32_t j, uint32_t e) {
+            if (j < 5) m0 |= (uint64_t)e << (12 * j);
+            else if (j < 10) m1 |= (uint64_t)e << (12 * (j - 5));
+            else if (j == 10) m2 = e;
+        };
         int32_t start = q0;
         uint32_t cnt = 0;
         int32_t exitp = walk(start, cnt, nullptr);
+        if (cnt < 256 && (uint32_t)(exitp - q1) < 15) memo_put(0, (uint32_t)(exitp - q1 + 1) | (cnt << 4));
         for (int round = 0; round < 64; round++) {
             int32_t pe = __shfl_up(exitp, 1);
             int32_t ns = lane == 0 ? s0 : pe;
             bool changed = ns != start;
             if (!__any(changed)) break;
-            if (changed) { start = ns; exitp = walk(start, cnt, nullptr); }
+            bool need = false;
+            uint32_t j = 0;
+            if (changed) {
+                start = ns;
+                j = (uint32_t)(start - q0); // < L for a lane that is entered from below; anything else is simply walked
+                const uint32_t e = memo_get(j);
+                if (e) { exitp = q1 + (int32_t)(e & 15) - 1; cnt = e >> 4; }
+                else need = true;
+            }
+            TCOUNT(11, 1);
+            if (__any(need)) {
+                TCOUNT(10, 1);
+                if (need) {
+                    exitp = walk(start, cnt, nullptr);
+                    if (cnt < 256 && (uint32_t)(exitp - q1) < 15) memo_put(j, (uint32_t)(exitp - q1 + 1) | (cnt << 4));
+                }
 #ifdef MZD_STAMPS
-            if (lane == 0) atomicAdd(&S.c.diag_slow, 1u); // diagnostic: synchronisation rounds
+                if (lane == 0) atomicAdd(&S.c.diag_slow, 1u); // diagnostic: synchronisation rounds that had to walk
 #endif
+            }
         }
         const uint32_t incl = wave_incl_scan(cnt, lane);
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
@@ -564,7 +601,19 @@ __device__ __noinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t n,
     if ((uint32_t)lane < head) d[lane] = s[lane];
     d += head; s += head; n -= head;
     uint32_t nv = n >> 4;
-    for (uint32_t i = lane; i < nv; i += 64) {
+    uint32_t i = (uint32_t)lane;
+    for (; i + 192 < nv; i += 256) { // four 16-byte loads in flight per lane (a lone wavefront is latency-bound)
+        uint4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, s + (size_t)i * 16, 16);
+        __builtin_memcpy(&v1, s + (size_t)(i + 64) * 16, 16);
+        __builtin_memcpy(&v2, s + (size_t)(i + 128) * 16, 16);
+        __builtin_memcpy(&v3, s + (size_t)(i + 192) * 16, 16);
+        *reinterpret_cast<uint4*>(d + (size_t)i * 16) = v0;
+        *reinterpret_cast<uint4*>(d + (size_t)(i + 64) * 16) = v1;
+        *reinterpret_cast<uint4*>(d + (size_t)(i + 128) * 16) = v2;
+        *reinterpret_cast<uint4*>(d + (size_t)(i + 192) * 16) = v3;
+    }
+    for (; i < nv; i += 64) {
         uint4 v;
         __builtin_memcpy(&v, s + (size_t)i * 16, 16);
         *reinterpret_cast<uint4*>(d + (size_t)i * 16) = v;
@@ -1389,10 +1438,11 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         if (lpos != __atomic_load_n(&S.c.plan_lit_used, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
     } else {
         if (cx.nlit > kBlockMax) return MZD_E_CORRUPT;
+        if (cx.nlit > cx.cap - opos) return MZD_E_DSTSIZE; // a block without sequences has no planner to check this
     }
     const uint32_t rest = cx.nlit - lpos;
     if (!wait_lits(cx.nlit)) return MZD_E_CORRUPT;
-    wave_copy(dst + opos, lit + lpos, rest, lane);
+    if (lit + lpos != dst + opos) wave_copy(dst + opos, lit + lpos, rest, lane); // (literal-only block decoded in place: nothing to move)
     opos += rest;
     wg_fence();
     if (lane == 0) __atomic_store_n(&S.c.exec_pos, opos, __ATOMIC_RELAXED);
@@ -1775,8 +1825,12 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     // 2 KiB of LDS per decoding wavefront, borrowed from buffers that are idle while literals decode: the
                     // copier's staging buffers (waves 1, 2); the walker's ring (waves 0, 3: they decode after the walk)
                     uint8_t* const hseg = wave == 1 ? S.stage + 2064 : (wave == 2 ? S.hseg2 : (wave == 0 ? S.ring : S.ring + 4096));
+                    // A block without sequences IS its literals: the Huffman streams are then decoded straight into the
+                    // output (no literal buffer, no copy), provided they fit -- decided once the sequence header is parsed.
+                    auto lit_in_place = [&]() -> bool { return lit_type >= 2 && nseq == 0 && nlit <= cap - out0; };
                     auto huf_streams = [&](uint32_t max_take) {
                         const uint32_t hl = c.huf_log;
+                        uint8_t* const lbase = lit_in_place() ? dst + out0 : lit_buf;
                         for (uint32_t took = 0; took < max_take; took++) {
                             // every lane takes part (lanes != 0 add 0): no divergent region around the returning atomic
                             uint32_t st = __atomic_fetch_add(&c.next_stream, lane == 0 ? 1u : 0u, __ATOMIC_RELAXED);
@@ -1784,7 +1838,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             if (st >= streams || st >= 4) break;
                             int r = 0;
                             if (!__atomic_load_n(&c.err, __ATOMIC_RELAXED))
-                                r = huf_stream_wave(blk + c.s_off[st], c.s_len[st], lit_buf + c.s_out[st], c.s_n[st], hl, hseg, lane);
+                                r = huf_stream_wave(blk + c.s_off[st], c.s_len[st], lbase + c.s_out[st], c.s_n[st], hl, hseg, lane);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) { post_err(&c.err, r); __atomic_fetch_or(&c.streams_mask, 1u << st, __ATOMIC_RELAXED); __atomic_fetch_add(&c.streams_done, 1u, __ATOMIC_RELAXED); }
                         }
@@ -1793,6 +1847,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                     auto huf_helper = [&]() {
                         if (lit_type < 2) return;
                         if (lit_type == 2 && !spin_ge(&c.huf_fill, 2, &c.err)) return;
+                        if (!get_seq()) return;
                         huf_streams(4);
                     };
                     // ---- the block pipeline, one role per wavefront:
@@ -1866,8 +1921,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             uint32_t w = (uint32_t)src[lit_off] * 0x01010101u;
                             for (uint32_t k = (uint32_t)(tid - 64) * 16; k < nlit; k += 128 * 16)
                                 *reinterpret_cast<uint4*>(lit_buf + k) = make_uint4(w, w, w, w); // lit_buf has slack past nlit
-                        } else if (lit_type >= 2 && !failed) { // K2: the copying wavefront decodes one stream and then starts
-                            huf_streams(wave == 1 ? 1u : 4u); // copying behind the literals; wavefront 2 (and idle ones) drain the queue
+                        } else if (lit_type >= 2 && !failed && get_seq()) { // K2: the copying wavefront decodes one stream and then
+                            huf_streams(wave == 1 && !lit_in_place() ? 1u : 4u); // copies behind the literals; wavefront 2 (and idle ones) drain the queue
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) {
@@ -1880,7 +1935,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             uint64_t opos = out0;
                             rc = MZD_E_CORRUPT;
                             if (get_seq() && (lit_type != 1 || spin_ge(&c.lit_done, 2, &c.err))) { // RLE literals: both halves filled
-                                CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit, nlit, cap, lit_type >= 2 ? streams : 0u};
+                                CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit_in_place() ? dst + out0 : lit, nlit, cap, lit_type >= 2 ? streams : 0u};
                                 TFIN(9);
                                 __builtin_amdgcn_s_setprio(2); // second on the critical path, behind the walker
                                 rc = copy_wave(nseq, cx, &opos, lane);
@@ -1893,7 +1948,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                                 c.out = opos; c.pos = pos0 + bsize;
                                 if (a.debug) {
                                     DebugSlot& ds = a.debug[blockIdx.x];
-                                    ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0; ds.lit_raw_ptr = (uint64_t)(uintptr_t)lit;
+                                    ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0 || lit_in_place(); ds.lit_raw_ptr = (uint64_t)(uintptr_t)(lit_in_place() ? dst + out0 : lit);
                                 }
                             }
                             STAMP(6);

@@ -66,6 +66,22 @@ def test_dst_too_small_and_empty():
     assert mzd.decode(b"", 16) == (0, b"")
 
 
+def test_dst_too_small_every_vector_matches_oracle():
+    """Every positive vector (raw, RLE, literal-only, Huffman+sequences, multi-block, multi-frame) into a buffer that is
+    one byte short / half size / one byte long, interleaved with full-size neighbours: same status class as the CPU
+    twin, and the neighbours (whose device buffers sit right behind the short ones) still come out intact, i.e. nothing
+    was written past a capacity."""
+    vs = [v for v in VECS if v.ok and v.dict is None and v.out_len > 0]
+    for cap_of in (lambda n: n - 1, lambda n: n // 2, lambda n: 1):
+        for parity in (0, 1):
+            caps = [max(cap_of(v.out_len), 0) if i % 2 == parity else v.out_len for i, v in enumerate(vs)]
+            res = mzd.decode_batch([v.comp for v in vs], caps)
+            for v, cap, (st, out) in zip(vs, caps, res):
+                rc, _ = oracle.decode(v.comp, cap=cap)
+                assert st == rc, (v.name, cap, st, rc)
+                assert st != 0 or out == v.expected()[:cap], v.name
+
+
 def test_dictionary_frames():
     vs = [v for v in VECS if v.ok and v.dict is not None]
     did = mzd.load_dict(vs[0].dict)
