@@ -30,6 +30,16 @@
 #include "../../include/mzd.h"
 #include "mzd_device.h"
 
+#ifndef MZD_PRIO_WALK
+#define MZD_PRIO_WALK 3
+#endif
+#ifndef MZD_PRIO_COPY
+#define MZD_PRIO_COPY 2
+#endif
+#ifndef MZD_PRIO_PLAN
+#define MZD_PRIO_PLAN 1
+#endif
+
 namespace mzd {
 
 #if defined(MZD_STAMPS) || defined(MZD_TFIN)
@@ -1866,7 +1876,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             if (lane == 0) flag_store(&c.tables_ready, 1);
                             STAMP(4);
                             TFIN(5);
-                            __builtin_amdgcn_s_setprio(3); // the chain is the critical path: win issue arbitration on this SIMD
+                            __builtin_amdgcn_s_setprio(MZD_PRIO_WALK); // the chain is the critical path: win issue arbitration on this SIMD
                             int rc = walk_sequences_wave(src + seq_off, seq_len, nseq, walk, &c.walk_prog, lane);
                             __builtin_amdgcn_s_setprio(0);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1884,7 +1894,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             int rc = MZD_E_CORRUPT;
                             if (spin_ge(&c.tables_ready, 1, &c.err)) {
                                 PlanCtx px{walk, src + seq_off, &c.walk_prog, c.frame_out0, cap, c.dict_content_len, nlit};
-                                __builtin_amdgcn_s_setprio(1);
+                                __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
                                 rc = plan_wave(seqs, nseq, px, out0, c.rep, lane);
                                 __builtin_amdgcn_s_setprio(0);
                             }
@@ -1937,7 +1947,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             if (get_seq() && (lit_type != 1 || spin_ge(&c.lit_done, 2, &c.err))) { // RLE literals: both halves filled
                                 CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit_in_place() ? dst + out0 : lit, nlit, cap, lit_type >= 2 ? streams : 0u};
                                 TFIN(9);
-                                __builtin_amdgcn_s_setprio(2); // second on the critical path, behind the walker
+                                __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); // second on the critical path, behind the walker
                                 rc = copy_wave(nseq, cx, &opos, lane);
                                 __builtin_amdgcn_s_setprio(0);
                             }

@@ -1,6 +1,6 @@
 """Diagnostic: kernel time per corpus kind (N files of 128 KiB each, product library)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fuse_zstd_amd as mzd, corpus, oracle
 mzd.init()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200

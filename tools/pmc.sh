@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage: bash tools_pmc.sh "<counters>" [bench args]   -- one rocprofv3 --pmc pass, prints per-launch averages for mzd_decode_kernel
+# Usage: bash tools/pmc.sh "<counters>" [bench args]   -- one rocprofv3 --pmc pass, prints per-launch averages for mzd_decode_kernel
 set -e
 ctr="$1"; shift
 export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 """Diagnostic: decode named golden vectors one by one (prints as it goes)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fuse_zstd_amd as mzd
 from tests import golden_util
 mzd.init()

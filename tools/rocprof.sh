@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): bash tools_rocprof.sh <tag> [bench args...]
+# Usage (on the GPU box, from the repo root): bash tools/rocprof.sh <tag> [bench args...]
 # Three separate rocprofv3 passes over `python3 bench.py --no-cpu-baseline ...` (counters never share a
 # pass with each other: FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950):
 #   1. --kernel-trace --stats           -> gpurun_out/prof_<tag>.txt          (kernel durations)

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fuse_zstd_amd as mzd, corpus, oracle
 mzd.init()
 kind = sys.argv[1]

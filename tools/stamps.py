@@ -1,6 +1,6 @@
 """Diagnostic: per-phase cycles of one workgroup (libmzd_diag.so, -DMZD_STAMPS).  Not a benchmark."""
 import ctypes as C, sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fuse_zstd_amd.api as api
 api._SO = os.path.join(os.path.dirname(api._SO), os.environ.get("MZD_DIAG_SO", "libmzd_diag.so"))
 import fuse_zstd_amd as mzd, corpus
