@@ -1472,7 +1472,8 @@ __device__ __forceinline__ uint64_t xmerge(uint64_t h, uint64_t v) { v = xround(
 // executing one through the frame (xxh_advance up to the published output position) and closes
 // the digest at the frame end (xxh_finish).
 __device__ __forceinline__ uint64_t xxh_init(int lane) {
-    return lane == 0 ? XP1 + XP2 : (lane == 1 ? XP2 : (lane == 2 ? 0ull : 0ull - XP1));
+    const int l = lane & 3; // every group of four lanes carries the same four accumulators
+    return l == 0 ? XP1 + XP2 : (l == 1 ? XP2 : (l == 2 ? 0ull : 0ull - XP1));
 }
 // rotl by 31 as two funnel shifts ({lo,hi} >> 1 and {hi,lo} >> 1)
 __device__ __forceinline__ uint64_t rotl64_31(uint64_t x) {
@@ -1485,11 +1486,11 @@ __device__ __noinline__ void xxh_advance(uint64_t& v, uint64_t& stripes, uint64_
 #ifdef MZD_EXP_NOHASH
     stripes = upto; return;
 #endif
-    if (lane < 4) {
+    { // all 64 lanes run (16 copies of the four accumulator lanes): no divergent region around the loop
         // The accumulator chain is serial (two 64-bit multiplies per stripe); everything else is kept off it: groups
         // of 8 stripes with no per-stripe bounds checks, the next group's loads in flight while the current one is
         // absorbed, two register sets used alternately (no hand-over copies).
-        gcptr q = (gcptr)(p + lane * 8 + stripes * 32);
+        gcptr q = (gcptr)(p + (lane & 3) * 8 + stripes * 32);
         uint64_t n = upto - stripes;
         uint64_t acc = v;
         uint64_t A[8], B[8];
