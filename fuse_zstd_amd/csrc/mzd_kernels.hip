@@ -1909,6 +1909,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         huf_helper(); // the ring (its staging area) is free: the walker has finished before the planner does
                     } else {
                         int rc = 0;
+                        // the literals gate the copier (the tail of the block): the copying wavefront's tree + first stream run
+                        // at the copier's priority, the remaining streams just below
+                        if (wave == 1) __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); else __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
                         if (lit_type == 2) { // K1: the Huffman tree (from an LDS copy of its description), by wavefront 1
                             if (wave == 1) {
                                 const uint32_t tl = c.huf_tree_len; // <= 129 bytes
@@ -1940,6 +1943,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             post_err(&c.err, rc);
                             __atomic_fetch_add(&c.lit_done, 1u, __ATOMIC_RELAXED);
                         }
+                        __builtin_amdgcn_s_setprio(0);
                         STAMP(3);
                         if (wave == 1) TFIN(4);
                         if (wave == 1) { // the copying half of K5
