@@ -50,17 +50,66 @@ struct DebugSlot { // what workgroup `slot` last decoded (mzd_debug_last_block)
                         // -DMZD_TFIN: cycles after block start when walker / copier / hasher / planner finished, literals were ready, tables were ready
 };
 
+// ---- block tasks (N1: the blocks of one frame run on different workgroups) -------------------------------
+// A workgroup decodes ONE block per task.  Task 0 of file j is handed out by the ticket counter; the task of
+// the next block (or of the next frame) of the same file is pushed into a ring of continuation records by its
+// predecessor as soon as that one has read its own block header, i.e. long before it has decoded anything.
+// What a block needs from its predecessor travels through the file's FileState / TableArea, in task order:
+//   * entropy tables (treeless literals, repeat-mode FSE tables): `tables_ver` = number of tasks whose tables
+//     are in the area; a task reads what it inherits at version t, writes what it rebuilt, and publishes t + 1;
+//   * output position, repeat offsets, XXH64 state, first error: published with `copied` = t + 1 when the
+//     task's copy + hash are complete.  The copy stage of task t starts when copied == t.
+struct FileState { // zeroed per launch
+    uint32_t copied;
+    uint32_t tables_ver;
+    int32_t err;            // first error of the file, in task order
+    uint32_t huf_valid, fse_valid, huf_log;
+    uint32_t al[3];
+    uint32_t rep[3];
+    uint64_t out;           // bytes produced by the tasks completed so far
+    uint64_t frame_out0;    // `out` at the start of the current frame
+    uint64_t xstripes;      // XXH64: 32-byte stripes of the current frame absorbed so far
+    uint64_t xxh[4];        // XXH64 accumulators
+    uint64_t pad[3];
+};
+static_assert(sizeof(FileState) == 128, "FileState layout");
+
+struct TableArea { // the entropy tables in force after the file's most recently published task (LDS layout)
+    uint64_t ll[512];
+    uint64_t ml[512];
+    uint64_t of[256];
+    uint16_t huf[2048];
+};
+
+struct ContRecord { // one pushed task: where it starts and the frame it belongs to
+    uint64_t seq;           // launch epoch << 32 | (push index + 1) once the record is complete
+    uint64_t pos;           // input offset of the block header (in_frame) or of the next frame header
+    uint64_t fcs;
+    uint32_t job, task;
+    uint32_t in_frame;      // 0: starts at a frame header (or at the end of the file)
+    uint32_t has_fcs, has_cksum, block_max, with_dict;
+    uint32_t pad[3];
+};
+static_assert(sizeof(ContRecord) == 64, "ContRecord layout");
+
+// counter words (uint32): 0 ticket, 1 slot that ran the last task of job 0, 2 pushes, 3 files finished
 struct KernelArgs {
     DevJob* jobs;
     uint32_t njobs;
-    uint32_t* counter;    // work queue head
+    uint32_t* counter;    // see above; zeroed per launch
     uint8_t* lit_scratch; // kLitStride bytes per workgroup
     uint4* seq_scratch;   // kSeqStride uint4 per workgroup
     uint2* walk_scratch;  // kSeqStride uint2 per workgroup (state-walk records)
     const DevDict* dicts;
     uint32_t ndicts;
     DebugSlot* debug;     // gridDim.x entries
-    uint32_t* job_slot0;  // slot that ran job 0
+    uint32_t* job_slot0;  // = counter + 1
+    FileState* fstate;    // njobs entries, zeroed per launch
+    TableArea* tables;    // njobs entries
+    ContRecord* ring;     // ring_cap entries
+    uint32_t ring_cap;    // >= njobs + 1 (at most one unread continuation per file)
+    uint32_t epoch;       // distinguishes this launch's ring records from stale ones
+    uint32_t use_tasks;   // 1: driver 2 (block tasks), 0: driver 1 (a workgroup per file)
 };
 
 void launch_decode(const KernelArgs& a, uint32_t grid, void* stream);

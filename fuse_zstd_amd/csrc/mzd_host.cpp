@@ -24,7 +24,7 @@
 
 namespace mzd {
 void launch_dict_kernel(const uint8_t* dict, uint32_t n, DevDict* out, int32_t* status, void* stream);
-void* decode_kernel_ptr();
+void* decode_kernel_ptr(int tasks);
 }
 
 namespace {
@@ -45,7 +45,12 @@ struct Device {
     uint4* seq_scratch = nullptr;
     uint2* walk_scratch = nullptr;
     DebugSlot* debug = nullptr;
-    uint32_t* counter = nullptr; // [0] work-queue head, [1] slot that ran job 0
+    uint32_t* counter = nullptr; // [0] tickets, [1] task << 12 | slot of the last compressed block of job 0, [2] pushes, [3] files finished
+    FileState* fstate = nullptr;  // per file of a launch: what a block task hands to its successor
+    TableArea* tables = nullptr;
+    ContRecord* ring = nullptr;   // pushed tasks
+    size_t task_cap = 0;          // files the three arrays above are sized for
+    uint32_t epoch = 0;
     DevJob* d_jobs = nullptr;
     size_t d_jobs_cap = 0;
     DevJob* h_jobs = nullptr; // pinned
@@ -66,7 +71,7 @@ std::vector<std::unique_ptr<Device>> g_dev;
 void free_device(Device& d) {
     hipSetDevice(d.hip_id);
     if (d.stream) hipStreamSynchronize(d.stream);
-    hipFree(d.lit_scratch); hipFree(d.seq_scratch); hipFree(d.walk_scratch); hipFree(d.debug); hipFree(d.counter); hipFree(d.d_jobs);
+    hipFree(d.lit_scratch); hipFree(d.seq_scratch); hipFree(d.walk_scratch); hipFree(d.debug); hipFree(d.counter); hipFree(d.d_jobs); hipFree(d.fstate); hipFree(d.tables); hipFree(d.ring);
     hipFree(d.d_in); hipFree(d.d_out); hipFree(d.d_dicts);
     for (void* p : d.dict_bufs) hipFree(p);
     if (d.h_jobs) hipHostFree(d.h_jobs);
@@ -83,7 +88,10 @@ int init_device(Device& d, int hip_id) {
     HIPCHK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
     int cus = 0, per_cu = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_id));
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_kernel_ptr(), kWG, 0));
+    int per_cu2 = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_kernel_ptr(0), kWG, 0));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, (const void*)decode_kernel_ptr(1), kWG, 0));
+    per_cu = std::min(per_cu, per_cu2); // the block-task driver needs its whole grid resident
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     d.max_wg = (uint32_t)(cus * per_cu);
@@ -112,20 +120,61 @@ int ensure_jobs(Device& d, size_t n) {
     return MZD_OK;
 }
 
+// per-file task state for launches of up to n files (grow-only)
+int ensure_task_state(Device& d, size_t n) {
+    if (n <= d.task_cap) return MZD_OK;
+    size_t cap = std::max<size_t>(n + n / 4, 1024);
+    hipFree(d.fstate); hipFree(d.tables); hipFree(d.ring);
+    d.fstate = nullptr; d.tables = nullptr; d.ring = nullptr; d.task_cap = 0;
+    HIPCHK(hipMalloc(&d.fstate, cap * sizeof(FileState)));
+    HIPCHK(hipMalloc(&d.tables, cap * sizeof(TableArea)));
+    HIPCHK(hipMalloc(&d.ring, (cap + 1) * sizeof(ContRecord)));
+    HIPCHK(hipMemset(d.ring, 0, (cap + 1) * sizeof(ContRecord)));
+    d.task_cap = cap;
+    return MZD_OK;
+}
+
 KernelArgs make_args(Device& d, DevJob* jobs, uint32_t njobs) {
     KernelArgs a;
     a.jobs = jobs; a.njobs = njobs; a.counter = d.counter;
     a.lit_scratch = d.lit_scratch; a.seq_scratch = d.seq_scratch; a.walk_scratch = d.walk_scratch;
     a.dicts = d.d_dicts; a.ndicts = d.ndicts; a.debug = d.debug; a.job_slot0 = d.counter + 1;
+    a.fstate = d.fstate; a.tables = d.tables; a.ring = d.ring; a.ring_cap = (uint32_t)d.task_cap + 1; a.epoch = d.epoch;
     return a;
 }
 
 // enqueue: reset queue head, time the kernel with events on the launch stream
-int enqueue(Device& d, DevJob* d_jobs, uint32_t njobs, hipStream_t s) {
-    HIPCHK(hipMemsetAsync(d.counter, 0, 4, s));
+// Workgroups worth launching: one per file, plus the block tasks big files will fork (a compressed 128 KiB block is
+// rarely below 2 KiB), capped by what is resident at once.  Idle workgroups leave as soon as every file is finished.
+// Returns 0 when no file of the launch can have more than one block (every capacity <= 128 KiB): then driver 1 runs,
+// one workgroup per file.
+uint32_t grid_for(const Device& d, const DevJob* h_jobs, size_t njobs) {
+    bool multi = false;
+    for (size_t i = 0; i < njobs && !multi; i++) multi = h_jobs[i].dst_cap > kBlockMax;
+    if (!multi) return 0;
+    uint64_t tasks = 0;
+    for (size_t i = 0; i < njobs && tasks < d.max_wg; i++) tasks += 1 + h_jobs[i].src_len / 2048;
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tasks, 1), d.max_wg);
+}
+
+int enqueue(Device& d, DevJob* d_jobs, uint32_t njobs, uint32_t grid, hipStream_t s) {
+    bool use_tasks = grid != 0;
+    if (const char* e = getenv("MZD_DRIVER")) use_tasks = atoi(e) == 2; // diagnostics: force driver 1 / 2
+    if (use_tasks) {
+        int trc = ensure_task_state(d, njobs);
+        if (trc) return trc;
+        d.epoch++; // ring records of earlier launches never match
+        grid = std::max<uint32_t>(grid, std::min<uint32_t>(njobs, d.max_wg));
+        HIPCHK(hipMemsetAsync(d.counter, 0, 16, s));
+        HIPCHK(hipMemsetAsync(d.fstate, 0, (size_t)njobs * sizeof(FileState), s));
+    } else {
+        grid = std::min<uint32_t>(njobs, d.max_wg);
+        HIPCHK(hipMemsetAsync(d.counter, 0, 16, s));
+    }
     HIPCHK(hipEventRecord(d.ev0, s));
-    uint32_t grid = std::min<uint32_t>(njobs, d.max_wg);
-    launch_decode(make_args(d, d_jobs, njobs), grid, s);
+    KernelArgs ka = make_args(d, d_jobs, njobs);
+    ka.use_tasks = use_tasks ? 1u : 0u;
+    launch_decode(ka, grid, s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(d.ev1, s));
     return MZD_OK;
@@ -144,7 +193,7 @@ int run_device_jobs(Device& d, mzd_job* jobs, size_t njobs, hipStream_t s) {
         j.out_len = 0; j.status = MZD_E_DEVICE; j.dict = jobs[i].dict_id;
     }
     HIPCHK(hipMemcpyAsync(d.d_jobs, d.h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice, s));
-    rc = enqueue(d, d.d_jobs, (uint32_t)njobs, s);
+    rc = enqueue(d, d.d_jobs, (uint32_t)njobs, grid_for(d, d.h_jobs, njobs), s);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(d.h_jobs, d.d_jobs, njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -212,7 +261,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
     hipStream_t s = d.stream;
     HIPCHK(hipMemcpyAsync(d.d_in, d.h_in, in_total, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d.d_jobs, d.h_jobs, idx.size() * sizeof(DevJob), hipMemcpyHostToDevice, s));
-    rc = enqueue(d, d.d_jobs, (uint32_t)idx.size(), s);
+    rc = enqueue(d, d.d_jobs, (uint32_t)idx.size(), grid_for(d, d.h_jobs, idx.size()), s);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(d.h_jobs, d.d_jobs, idx.size() * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     // The output comes back in slices of jobs; while slice i+1 crosses the link, slice i is copied out to the callers' buffers.
@@ -409,7 +458,7 @@ int mzd_batch_launch(mzd_batch* b, void* stream) {
     if (!d) return MZD_E_DEVICE;
     std::lock_guard<std::mutex> lk(d->mu);
     HIPCHK(hipSetDevice(d->hip_id));
-    return enqueue(*d, b->d_jobs, (uint32_t)b->njobs, stream ? (hipStream_t)stream : d->stream);
+    return enqueue(*d, b->d_jobs, (uint32_t)b->njobs, grid_for(*d, b->h_jobs, b->njobs), stream ? (hipStream_t)stream : d->stream);
 }
 
 int mzd_batch_collect(mzd_batch* b, mzd_job* jobs, void* stream) {
@@ -476,6 +525,7 @@ int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit
     HIPCHK(hipSetDevice(d->hip_id));
     uint32_t slot = 0;
     HIPCHK(hipMemcpy(&slot, d->counter + 1, 4, hipMemcpyDeviceToHost));
+    slot &= 0xFFFu; // task << 12 | slot
     if (slot >= d->max_wg) return MZD_E_PARAM;
     DebugSlot ds;
     HIPCHK(hipMemcpy(&ds, d->debug + slot, sizeof(ds), hipMemcpyDeviceToHost));
@@ -498,6 +548,7 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
     HIPCHK(hipSetDevice(d->hip_id));
     uint32_t slot = 0;
     HIPCHK(hipMemcpy(&slot, d->counter + 1, 4, hipMemcpyDeviceToHost));
+    slot &= 0xFFFu; // task << 12 | slot
     if (slot >= d->max_wg) return MZD_E_PARAM;
     DebugSlot ds;
     HIPCHK(hipMemcpy(&ds, d->debug + slot, sizeof(ds), hipMemcpyDeviceToHost));

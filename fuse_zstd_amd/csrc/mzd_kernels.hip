@@ -44,12 +44,16 @@ namespace mzd {
 
 #if defined(MZD_STAMPS) || defined(MZD_TFIN)
 #define TFIN(k) do { if (lane == 0) S.tfin[k] = __builtin_readcyclecounter() - S.tstart; } while (0)
-#define TSTART() do { if (tid == 0) { S.tstart = __builtin_readcyclecounter(); S.tfin[10] = 0; S.tfin[11] = 0; } } while (0)
+#define TSTART() do { if (tid == 0) { S.tstart = __builtin_readcyclecounter(); S.tfin[10] = S.tstart - S.ttask; } } while (0)
+#define TTASK() do { if (tid == 0) S.ttask = __builtin_readcyclecounter(); } while (0)
+#define TTASK_END() do { if (tid == 0) S.tfin[11] = __builtin_readcyclecounter() - S.ttask; } while (0)
 #define TCOUNT(k, v) do { if (lane == 0) atomicAdd((unsigned long long*)&S.tfin[k], (unsigned long long)(v)); } while (0)
 #define TFIN_FLUSH() do { if (tid == 0 && a.debug) for (int k_ = 0; k_ < 12; k_++) a.debug[blockIdx.x].tfin[k_] = S.tfin[k_]; } while (0)
 #else
 #define TFIN(k)
 #define TCOUNT(k, v)
+#define TTASK()
+#define TTASK_END()
 #define TSTART()
 #define TFIN_FLUSH()
 #endif
@@ -102,8 +106,16 @@ struct Ctl {
     uint32_t diag_slow;                            // diagnostic build: walker iterations that needed a lower window
     uint32_t nseq, mode[3], al[3], nsym[3], fse_valid, seq_len;
     uint32_t rep[3];
+    uint32_t rep_op[4];                             // the block's repeat-offset transform (start slots -> end slots): s, v0, v1, v2
     uint32_t dict_content_len;
     const uint8_t* dict_content;
+    // the task (one block of one file) and what its predecessor published
+    uint32_t t_valid, task, in_frame, with_dict;
+    uint32_t pred_ready;                            // the predecessor's state is in pred_* (LDS flag of the block pipeline)
+    int32_t pred_err;
+    uint32_t pred_rep[3];
+    uint32_t tables_published;
+    uint64_t pred_out, pred_frame_out0, pred_xstripes, pred_xxh[4];
 };
 
 struct __attribute__((aligned(16))) Shared {
@@ -120,7 +132,7 @@ struct __attribute__((aligned(16))) Shared {
     uint64_t cdiag[8];
 #endif
 #if defined(MZD_STAMPS) || defined(MZD_TFIN)
-    uint64_t tstart, tfin[12]; // block start; finish of walker / copier / hasher / planner; literals ready; tables ready
+    uint64_t ttask, tstart, tfin[12]; // block start; finish of walker / copier / hasher / planner; literals ready; tables ready
 #endif
     uint16_t huf[2048]; // sym | len << 8
     int16_t norm[3][64];
@@ -508,7 +520,7 @@ __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint
             if (blo + o >= 16) __builtin_memcpy(&v, sp + (blo + o - 16), 16); // may over-read <= 15 bytes past the stream (input padding)
             *reinterpret_cast<uint4*>(seg + o) = v;
         }
-        const uint8_t* const seg0 = seg + 16 - blo; // seg0 + j = stream byte j
+        const int32_t seg_bias = 16 - (int32_t)blo; // stream byte j lives at seg[j + seg_bias] (the index is formed first: a pointer below `seg` would be out of bounds)
         int32_t C = (s1 - s0 + 63) / 64;
         if (C < 32) C = 32;
         int32_t q0 = s0 + lane * C, q1 = q0 + C;
@@ -524,7 +536,7 @@ __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint
             while (rem > lim) {
                 const int32_t bi = (rem - 57) >> 3; // window = stream bytes [bi, bi + 8): the 57..64 bits below the read point
                 uint64_t W;
-                __builtin_memcpy(&W, seg0 + bi, 8);
+                __builtin_memcpy(&W, seg + (uint32_t)(bi + seg_bias), 8);
                 int32_t h = rem - bi * 8;           // read point inside the window
 #pragma unroll
                 for (int k = 0; k < 5; k++) {
@@ -577,9 +589,7 @@ __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint
                 if (e) { exitp = q1 + (int32_t)(e & 15) - 1; cnt = e >> 4; }
                 else need = true;
             }
-            TCOUNT(11, 1);
             if (__any(need)) {
-                TCOUNT(10, 1);
                 if (need) {
                     exitp = walk(start, cnt, nullptr);
                     if (cnt < 256 && (uint32_t)(exitp - q1) < 15) memo_put(j, (uint32_t)(exitp - q1 + 1) | (cnt << 4));
@@ -1061,20 +1071,32 @@ struct PlanCtx { // what the planning wavefront needs
     const uint2* walk;       // state-walk records of the block (HBM scratch)
     const uint8_t* seq_sp;   // the block's sequence bitstream
     const uint32_t* prog;    // walker progress (LDS)
-    uint64_t frame_start;    // offset of the current frame's first byte in dst
-    uint64_t cap;
-    uint32_t dict_len;
     uint32_t nlit;
+    uint32_t rep_known;      // the repeat offsets at the start of the block are known (first block of a frame)
+    uint32_t rep[3];
 };
 
+// Offsets in the plan: a plain value, or -- when the block starts before its predecessor has finished, so that
+// the repeat offsets at its start are still unknown -- a reference to one of the three start slots plus a delta.
+// The copier resolves those (it runs after the predecessor).  0 is never a valid offset.
+constexpr uint32_t kOffTag = 0x80000000u;
+constexpr int32_t kOffBias = 1 << 28;
+__device__ __forceinline__ uint32_t off_symbolic(uint32_t slot, int32_t delta) { return kOffTag | (slot << 29) | ((uint32_t)(delta + kOffBias) & 0x1FFFFFFFu); }
+
 // K4(b) + the bookkeeping half of K5, by one wavefront, 64 sequences per step (lane = sequence):
-// field conversion from the walk records, repeat offsets, positions, validation.  The result goes
-// to the plan array in HBM: per sequence {ll, ml, off, output offset inside the chunk}.  Returns 0 or an error.
-__device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanCtx& cx, uint64_t opos, uint32_t* rep, int lane) {
+// field conversion from the walk records, repeat offsets, positions, what can be validated without knowing
+// where the block's output starts (the copier checks capacity and offsets).  The result goes to the plan array in
+// HBM: per sequence {ll, ml, off, output offset inside the chunk}.  The block's total repeat-offset transform
+// (start slots -> end slots) is left in S.c.rep_op.  Returns 0 or an error.
+__device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanCtx& cx, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
-    const uint64_t block_start = opos;
+    uint32_t opos = 0; // output produced so far, relative to the block start
     uint32_t lpos = 0;
-    uint32_t r0 = __builtin_amdgcn_readfirstlane(rep[0]), r1 = __builtin_amdgcn_readfirstlane(rep[1]), r2 = __builtin_amdgcn_readfirstlane(rep[2]);
+    // R: block start -> before the current chunk.  Known start offsets make it a constant map (every offset then
+    // comes out as a plain value); unknown ones the identity.
+    RepOp R;
+    if (cx.rep_known) { R.s = 3 | (3 << 2) | (3 << 4); R.v0 = (int32_t)cx.rep[0]; R.v1 = (int32_t)cx.rep[1]; R.v2 = (int32_t)cx.rep[2]; }
+    else { R.s = 0 | (1 << 2) | (2 << 4); R.v0 = 0; R.v1 = 0; R.v2 = 0; }
     // The walk records and the extra bits live in HBM (the walker may be arbitrarily far ahead, e.g. while
     // the literals are still being decoded).  Their latency is taken off this wavefront's critical path
     // by a two-stage software pipeline: while chunk k is planned, the records of chunk k+2 and the bit
@@ -1155,34 +1177,41 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
             RepOp before; // exclusive
             before.s = __shfl_up(acc.s, 1); before.v0 = __shfl_up(acc.v0, 1); before.v1 = __shfl_up(acc.v1, 1); before.v2 = __shfl_up(acc.v2, 1);
             if (lane == 0) { before.s = 0 | (1 << 2) | (2 << 4); before.v0 = 0; before.v1 = 0; before.v2 = 0; }
-            uint32_t b0 = rep_eval(before, 0, r0, r1, r2), b1 = rep_eval(before, 1, r0, r1, r2), b2 = rep_eval(before, 2, r0, r1, r2);
+            const RepOp T = rep_compose(before, R); // block start -> just before this sequence
             if (ofv > 3) off = ofv - 3;
-            else off = idx == 0 ? b0 : (idx == 1 ? b1 : (idx == 2 ? b2 : b0 - 1));
-            uint32_t e0 = rep_eval(acc, 0, r0, r1, r2), e1 = rep_eval(acc, 1, r0, r1, r2), e2 = rep_eval(acc, 2, r0, r1, r2);
-            r0 = __builtin_amdgcn_readlane(e0, 63); r1 = __builtin_amdgcn_readlane(e1, 63); r2 = __builtin_amdgcn_readlane(e2, 63);
+            else {
+                const uint32_t slot = idx == 1 ? 1u : (idx == 2 ? 2u : 0u); // idx 0 and 3 read slot 0
+                const uint32_t src = (T.s >> (2 * slot)) & 3;
+                const int32_t v = sel3(slot, T.v0, T.v1, T.v2) - (idx == 3 ? 1 : 0);
+                if (src == 3) off = v > 0 ? (uint32_t)v : 0u; // 0: invalid, the copier rejects it
+                else off = off_symbolic(src, v);
+            }
+            // chunk end -> R of the next chunk
+            RepOp last;
+            last.s = __builtin_amdgcn_readlane(acc.s, 63); last.v0 = __builtin_amdgcn_readlane(acc.v0, 63);
+            last.v1 = __builtin_amdgcn_readlane(acc.v1, 63); last.v2 = __builtin_amdgcn_readlane(acc.v2, 63);
+            R = rep_compose(last, R);
         }
         // ---- positions and validation
         const uint32_t tot = ll + ml;
         const uint32_t incl_t = wave_incl_scan(tot, lane), incl_l = wave_incl_scan(ll, lane);
         const uint32_t chunk_tot = __builtin_amdgcn_readlane(incl_t, 63), chunk_lit = __builtin_amdgcn_readlane(incl_l, 63);
         if (chunk_lit > cx.nlit - lpos) return MZD_E_CORRUPT;
-        if ((opos - block_start) + chunk_tot > kBlockMax) return MZD_E_CORRUPT;
-        if (chunk_tot > cx.cap - opos) return MZD_E_DSTSIZE;
+        if (opos + chunk_tot > kBlockMax) return MZD_E_CORRUPT;
         const uint32_t ex_t = incl_t - tot; // this sequence's output offset inside the 64-chunk
-        const uint64_t mdst = opos + ex_t + ll;
-        const uint64_t avail = (mdst - cx.frame_start) + cx.dict_len;
-        if (__any(valid && (off == 0 || off > avail))) return MZD_E_CORRUPT;
-        // the plan of this sequence: {ll, ml, resolved offset, output offset inside the chunk} -> HBM (unbounded, so the
+        // the plan of this sequence: {ll, ml, offset, output offset inside the chunk} -> HBM (unbounded, so the
         // planner never waits for the copier, which may still be decoding literals); also what mzd_debug_last_block shows
         if (valid) seqs[i] = make_uint4(ll, ml, off, ex_t);
         opos += chunk_tot;
         lpos += chunk_lit;
     }
     const uint32_t rest = cx.nlit - lpos;
-    if (rest > cx.cap - opos) return MZD_E_DSTSIZE;
-    if ((opos - block_start) + rest > kBlockMax) return MZD_E_CORRUPT;
+    if (opos + rest > kBlockMax) return MZD_E_CORRUPT;
     wg_fence();
-    if (lane == 0) { rep[0] = r0; rep[1] = r1; rep[2] = r2; S.c.plan_lit_used = lpos; flag_store(&S.c.plan_prog, chunk); }
+    if (lane == 0) {
+        S.c.rep_op[0] = R.s; S.c.rep_op[1] = (uint32_t)R.v0; S.c.rep_op[2] = (uint32_t)R.v1; S.c.rep_op[3] = (uint32_t)R.v2;
+        S.c.plan_lit_used = lpos; flag_store(&S.c.plan_prog, chunk);
+    }
     return 0;
 }
 
@@ -1196,6 +1225,8 @@ struct CopyCtx {
     uint32_t nlit;
     uint64_t cap;            // capacity of dst
     uint32_t lit_streams;    // Huffman streams the literals arrive in (0: all literals are there from the start)
+    uint32_t rep[3];         // the repeat offsets at the start of the block (the plan may refer to them)
+    uint4* plan_wb;          // debug view only: resolved offsets are written back to the plan (else null)
 };
 
 // The copying half of K5, by one wavefront.  It publishes the finished output position in S.c.exec_pos
@@ -1231,6 +1262,13 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
     uint8_t* const dst = cx.dst;
     const uint8_t* const lit = cx.lit;
+    // the context lives in the caller's frame (scratch memory): what the loops use is read once, into scalar
+    // registers (wave-uniform; the vector registers are all taken); the rare paths read the rest where they need it
+    auto u32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto u64 = [&](uint64_t v) -> uint64_t { return (uint64_t)u32((uint32_t)v) | ((uint64_t)u32((uint32_t)(v >> 32)) << 32); };
+    const uint64_t cap = u64(cx.cap), frame_start = u64(cx.frame_start);
+    const uint32_t dict_len = u32(cx.dict_len), nlit_all = u32(cx.nlit), lit_streams = u32(cx.lit_streams);
+    const uint4* const plan = (const uint4*)(uintptr_t)u64((uint64_t)(uintptr_t)cx.plan);
     uint64_t opos = *opos_io;
     uint32_t lpos = 0;
     CSTAMP_DECL;
@@ -1245,13 +1283,13 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         return (pg & ~kPlanFin) >= nchunks_needed;
     };
     // literals become available stream by stream (in order: stream k fills [s_out[k], s_out[k] + s_n[k]))
-    uint32_t lit_avail = cx.lit_streams ? 0u : cx.nlit;
+    uint32_t lit_avail = lit_streams ? 0u : nlit_all;
     auto wait_lits = [&](uint32_t need) -> bool {
         if (need <= lit_avail) return true;
         for (uint32_t it = 0; it < (1u << 24); it++) {
             const uint32_t m = flag_load(&S.c.streams_mask);
             const uint32_t k = (uint32_t)__builtin_ctz(~m); // first stream not decoded yet
-            lit_avail = k >= cx.lit_streams ? cx.nlit : S.c.s_out[k];
+            lit_avail = k >= lit_streams ? nlit_all : S.c.s_out[k];
             if (need <= lit_avail) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
             if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return false;
             __builtin_amdgcn_s_sleep(4);
@@ -1339,7 +1377,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     uint4 pe_next = make_uint4(0, 0, 0, 0);
     if (nseq) {
         if (!wait_plan(1)) return MZD_E_CORRUPT; // the planner failed and posted the error
-        if ((uint32_t)lane < nseq) pe_next = cx.plan[lane];
+        if ((uint32_t)lane < nseq) pe_next = plan[lane];
     }
     uint32_t chunk = 0;
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
@@ -1350,18 +1388,26 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             if (!wait_plan(chunk + 2)) return MZD_E_CORRUPT;
             CSTAMP(0);
             const uint32_t j = base + 64 + (uint32_t)lane;
-            pe_next = j < nseq ? cx.plan[j] : make_uint4(0, 0, 0, 0);
+            pe_next = j < nseq ? plan[j] : make_uint4(0, 0, 0, 0);
         }
         const bool valid = (uint32_t)lane < cnt;
-        const uint32_t ll = valid ? pe.x : 0, ml = valid ? pe.y : 0, off = pe.z, ex_t = pe.w;
+        const uint32_t ll = valid ? pe.x : 0, ml = valid ? pe.y : 0, ex_t = pe.w;
+        uint32_t off = pe.z;
+        if (off & kOffTag) { // an offset left symbolic by the planner: start slot + delta
+            const uint32_t slot = (off >> 29) & 3;
+            off = (uint32_t)sel3(slot, (int32_t)cx.rep[0], (int32_t)cx.rep[1], (int32_t)cx.rep[2]) + (off & 0x1FFFFFFFu) - (uint32_t)kOffBias;
+            if (cx.plan_wb && valid) cx.plan_wb[base + (uint32_t)lane].z = off;
+        }
         const uint32_t incl_t = ex_t + ll + ml;
         const uint32_t chunk_tot = __builtin_amdgcn_readlane(incl_t, cnt - 1);
+        if (chunk_tot > cap - opos) return MZD_E_DSTSIZE;
+        if (__any(valid && (off == 0 || off > (opos + ex_t + ll - frame_start) + dict_len))) return MZD_E_CORRUPT; // beyond the window's history
         const uint32_t incl_l = wave_incl_scan(ll, lane);
         const uint32_t my_lit = lpos + (incl_l - ll);
         lpos += __builtin_amdgcn_readlane(incl_l, 63);
         if (!wait_lits(lpos)) return MZD_E_CORRUPT; // a literal stream failed (the error is posted)
         const uint64_t mdst = opos + ex_t + ll; // absolute match destination
-        const bool in_dict = valid && off > mdst - cx.frame_start;
+        const bool in_dict = valid && off > mdst - frame_start;
         const bool islong = valid && (ll > kShort || ml > kShort || in_dict);
         const uint64_t longmask = __ballot(islong);
 
@@ -1377,14 +1423,14 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 wg_fence();                                   // everything so far (flushes and these literals) has landed
                 if (lane == 0) __atomic_store_n(&S.c.exec_pos, run_pos + l, __ATOMIC_RELAXED);
                 uint8_t* d = dst + run_pos + l;
-                const uint64_t have = run_pos + l - cx.frame_start;
+                const uint64_t have = run_pos + l - frame_start;
                 if (o > have) { // starts inside the dictionary: owner lane, sequential semantics
                     if ((uint32_t)lane == a) {
                         uint64_t back = o - have;
-                        const uint8_t* dp = cx.dict + cx.dict_len - back;
+                        const uint8_t* dp = cx.dict + dict_len - back;
                         uint32_t k = 0;
                         for (; k < m && k < back; k++) d[k] = dp[k];
-                        for (; k < m; k++) d[k] = dst[cx.frame_start + (k - back)];
+                        for (; k < m; k++) d[k] = dst[frame_start + (k - back)];
                     }
                 } else if (o >= m) wave_copy(d, d - o, m, lane);
                 else wave_pattern(d, o, m, lane);
@@ -1420,7 +1466,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 else if (pe_ < 0) N.bytewise = true;                                                         // straddles the run start
                 else if (v1 && pd <= lim1) N.src_lds = NI.buf1 * kBufStride + (uint32_t)(lim1 - pd);         // inside the previous run
                 else if (v1 && v2 && pe_ >= lim1 && pd <= lim2) N.src_lds = NI.buf2 * kBufStride + (uint32_t)(lim2 - pd); // inside the run before it
-                else if (pe_ >= lim2 && run_pos - (uint64_t)pe_ + 8 <= cx.cap) N.kind = N.ml > 31 ? 5 : 4;   // older: HBM (may over-read 7 bytes)
+                else if (pe_ >= lim2 && run_pos - (uint64_t)pe_ + 8 <= cap) N.kind = N.ml > 31 ? 5 : 4;   // older: HBM (may over-read 7 bytes)
                 else N.bytewise = true;                                                                       // straddles two buffers / ends at the buffer end
             }
             NI.bigl = __any(N.ll > 31);
@@ -1446,12 +1492,13 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
         if (lpos != __atomic_load_n(&S.c.plan_lit_used, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
+        if (nlit_all - lpos > cap - opos) return MZD_E_DSTSIZE;
     } else {
-        if (cx.nlit > kBlockMax) return MZD_E_CORRUPT;
-        if (cx.nlit > cx.cap - opos) return MZD_E_DSTSIZE; // a block without sequences has no planner to check this
+        if (nlit_all > kBlockMax) return MZD_E_CORRUPT;
+        if (nlit_all > cap - opos) return MZD_E_DSTSIZE; // a block without sequences has no planner to check this
     }
-    const uint32_t rest = cx.nlit - lpos;
-    if (!wait_lits(cx.nlit)) return MZD_E_CORRUPT;
+    const uint32_t rest = nlit_all - lpos;
+    if (!wait_lits(nlit_all)) return MZD_E_CORRUPT;
     if (lit + lpos != dst + opos) wave_copy(dst + opos, lit + lpos, rest, lane); // (literal-only block decoded in place: nothing to move)
     opos += rest;
     wg_fence();
@@ -1725,7 +1772,10 @@ __device__ __noinline__ void build_tables_wave(int lane) {
 #define WG_SNAPSHOT(...) do { __syncthreads(); __VA_ARGS__; __syncthreads(); } while (0)
 
 
-__global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
+// ---- driver 1: one workgroup decodes a whole file, block after block.  Used when no file of the launch can have more
+// than one block (every output capacity <= 128 KiB): nothing is forked, nothing is published, the file's state
+// stays in registers and LDS.
+__global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* const lit_buf = a.lit_scratch + (size_t)blockIdx.x * kLitStride;
     uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
@@ -1735,7 +1785,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
 
     for (;;) {
-        if (tid == 0) c.job = atomicAdd(a.counter, 1u);
+        if (tid == 0) c.job = atomicAdd(&a.counter[0], 1u);
         uint32_t j;
         WG_SNAPSHOT(j = c.job);
         if (j >= a.njobs) break;
@@ -1749,7 +1799,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
 #ifdef MZD_STAMPS
             for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = 0;
 #endif
-            if (j == 0 && a.job_slot0) *a.job_slot0 = blockIdx.x;
+            if (j == 0) a.counter[1] = blockIdx.x;
             if (job_dict > a.ndicts) c.err = MZD_E_DICT;
         }
         int err = 0;
@@ -1814,6 +1864,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = out0;
                         c.next_stream = 0; c.streams_done = 0; c.streams_mask = 0;
                         c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.seq_parsed = 0;
+                        c.rep_op[0] = 0 | (1 << 2) | (2 << 4); c.rep_op[1] = 0; c.rep_op[2] = 0; c.rep_op[3] = 0;
                         parse_literals(S.stage, bsize);
                     }
                     uint32_t lit_type = 0, nlit = 0, streams = 0, nseq = 0, seq_len = 0;
@@ -1894,9 +1945,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         if (get_seq() && nseq) {
                             int rc = MZD_E_CORRUPT;
                             if (spin_ge(&c.tables_ready, 1, &c.err)) {
-                                PlanCtx px{walk, src + seq_off, &c.walk_prog, c.frame_out0, cap, c.dict_content_len, nlit};
+                                PlanCtx px{walk, src + seq_off, &c.walk_prog, nlit, 1u, {c.rep[0], c.rep[1], c.rep[2]}};
                                 __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
-                                rc = plan_wave(seqs, nseq, px, out0, c.rep, lane);
+                                rc = plan_wave(seqs, nseq, px, lane);
                                 __builtin_amdgcn_s_setprio(0);
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1950,7 +2001,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                             uint64_t opos = out0;
                             rc = MZD_E_CORRUPT;
                             if (get_seq() && (lit_type != 1 || spin_ge(&c.lit_done, 2, &c.err))) { // RLE literals: both halves filled
-                                CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit_in_place() ? dst + out0 : lit, nlit, cap, lit_type >= 2 ? streams : 0u};
+                                CopyCtx cx{seqs, dst, c.frame_out0, c.dict_content, c.dict_content_len, lit_in_place() ? dst + out0 : lit, nlit, cap, lit_type >= 2 ? streams : 0u, {c.rep[0], c.rep[1], c.rep[2]}, nullptr};
                                 TFIN(9);
                                 __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); // second on the critical path, behind the walker
                                 rc = copy_wave(nseq, cx, &opos, lane);
@@ -1985,6 +2036,14 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
                         }
                     }
                 }
+                if (btype == 2) { // the block's repeat-offset transform (the planner leaves it symbolic) -> the offsets after it
+                    __syncthreads();
+                    if (tid == 0) {
+                        RepOp Rf; Rf.s = c.rep_op[0]; Rf.v0 = (int32_t)c.rep_op[1]; Rf.v1 = (int32_t)c.rep_op[2]; Rf.v2 = (int32_t)c.rep_op[3];
+                        const uint32_t a0 = c.rep[0], a1 = c.rep[1], a2 = c.rep[2];
+                        c.rep[0] = rep_eval(Rf, 0, a0, a1, a2); c.rep[1] = rep_eval(Rf, 1, a0, a1, a2); c.rep[2] = rep_eval(Rf, 2, a0, a1, a2);
+                    }
+                }
                 WG_SNAPSHOT(err = c.err);
                 STAMP(6);
                 if (err || last) break;
@@ -2017,6 +2076,539 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel(KernelArgs a) {
             }
         }
         if (tid == 0) { a.jobs[j].out_len = c.out; a.jobs[j].status = c.err; }
+        STAMP_FLUSH();
+        TFIN_FLUSH();
+        __syncthreads();
+    }
+}
+
+
+// ---- driver 2: block tasks.  inter-workgroup hand-over (agent scope): a task publishes, its successor on another CU acquires
+__device__ __forceinline__ uint32_t g_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void g_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void g_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void g_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Agent-scope fences write back / invalidate the XCD's whole L2 (buffer_wbl2 / buffer_inv): they are kept for the one thing
+// that needs them -- the output bytes a successor on another XCD reads -- and everything small (task records, per-file
+// state, table areas) travels through agent-scope atomic loads and stores, which are coherent by themselves.
+// `g_settle` orders such stores before the flag that publishes them.
+template <class T> __device__ __forceinline__ T g_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void g_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void g_settle() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// wait until *p >= want (bounded: a launch that lost a task must end, not hang); one lane calls this
+__device__ __noinline__ bool g_wait_ge(const uint32_t* p, uint32_t want) {
+    for (uint32_t it = 0; it < (1u << 23); it++) {
+        if (g_load(p) >= want) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
+// lane 0: what the predecessor of task t left behind -> S.c.pred_*.  false: the launch is broken (timeout).
+__device__ __noinline__ bool load_pred(const FileState* fs, uint32_t t) {
+    Ctl& c = S.c;
+    if (t == 0) {
+        c.pred_err = 0; c.pred_out = 0; c.pred_frame_out0 = 0; c.pred_xstripes = 0;
+        c.pred_rep[0] = 1; c.pred_rep[1] = 4; c.pred_rep[2] = 8;
+        for (int k = 0; k < 4; k++) c.pred_xxh[k] = 0;
+    } else {
+        if (!g_wait_ge(&fs->copied, t)) { c.pred_err = MZD_E_DEVICE; c.pred_out = 0; c.pred_frame_out0 = 0; c.pred_xstripes = 0; return false; }
+        c.pred_err = g_ld(&fs->err); c.pred_out = g_ld(&fs->out); c.pred_frame_out0 = g_ld(&fs->frame_out0); c.pred_xstripes = g_ld(&fs->xstripes);
+        c.pred_rep[0] = g_ld(&fs->rep[0]); c.pred_rep[1] = g_ld(&fs->rep[1]); c.pred_rep[2] = g_ld(&fs->rep[2]);
+        for (int k = 0; k < 4; k++) c.pred_xxh[k] = g_ld(&fs->xxh[k]);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t* const lit_buf = a.lit_scratch + (size_t)blockIdx.x * kLitStride;
+    uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
+    uint2* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
+    Ctl& c = S.c;
+    if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
+    if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
+
+    for (;;) {
+        // ---------------- take a task: tickets below njobs are the first blocks of the files, the others the pushed
+        // continuations in push order (a ticket may have to wait for its record; it gives up once every file is finished)
+        if (tid == 0) {
+            c.t_valid = 0;
+            const uint32_t ticket = atomicAdd(&a.counter[0], 1u);
+            if (ticket < a.njobs) { c.job = ticket; c.task = 0; c.pos = 0; c.in_frame = 0; c.with_dict = 0; c.t_valid = 1; }
+            else {
+                const uint32_t m = ticket - a.njobs;
+                const ContRecord* r = &a.ring[m % a.ring_cap];
+                const uint64_t want = ((uint64_t)a.epoch << 32) | (uint64_t)(m + 1);
+                for (uint32_t it = 0; it < (1u << 23); it++) {
+                    bool got = __hip_atomic_load(&r->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+                    if (!got && g_load(&a.counter[3]) >= a.njobs) { // every file is finished: nothing is pushed any more
+                        got = __hip_atomic_load(&r->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+                        if (!got) break;
+                    }
+                    if (got) {
+                        c.job = g_ld(&r->job); c.task = g_ld(&r->task); c.pos = g_ld(&r->pos); c.in_frame = g_ld(&r->in_frame); c.with_dict = g_ld(&r->with_dict);
+                        c.has_fcs = g_ld(&r->has_fcs); c.has_cksum = g_ld(&r->has_cksum); c.block_max = g_ld(&r->block_max); c.fcs = g_ld(&r->fcs);
+                        c.t_valid = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+        }
+        uint32_t t_valid = 0, j = 0, t = 0, in_frame = 0;
+        WG_SNAPSHOT(t_valid = c.t_valid; j = c.job; t = c.task; in_frame = c.in_frame);
+        if (!t_valid) break;
+        TTASK();
+        const uint8_t* const src = a.jobs[j].src;
+        const uint64_t n = a.jobs[j].src_len;
+        uint8_t* const dst = a.jobs[j].dst;
+        const uint64_t cap = a.jobs[j].dst_cap;
+        const uint32_t job_dict = a.jobs[j].dict;
+        FileState* const fs = &a.fstate[j];
+        TableArea* const ta = &a.tables[j];
+        if (tid == 0) {
+            c.out = 0; c.err = 0; c.action = 0; c.diag_slow = 0; c.pred_ready = 0; c.tables_published = 0; c.last = 0;
+#ifdef MZD_STAMPS
+            for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = 0;
+#endif
+            if (job_dict > a.ndicts) c.err = MZD_E_DICT;
+            if (in_frame) { // the frame's context travels with the task; its dictionary content is looked up again
+                c.dict_content = nullptr; c.dict_content_len = 0;
+                if (c.with_dict && job_dict >= 1 && job_dict <= a.ndicts) { c.dict_content = a.dicts[job_dict - 1].content; c.dict_content_len = a.dicts[job_dict - 1].content_len; }
+                c.huf_valid = 1; c.fse_valid = 1; // provisional: what is inherited is checked when it is fetched
+            }
+        }
+        int err = 0;
+        uint32_t action = 0;
+        uint64_t xv = 0, xstripes = 0; // K7 state of the hashing wavefront (wave 2)
+        STAMP_DECL;
+
+        // ---------------- frame header (K0): a task that does not continue a frame starts at one (or at the file's end)
+        bool frame_first = false;
+        if (!in_frame) {
+            for (;;) {
+                if (tid == 0 && !c.err) parse_frame_or_skip(src, n, a.dicts, a.ndicts, job_dict);
+                WG_SNAPSHOT(err = c.err; action = c.action);
+                if (err || action != 1) break; // 1: a skippable frame was skipped, look again
+            }
+            frame_first = !err && action != 2;
+            if (frame_first && action == 3) { // dictionary: entropy tables, repeat offsets and content
+                const DevDict* dd = &a.dicts[job_dict - 1];
+                if (dd->formatted) {
+                    for (int i = tid; i < 512; i += kWG) { S.ll[i] = dd->ll[i]; S.ml[i] = dd->ml[i]; }
+                    for (int i = tid; i < 256; i += kWG) S.of[i] = dd->of[i];
+                    for (int i = tid; i < 2048; i += kWG) S.huf[i] = dd->huf[i];
+                    if (tid == 0) {
+                        c.al[0] = dd->al[0]; c.al[1] = dd->al[1]; c.al[2] = dd->al[2];
+                        c.huf_log = dd->huf_log; c.huf_valid = 1; c.fse_valid = 1;
+                        c.rep[0] = dd->rep[0]; c.rep[1] = dd->rep[1]; c.rep[2] = dd->rep[2];
+                    }
+                }
+                if (tid == 0) { c.dict_content = dd->content; c.dict_content_len = dd->content_len; c.with_dict = 1; }
+            }
+        }
+        const bool hashing = c.has_cksum != 0; // (garbage without a frame; unused then)
+
+        // ---------------- block header, and the successor is pushed before anything is decoded
+        bool have_block = !err && (in_frame || frame_first);
+        uint32_t btype = 0, bsize = 0, last = 0;
+        uint64_t pos0 = 0;
+        if (have_block) {
+            if (tid == 0) parse_block_header(src, n);
+            WG_SNAPSHOT(err = c.err; btype = c.btype; bsize = c.bsize; last = c.last; pos0 = c.pos);
+            if (err) have_block = false;
+        }
+        bool is_final = true; // no successor: this task closes the file
+        if (have_block) {
+            const uint64_t body_end = pos0 + (btype == 1 ? 1u : bsize);
+            uint64_t next_pos = body_end;
+            bool push = !last;
+            if (last) { // the next frame, if any, starts behind the optional checksum
+                const bool ck_ok = !hashing || n - body_end >= 4; // a truncated checksum is reported by this task
+                next_pos = body_end + (hashing ? 4 : 0);
+                push = ck_ok && next_pos < n;
+            }
+            if (push) {
+                is_final = false;
+                if (tid == 0) {
+                    const uint32_t m = atomicAdd(&a.counter[2], 1u);
+                    ContRecord* r = &a.ring[m % a.ring_cap];
+                    g_st(&r->job, j); g_st(&r->task, t + 1); g_st(&r->pos, next_pos); g_st(&r->in_frame, last ? 0u : 1u); g_st(&r->with_dict, c.with_dict);
+                    g_st(&r->has_fcs, c.has_fcs); g_st(&r->has_cksum, c.has_cksum); g_st(&r->block_max, c.block_max); g_st(&r->fcs, c.fcs);
+                    g_settle();
+                    __hip_atomic_store(&r->seq, ((uint64_t)a.epoch << 32) | (uint64_t)(m + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+
+        // ---------------- the block
+        uint64_t out0 = 0, frame_start = 0, out_end = 0;
+        bool pred_loaded = false; // (workgroup-uniform) c.pred_* is filled in
+        if (have_block && btype < 2) { // K6 raw / RLE: nothing to decode ahead; wait for the predecessor, then copy / fill
+            if (tid == 0) { load_pred(fs, t); }
+            int perr = 0;
+            WG_SNAPSHOT(perr = c.pred_err; out0 = c.pred_out; frame_start = frame_first ? c.pred_out : c.pred_frame_out0);
+            if (t && wave == 2) g_acquire(); // the hash reads what the predecessor wrote
+            pred_loaded = true;
+            out_end = out0;
+            if (!perr) {
+                if (bsize > cap - out0) { if (tid == 0) c.err = MZD_E_DSTSIZE; }
+                else {
+                    if (btype == 0) wg_copy(dst + out0, src + pos0, bsize, tid);
+                    else wg_fill(dst + out0, src[pos0], bsize, tid);
+                    out_end = out0 + bsize;
+                }
+            }
+            if (tid == 0) { c.out = out_end; c.pos = pos0 + (btype == 1 ? 1u : bsize); }
+            __syncthreads();
+            if (wave == 2 && hashing && !perr) { // this block's stripes (K7 state travels from task to task)
+                xv = frame_first ? xxh_init(lane) : c.pred_xxh[lane & 3];
+                xstripes = frame_first ? 0 : c.pred_xstripes;
+                xxh_advance(xv, xstripes, (out_end - frame_start) / 32, dst + frame_start, lane);
+            }
+        } else if (have_block) {
+            const uint8_t* const blk = src + pos0;
+            STAMP(0);
+            // K0/K1/K3 headers: where everything is; nothing is decoded yet.  The two header regions
+            // (<= 256 bytes each: literals header + tree extent + jump table; sequence count, modes and
+            // the three normalized-count headers) are staged in LDS first, so that lane 0's byte-wise
+            // parsing does not pay an HBM round trip per byte.
+            TSTART();
+            for (uint32_t k = tid; k < bsize && k < 256; k += kWG) S.stage[k] = blk[k];
+            __syncthreads();
+            if (tid == 0) {
+                c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = 0;
+                c.next_stream = 0; c.streams_done = 0; c.streams_mask = 0;
+                c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.seq_parsed = 0;
+                c.rep_op[0] = 0 | (1 << 2) | (2 << 4); c.rep_op[1] = 0; c.rep_op[2] = 0; c.rep_op[3] = 0; // identity: a block without sequences
+                parse_literals(S.stage, bsize);
+            }
+            uint32_t lit_type = 0, nlit = 0, streams = 0, nseq = 0, seq_len = 0;
+            uint64_t lit_off = 0, seq_off = 0;
+            WG_SNAPSHOT(err = c.err; lit_type = c.lit_type; nlit = c.nlit; streams = c.streams; lit_off = c.lit_off;
+                        seq_off = c.seq_off; seq_len = c.seq_len);
+            if (!err) {
+                for (uint32_t k = tid; k < seq_len && k < 256; k += kWG) S.stage[256 + k] = src[seq_off + k];
+                __syncthreads();
+                STAMP(1);
+                // The sequence header (three normalized-count descriptions: a serial bit parse) is read by lane 0 of
+                // the walking wavefront INSIDE the pipeline, so the literal side (Huffman tree, streams) starts at once.
+                auto get_seq = [&]() -> bool { // nseq / seq_off / seq_len once the header is parsed; false: the block failed
+                    if (!spin_ge(&c.seq_parsed, 1, &c.err) || __atomic_load_n(&c.err, __ATOMIC_RELAXED)) return false;
+                    nseq = c.nseq; seq_off = c.seq_off; seq_len = c.seq_len;
+                    return true;
+                };
+                const uint8_t* const lit = lit_type == 0 ? src + lit_off : lit_buf;
+                // K2 worker: take Huffman streams from the block's queue until none is left
+                // 2 KiB of LDS per decoding wavefront, borrowed from buffers that are idle while literals decode: the
+                // copier's staging buffers (wave 1); the walker's ring (waves 0, 3: they decode after the walk)
+                uint8_t* const hseg = wave == 1 ? S.stage + 2064 : (wave == 2 ? S.hseg2 : (wave == 0 ? S.ring : S.ring + 4096));
+                // A block without sequences IS its literals: the Huffman streams are then decoded straight into the
+                // output (no literal buffer, no copy), provided they fit and the output position is already known
+                // (first task of a file) -- decided once the sequence header is parsed.
+                auto lit_in_place = [&]() -> bool { return lit_type >= 2 && nseq == 0 && t == 0 && nlit <= cap; };
+                auto huf_streams = [&](uint32_t max_take) {
+                    const uint32_t hl = c.huf_log;
+                    uint8_t* const lbase = lit_in_place() ? dst : lit_buf;
+                    for (uint32_t took = 0; took < max_take; took++) {
+                        // every lane takes part (lanes != 0 add 0): no divergent region around the returning atomic
+                        uint32_t st = __atomic_fetch_add(&c.next_stream, lane == 0 ? 1u : 0u, __ATOMIC_RELAXED);
+                        st = (uint32_t)__builtin_amdgcn_readfirstlane(st);
+                        if (st >= streams || st >= 4) break;
+                        int r = 0;
+                        if (!__atomic_load_n(&c.err, __ATOMIC_RELAXED))
+                            r = huf_stream_wave(blk + c.s_off[st], c.s_len[st], lbase + c.s_out[st], c.s_n[st], hl, hseg, lane);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) { post_err(&c.err, r); __atomic_fetch_or(&c.streams_mask, 1u << st, __ATOMIC_RELAXED); __atomic_fetch_add(&c.streams_done, 1u, __ATOMIC_RELAXED); }
+                    }
+                };
+                // wavefronts 0 and 3 decode literals too once their own role is over (at once in a block without sequences)
+                auto huf_helper = [&]() {
+                    if (lit_type < 2) return;
+                    if (!spin_ge(&c.huf_fill, 2, &c.err)) return;
+                    if (!get_seq()) return;
+                    huf_streams(4);
+                };
+                // the file's tables at version t (what the predecessor left): one lane waits, the wavefront copies
+                auto wait_tables = [&]() -> bool {
+                    int ok = 1;
+                    if (lane == 0) ok = g_wait_ge(&fs->tables_ver, t) ? 1 : 0;
+                    ok = __builtin_amdgcn_readfirstlane(ok);
+                    return ok != 0;
+                };
+                // ---- the block pipeline, one role per wavefront:
+                //   wave 0  K3 tables, K4a serial state walk
+                //   wave 1  K1/K2 literals (first stream), then the copying half of K5 (after the predecessor)
+                //   wave 2  K2 literals (other streams), then K7 hashing behind the copier
+                //   wave 3  publishes the tables for the successor, K4b field conversion + repeat offsets + positions (the plan)
+                if (wave == 0) {
+                    if (lane == 0) parse_seq_header(S.stage + 256, seq_len);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) flag_store(&c.seq_parsed, 1);
+                    TFIN(6);
+                    if (get_seq() && nseq) {
+                        int rc = 0;
+                        const bool inherit = !frame_first && (c.mode[0] == 3 || c.mode[1] == 3 || c.mode[2] == 3);
+                        if (inherit) { // repeat mode: the table the previous block used (another workgroup built it)
+                            if (!wait_tables()) rc = MZD_E_DEVICE;
+                            else if (!g_ld(&fs->fse_valid)) rc = MZD_E_CORRUPT;
+                            else {
+                                if (c.mode[0] == 3) { for (int i = lane; i < 512; i += 64) S.ll[i] = g_ld(&ta->ll[i]); if (lane == 0) c.al[0] = g_ld(&fs->al[0]); }
+                                if (c.mode[1] == 3) { for (int i = lane; i < 256; i += 64) S.of[i] = g_ld(&ta->of[i]); if (lane == 0) c.al[1] = g_ld(&fs->al[1]); }
+                                if (c.mode[2] == 3) { for (int i = lane; i < 512; i += 64) S.ml[i] = g_ld(&ta->ml[i]); if (lane == 0) c.al[2] = g_ld(&fs->al[2]); }
+                            }
+                        }
+                        if (!rc) build_tables_wave(lane);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) { post_err(&c.err, rc); flag_store(&c.tables_ready, 1); }
+                        STAMP(4);
+                        TFIN(5);
+                        if (!rc) {
+                            __builtin_amdgcn_s_setprio(MZD_PRIO_WALK); // the chain is the critical path: win issue arbitration on this SIMD
+                            rc = walk_sequences_wave(src + seq_off, seq_len, nseq, walk, &c.walk_prog, lane);
+                            __builtin_amdgcn_s_setprio(0);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) {
+                            post_err(&c.err, rc);
+                            flag_store(&c.walk_prog, rc ? kWalkFin : (nseq | kWalkFin)); // a failed walk publishes nothing
+                        }
+                        STAMP(5);
+                        TFIN(0);
+                    }
+                    huf_helper();
+                } else if (wave == 3) {
+                    const bool seq_ok = get_seq();
+                    // ---- the successor's inheritance: once this block's tables are final (and whatever it inherits itself has
+                    // been read), the kinds it rebuilt go to the file's table area and the version moves on
+                    if (seq_ok && !is_final) { // (a file's last task has nobody to publish for)
+                        bool ok = true;
+                        if (nseq) ok = spin_ge(&c.tables_ready, 1, &c.err);
+                        if (ok && lit_type >= 2) ok = spin_ge(&c.huf_fill, 2, &c.err);
+                        if (ok && !__atomic_load_n(&c.err, __ATOMIC_RELAXED) && wait_tables()) {
+                            if (!last) {
+                                const bool fse_new = nseq != 0 || (frame_first && c.fse_valid), huf_new = lit_type == 2 || (frame_first && c.huf_valid);
+                                if (fse_new) {
+                                    for (int i = lane; i < 512; i += 64) { g_st(&ta->ll[i], S.ll[i]); g_st(&ta->ml[i], S.ml[i]); }
+                                    for (int i = lane; i < 256; i += 64) g_st(&ta->of[i], S.of[i]);
+                                }
+                                if (huf_new) for (int i = lane; i < 1024; i += 64) g_st(&reinterpret_cast<uint32_t*>(ta->huf)[i], reinterpret_cast<const uint32_t*>(S.huf)[i]);
+                                if (lane == 0) {
+                                    if (fse_new) { g_st(&fs->al[0], c.al[0]); g_st(&fs->al[1], c.al[1]); g_st(&fs->al[2], c.al[2]); g_st(&fs->fse_valid, 1u); }
+                                    else if (frame_first) g_st(&fs->fse_valid, 0u);
+                                    if (huf_new) { g_st(&fs->huf_log, c.huf_log); g_st(&fs->huf_valid, 1u); }
+                                    else if (frame_first) g_st(&fs->huf_valid, 0u);
+                                }
+                            }
+                            g_settle();
+                            if (lane == 0) { g_store(&fs->tables_ver, t + 1); c.tables_published = 1; }
+                        }
+                    }
+                    if (seq_ok && nseq) {
+                        int rc = MZD_E_CORRUPT;
+                        if (spin_ge(&c.tables_ready, 1, &c.err)) {
+                            PlanCtx px{walk, src + seq_off, &c.walk_prog, nlit, frame_first ? 1u : 0u, {c.rep[0], c.rep[1], c.rep[2]}};
+                            __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
+                            rc = plan_wave(seqs, nseq, px, lane);
+                            __builtin_amdgcn_s_setprio(0);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) {
+                            post_err(&c.err, rc);
+                            flag_store(&c.plan_prog, flag_load(&c.plan_prog) | kPlanFin);
+                        }
+                        TFIN(3);
+                    }
+                    huf_helper(); // the ring (its staging area) is free: the walker has finished before the planner does
+                } else {
+                    int rc = 0;
+                    // the literals gate the copier (the tail of the block): the copying wavefront's tree + first stream run
+                    // at the copier's priority, the remaining streams just below
+                    if (wave == 1) __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); else __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
+                    if (lit_type >= 2) { // K1: the Huffman table, by wavefront 1: built from this block's tree or inherited
+                        if (wave == 1) {
+                            int hr = 0;
+                            if (lit_type == 2) {
+                                const uint32_t tl = c.huf_tree_len; // <= 129 bytes
+                                for (uint32_t k = (uint32_t)lane; k < tl + 8; k += 64) S.stage[1024 + k] = k < tl ? blk[c.huf_tree_off + k] : 0;
+                                int used = 1;
+                                if (lane == 0) used = read_huf_weights_staged(1024, c.huf_tree_len);
+                                used = __builtin_amdgcn_readfirstlane(used);
+                                TFIN(7);
+                                hr = used <= 0 ? MZD_E_CORRUPT : finish_huf_table_wave(lane);
+                            } else if (!frame_first) { // treeless: the table of the previous compressed-literals block
+                                if (!wait_tables()) hr = MZD_E_DEVICE;
+                                else if (!g_ld(&fs->huf_valid)) hr = MZD_E_CORRUPT;
+                                else {
+                                    for (int i = lane; i < 1024; i += 64) reinterpret_cast<uint32_t*>(S.huf)[i] = g_ld(&reinterpret_cast<const uint32_t*>(ta->huf)[i]);
+                                    if (lane == 0) c.huf_log = g_ld(&fs->huf_log);
+                                }
+                            }
+                            if (lane == 0 && hr) post_err(&c.err, hr);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) flag_store(&c.huf_fill, 2);
+                            TFIN(8);
+                        }
+                        spin_ge(&c.huf_fill, 2, &c.err);
+                    }
+                    const bool failed = __atomic_load_n(&c.err, __ATOMIC_RELAXED) != 0;
+                    if (lit_type == 1) { // RLE literals
+                        uint32_t w = (uint32_t)src[lit_off] * 0x01010101u;
+                        for (uint32_t k = (uint32_t)(tid - 64) * 16; k < nlit; k += 128 * 16)
+                            *reinterpret_cast<uint4*>(lit_buf + k) = make_uint4(w, w, w, w); // lit_buf has slack past nlit
+                    } else if (lit_type >= 2 && !failed && get_seq()) { // K2: the copying wavefront decodes one stream and then
+                        huf_streams(wave == 1 && !lit_in_place() ? 1u : 4u); // copies behind the literals; wavefront 2 (and idle ones) drain the queue
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) {
+                        post_err(&c.err, rc);
+                        __atomic_fetch_add(&c.lit_done, 1u, __ATOMIC_RELAXED);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                    STAMP(3);
+                    if (wave == 1) TFIN(4);
+                    if (wave == 1) { // the copying half of K5: it needs the predecessor's output, position and repeat offsets
+                        if (lane == 0) { load_pred(fs, t); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); flag_store(&c.pred_ready, 1); }
+                        spin_ge(&c.pred_ready, 1, &c.err);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        if (t) g_acquire(); // the predecessor's output (another XCD's L2 may have held it)
+                        const uint64_t o0 = c.pred_out;
+                        uint64_t opos = o0;
+                        rc = 0;
+                        if (c.pred_err) rc = 0; // the file has already failed: nothing to copy (the error travels on)
+                        else if (!get_seq() || (lit_type == 1 && !spin_ge(&c.lit_done, 2, &c.err))) rc = MZD_E_CORRUPT;
+                        else {
+                            const uint64_t fstart = frame_first ? o0 : c.pred_frame_out0;
+                            CopyCtx cx{seqs, dst, fstart, c.dict_content, c.dict_content_len, lit_in_place() ? dst : lit, nlit, cap, lit_type >= 2 ? streams : 0u,
+                                       {frame_first ? c.rep[0] : c.pred_rep[0], frame_first ? c.rep[1] : c.pred_rep[1], frame_first ? c.rep[2] : c.pred_rep[2]},
+                                       a.debug ? seqs : nullptr};
+                            TFIN(9);
+                            __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); // second on the critical path, behind the walker
+                            rc = copy_wave(nseq, cx, &opos, lane);
+                            __builtin_amdgcn_s_setprio(0);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) {
+                            post_err(&c.err, rc);
+                            c.out = opos; c.pos = pos0 + bsize;
+                            flag_store(&c.exec_done, 1);
+                            if (a.debug) {
+                                DebugSlot& ds = a.debug[blockIdx.x];
+                                ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0 || lit_in_place(); ds.lit_raw_ptr = (uint64_t)(uintptr_t)(lit_in_place() ? dst : lit);
+                                if (j == 0) atomicMax(&a.counter[1], (t << 12) | blockIdx.x); // the slot that ran the last compressed block of job 0
+                            }
+                        }
+                        STAMP(6);
+                        TFIN(1);
+                    } else if (hashing) { // wave 2, K7: hash behind the copier while it works (state from the predecessor)
+                        if (spin_ge(&c.pred_ready, 1, &c.err)) {
+                            if (t) g_acquire();
+                            if (!c.pred_err) {
+                                const uint64_t fstart = frame_first ? c.pred_out : c.pred_frame_out0;
+                                xv = frame_first ? xxh_init(lane) : c.pred_xxh[lane & 3];
+                                xstripes = frame_first ? 0 : c.pred_xstripes;
+                                const uint8_t* fp = dst + fstart;
+                                for (uint32_t it = 0; it < (1u << 24); it++) {
+                                    const uint32_t fin = flag_load(&c.exec_done);
+                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                    const uint64_t pos = fin ? c.out : __atomic_load_n(&c.exec_pos, __ATOMIC_RELAXED);
+                                    uint64_t upto = pos > fstart ? (pos - fstart) / 32 : 0;
+                                    if (!fin) upto = upto >= xstripes + 64 ? xstripes + ((upto - xstripes) & ~7ull) : xstripes; // >= 2 KiB at a time, whole groups of 8 stripes
+                                    if (upto > xstripes) xxh_advance(xv, xstripes, upto, fp, lane);
+                                    else if (fin || __atomic_load_n(&c.err, __ATOMIC_RELAXED)) break;
+                                    else __builtin_amdgcn_s_sleep(8);
+                                    if (fin) break;
+                                }
+                            }
+                        }
+                        TFIN(2);
+                    }
+                }
+            }
+            WG_SNAPSHOT(err = c.err);
+            STAMP(6);
+            pred_loaded = c.pred_ready != 0;
+        }
+
+        // ---------------- completion, in task order: frame trailer (K7), then the state for the successor
+        __syncthreads();
+        if (tid == 0 && !pred_loaded) load_pred(fs, t);
+        int perr = 0;
+        uint64_t pred_out = 0, fstart = 0, out_now = 0, pos_now = 0;
+        uint32_t has_ck = 0;
+        WG_SNAPSHOT(perr = c.pred_err; pred_out = c.pred_out; fstart = frame_first ? c.pred_out : c.pred_frame_out0; err = c.err; out_now = c.out; pos_now = c.pos; has_ck = c.has_cksum; last = c.last);
+        if (!have_block) out_now = pred_out; // a task without a block (end of file, or a header error) produces nothing
+        int final_err = perr ? perr : err;
+        if (!final_err && have_block && last) { // frame trailer: content size and checksum
+            if (tid == 0) {
+                if (c.has_fcs && out_now - fstart != c.fcs) c.err = MZD_E_CORRUPT;
+                else if (has_ck && n - pos_now < 4) c.err = MZD_E_TRUNCATED;
+            }
+            WG_SNAPSHOT(err = c.err);
+            if (!err && has_ck) {
+                if (wave == 2) {
+                    xxh_advance(xv, xstripes, (out_now - fstart) / 32, dst + fstart, lane);
+                    uint64_t h = xxh_finish(xv, dst + fstart, out_now - fstart, lane);
+                    if (lane == 0) {
+#ifndef MZD_EXP_NOHASH
+                        if ((uint32_t)h != ld32(src + pos_now)) c.err = MZD_E_CHECKSUM;
+#endif
+                    }
+                    STAMP(7);
+                }
+                WG_SNAPSHOT(err = c.err);
+            }
+            final_err = err;
+        }
+        // the state for the successor (or the file's result), published in task order
+        if (!is_final) {
+            if (wave == 2) { // K7 state lives in this wavefront's registers
+                if (lane < 4) g_st(&fs->xxh[lane], xv);
+                if (lane == 0) g_st(&fs->xstripes, xstripes);
+            }
+            if (!c.tables_published) { // raw/RLE block, early error: the tables are unchanged, the version still moves on
+                if (tid == 0) c.t_valid = g_wait_ge(&fs->tables_ver, t) ? 1u : 0u;
+                uint32_t ver_ok = 0, hv = 0, fv = 0;
+                WG_SNAPSHOT(ver_ok = c.t_valid; hv = c.huf_valid; fv = c.fse_valid);
+                if (ver_ok) {
+                    if (frame_first && !final_err) { // the frame starts here: what its successors inherit is the dictionary's tables, or nothing
+                        if (fv) {
+                            for (int i = tid; i < 512; i += kWG) { g_st(&ta->ll[i], S.ll[i]); g_st(&ta->ml[i], S.ml[i]); }
+                            for (int i = tid; i < 256; i += kWG) g_st(&ta->of[i], S.of[i]);
+                        }
+                        if (hv) for (int i = tid; i < 1024; i += kWG) g_st(&reinterpret_cast<uint32_t*>(ta->huf)[i], reinterpret_cast<const uint32_t*>(S.huf)[i]);
+                        if (tid == 0) {
+                            g_st(&fs->fse_valid, fv); g_st(&fs->huf_valid, hv); g_st(&fs->huf_log, c.huf_log);
+                            g_st(&fs->al[0], c.al[0]); g_st(&fs->al[1], c.al[1]); g_st(&fs->al[2], c.al[2]);
+                        }
+                    }
+                    g_settle();
+                    __syncthreads();
+                    if (tid == 0) g_store(&fs->tables_ver, t + 1);
+                }
+            }
+            if (tid == 0) {
+                const uint32_t ri0 = frame_first ? c.rep[0] : c.pred_rep[0], ri1 = frame_first ? c.rep[1] : c.pred_rep[1], ri2 = frame_first ? c.rep[2] : c.pred_rep[2];
+                RepOp Rf;
+                if (have_block && btype == 2) { Rf.s = c.rep_op[0]; Rf.v0 = (int32_t)c.rep_op[1]; Rf.v1 = (int32_t)c.rep_op[2]; Rf.v2 = (int32_t)c.rep_op[3]; }
+                else { Rf.s = 0 | (1 << 2) | (2 << 4); Rf.v0 = 0; Rf.v1 = 0; Rf.v2 = 0; }
+                g_st(&fs->rep[0], rep_eval(Rf, 0, ri0, ri1, ri2)); g_st(&fs->rep[1], rep_eval(Rf, 1, ri0, ri1, ri2)); g_st(&fs->rep[2], rep_eval(Rf, 2, ri0, ri1, ri2));
+                g_st(&fs->err, (int32_t)final_err);
+                g_st(&fs->out, final_err ? pred_out : out_now);
+                g_st(&fs->frame_out0, fstart);
+            }
+            // this task's output bytes must be in memory before the successor (possibly on another XCD) is let go:
+            // every wavefront that stored output has waited for its stores (its own fences); one agent-scope release
+            // writes the XCD's L2 back
+            g_settle();
+            __syncthreads();
+            if (tid == 0) { g_release(); g_store(&fs->copied, t + 1); }
+        } else if (tid == 0) { // the file is finished: its result, and one file less to wait for
+            a.jobs[j].out_len = final_err ? pred_out : out_now;
+            a.jobs[j].status = final_err;
+            atomicAdd(&a.counter[3], 1u);
+        }
+        TTASK_END();
         STAMP_FLUSH();
         TFIN_FLUSH();
         __syncthreads();
@@ -2092,10 +2684,11 @@ void launch_dict_kernel(const uint8_t* dict, uint32_t n, DevDict* out, int32_t* 
     hipLaunchKernelGGL(mzd_dict_kernel, dim3(1), dim3(kWG), 0, (hipStream_t)stream, dict, n, out, status);
 }
 
-void* decode_kernel_ptr() { return (void*)mzd_decode_kernel; }
+void* decode_kernel_ptr(int tasks) { return tasks ? (void*)mzd_decode_kernel_tasks : (void*)mzd_decode_kernel_files; }
 
 void launch_decode(const KernelArgs& a, uint32_t grid, void* stream) {
-    hipLaunchKernelGGL(mzd_decode_kernel, dim3(grid), dim3(kWG), 0, (hipStream_t)stream, a);
+    if (a.use_tasks) hipLaunchKernelGGL(mzd_decode_kernel_tasks, dim3(grid), dim3(kWG), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(mzd_decode_kernel_files, dim3(grid), dim3(kWG), 0, (hipStream_t)stream, a);
 }
 
 int kernel_lds_bytes() { return (int)sizeof(Shared); }

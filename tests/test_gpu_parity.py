@@ -98,6 +98,47 @@ def test_dictionary_frames():
 needs_zstd = pytest.mark.skipif(not corpus.have_zstd(), reason="no libzstd shared object to compress a corpus with")
 
 
+@pytest.mark.parametrize("driver", ["1", "2"])
+def test_both_drivers_decode_every_vector(driver, monkeypatch):
+    """The library has two kernel drivers: one workgroup per file (launches whose capacities are all <= 128 KiB) and
+    block tasks (the blocks of a frame on different workgroups: tables, repeat offsets, output position and checksum
+    state handed from task to task).  Forced through MZD_DRIVER, each must decode every positive vector (single- and
+    multi-block, multi-frame, skippable, windows > 128 KiB) byte-exactly, in one batch and one by one, and report the
+    oracle's error class on every negative vector."""
+    monkeypatch.setenv("MZD_DRIVER", driver)
+    vs = [v for v in VECS if v.ok and v.dict is None]
+    res = mzd.decode_batch([v.comp for v in vs], [v.out_len for v in vs])
+    bad = [(v.name, st) for v, (st, out) in zip(vs, res) if st != 0 or out != v.expected()]
+    assert not bad, bad
+    for v in vs:
+        if len(v.comp) > (64 << 10) or v.out_len > (128 << 10): # the multi-block ones again, alone (few workgroups busy)
+            st, out = mzd.decode(v.comp, v.out_len)
+            assert st == 0 and out == v.expected(), v.name
+    for v in [v for v in VECS if not v.ok]:
+        st, _ = mzd.decode(v.comp, 1 << 22)
+        assert st == v.oracle_class, (v.name, st, v.oracle_class)
+    dv = [v for v in VECS if v.ok and v.dict is not None]
+    if dv:
+        did = mzd.load_dict(dv[0].dict)
+        for v, (st, out) in zip(dv, mzd.decode_batch([v.comp for v in dv], [v.out_len for v in dv], [did] * len(dv))):
+            assert st == 0 and out == v.expected(), v.name
+
+
+@needs_zstd
+@pytest.mark.parametrize("driver", ["1", "2"])
+def test_multi_block_corpus_both_drivers(driver, monkeypatch):
+    """Seeded files of 4 KiB .. 1 MiB (up to 8 blocks, treeless literals and repeat tables between them) in one batch."""
+    monkeypatch.setenv("MZD_DRIVER", driver)
+    sizes = [4096, 200000, 1 << 20, 131073, 70000, 1 << 20, 300000, 4096, 655360, 131072, 262144, 99999] * 3
+    for kind in ("json", "text", "xray", "repeats"):
+        cp = corpus.build_corpus(kind, 7, sizes)
+        res = mzd.decode_batch([cp.comp_file(i).tobytes() for i in range(len(sizes))], sizes)
+        for i, (st, out) in enumerate(res):
+            assert st == 0 and out == cp.raw_file(i).tobytes(), (kind, i, sizes[i], st)
+
+
+
+
 @needs_zstd
 @pytest.mark.parametrize("kind,level", [("json", 3), ("json", 1), ("json", 19), ("text", 3), ("markup", 9), ("int32", 3),
                                         ("dna", 3), ("xray", 3), ("random", 3), ("repeats", 3)])

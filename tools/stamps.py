@@ -33,5 +33,5 @@ if ns > 0:
     arr = np.frombuffer(buf, dtype=np.uint64)[: ns * 12].reshape(ns, 12).astype(np.float64)
     arr = arr[arr[:, 0] > 0][: n]
     if len(arr):
-        names6 = ["walker done", "copier done", "hasher done", "planner done", "first literal stream done (copier wave)", "tables ready", "headers parsed", "Huffman weights decoded", "Huffman table filled", "copier started", "(count) Huffman sync rounds that walked", "(count) Huffman sync rounds"]
+        names6 = ["walker done", "copier done", "hasher done", "planner done", "first literal stream done (copier wave)", "tables ready", "headers parsed", "Huffman weights decoded", "Huffman table filled", "copier started", "task start -> block start", "task start -> task end"]
         print("over %d workgroups (cycles after block start): " % len(arr) + "; ".join(("%s mean %.1f max %.0f" % (nm, arr[:, k].mean(), arr[:, k].max())) if nm.startswith("(count)") else ("%s mean %.0fK max %.0fK" % (nm, arr[:, k].mean() / 1e3, arr[:, k].max() / 1e3)) for k, nm in enumerate(names6)))
