@@ -826,13 +826,13 @@ __device__ __forceinline__ uint64_t ring_read64(uint32_t e) {
     return v;
 }
 
-// walk record (16 bytes, unpacked: the four values are consecutive registers, so a record costs one store and no
-// packing instruction): LL, ML, OF state offsets (byte offsets into the tables: 8 * state), g-bit position - 32
+// walk record: x = LL state offset | ML state offset << 12 ; y = (g-bit position - 32) | OF state offset << 21
+//   (state offsets are byte offsets into the tables: 8 * state)
 constexpr uint32_t kWalkBatch = 32; // sequences between two ring checks (<= 89 bits each)
 
 constexpr uint32_t kWalkFin = 0x80000000u;
 
-__device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint4* walk, uint32_t* prog, int lane) {
+__device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint2* walk, uint32_t* prog, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
     // a global (not flat) pointer: flat stores would also count on lgkmcnt, i.e. sit in the LDS waits below
     __attribute__((address_space(1))) uint8_t* gwalk;
@@ -904,8 +904,8 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
             uint32_t ra = (u >> 3) & (kRingBytes - 4);
             uint64_t X;
             __builtin_memcpy(&X, &S.ring[ra], 8);
-            { typedef uint32_t v4u __attribute__((ext_vector_type(4))); v4u rec_ = {vL, vM, vO, Gm}; *(__attribute__((address_space(1))) v4u*)(gwalk + woff) = rec_; }
-            woff += 16;
+            *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(Gm | (vO << 21)) << 32);
+            woff += 8;
             asm volatile("" : "+v"(X)); // keep all four LDS reads in flight together
             const uint32_t hL = (uint32_t)(eL >> 32), hM = (uint32_t)(eM >> 32), hO = (uint32_t)(eO >> 32);
             const uint32_t total = ((hL + hM + hO) >> 8) & 0xFF;
@@ -950,7 +950,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         __builtin_memcpy(&eL, tL + vL, 8);
         __builtin_memcpy(&eM, tM + vM, 8);
         __builtin_memcpy(&eO, tO + vO, 8);
-        { typedef uint32_t v4u __attribute__((ext_vector_type(4))); v4u rec_ = {vL, vM, vO, G - 32}; *(__attribute__((address_space(1))) v4u*)(gwalk + woff) = rec_; }
+        *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = (uint64_t)(vL | (vM << 12)) | ((uint64_t)((G - 32) | (vO << 21)) << 32);
         uint32_t extra = (uint32_t)(eL >> 56) + (uint32_t)(eM >> 56) + (uint32_t)(eO >> 56);
         if (G - Gzero != extra) return MZD_E_CORRUPT; // the bitstream must be consumed exactly
     }
@@ -1068,7 +1068,7 @@ __device__ __forceinline__ void copy_short(uint32_t n, LD ld, ST st) { // n <= 6
 constexpr uint32_t kPlanFin = 0x80000000u;
 
 struct PlanCtx { // what the planning wavefront needs
-    const uint4* walk;       // state-walk records of the block (HBM scratch)
+    const uint2* walk;       // state-walk records of the block (HBM scratch)
     const uint8_t* seq_sp;   // the block's sequence bitstream
     const uint32_t* prog;    // walker progress (LDS)
     uint32_t nlit;
@@ -1115,10 +1115,10 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         return (pg & ~kWalkFin) >= need;
     };
     struct Win { uint32_t hL, hM, hO, G; uint64_t bO, bM, bL; }; // entry words + raw 8-byte windows of one sequence
-    auto load_rec = [&](uint32_t idx) -> uint4 { return idx < nseq ? cx.walk[idx] : make_uint4(0, 0, 0, 0); };
-    auto issue_bits = [&](uint4 w, bool live, Win& o) {
-        const uint32_t vL = w.x, vM = w.y, vO = w.z;
-        o.G = w.w + 32; // records carry the read head - 32
+    auto load_rec = [&](uint32_t idx) -> uint2 { return idx < nseq ? cx.walk[idx] : make_uint2(0, 0); };
+    auto issue_bits = [&](uint2 w, bool live, Win& o) {
+        const uint32_t vL = w.x & 0xFFF, vM = w.x >> 12, vO = w.y >> 21;
+        o.G = (w.y & 0x1FFFFF) + 32; // records carry the read head - 32
         o.hL = (uint32_t)(S.ll[vL >> 3] >> 32); o.hM = (uint32_t)(S.ml[vM >> 3] >> 32); o.hO = (uint32_t)(S.of[vO >> 3] >> 32);
         o.bO = 0; o.bM = 0; o.bL = 0;
         if (live) {
@@ -1128,7 +1128,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         }
     };
     if (!wait_walker(128)) return MZD_E_CORRUPT;
-    uint4 recA = load_rec((uint32_t)lane), recB = load_rec(64 + (uint32_t)lane); // chunks 0 and 1
+    uint2 recA = load_rec((uint32_t)lane), recB = load_rec(64 + (uint32_t)lane); // chunks 0 and 1
     Win win;
     issue_bits(recA, (uint32_t)lane < nseq, win);
     uint32_t chunk = 0;
@@ -1141,7 +1141,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         if (lane == 0) flag_store(&S.c.plan_prog, chunk);
         // stage 1: records of chunk k+2, bit windows of chunk k+1 (recB arrived an iteration ago)
         if (!wait_walker(base + 192)) return MZD_E_CORRUPT; // the walker failed (it posted the error) or never got there
-        const uint4 recC = load_rec(base + 128 + (uint32_t)lane);
+        const uint2 recC = load_rec(base + 128 + (uint32_t)lane);
         Win next;
         issue_bits(recB, base + 64 + (uint32_t)lane < nseq, next);
         // stage 2: fields of chunk k from the windows issued an iteration ago
@@ -1779,7 +1779,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* const lit_buf = a.lit_scratch + (size_t)blockIdx.x * kLitStride;
     uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
-    uint4* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
+    uint2* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
@@ -2123,7 +2123,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* const lit_buf = a.lit_scratch + (size_t)blockIdx.x * kLitStride;
     uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
-    uint4* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
+    uint2* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
