@@ -39,6 +39,7 @@ WORKLOADS = {
     "cfg3": ("text", 3, 7, "Silesia-proxy mix as 128 KiB single-block frames, level 3 (BASELINE configs[2]; Silesia itself is not on the box)"),
     "cfg4": ("json", 4, 0, "4 KiB JSON files, parallel-files.fio shape (BASELINE configs[3])"),
     "cfg4lu": ("json", 4, 0, "JSON files log-uniform 4 KiB..1 MiB (BASELINE configs[3] variant)"),
+    "cfg5": ("json", 5, 0, "JSON records of 300..3000 B, one shared ZDICT-trained dictionary (BASELINE configs[4]; 50 000 files per GPU by default)"),
 }
 
 
@@ -47,6 +48,10 @@ def file_sizes(workload, nfiles, rank, world):
         return [131072] * nfiles
     if workload == "cfg4":
         return [4096] * nfiles
+    if workload == "cfg5":
+        rng = np.random.RandomState(55)
+        allsz = rng.randint(300, 3001, size=nfiles * world)
+        return [int(x) for x in allsz[rank::world]]
     rng = np.random.RandomState(1234)  # same table on every rank; rank r takes entries r, r+world, ...
     allsz = np.exp(rng.uniform(np.log(4096), np.log(1 << 20), size=nfiles * world)).astype(np.int64)
     return [int(x) for x in allsz[rank::world]]
@@ -115,6 +120,23 @@ def cpu_baseline(cp, budget_s=10.0):
             "sample": "first %d files, oracle/zstd_oracle.c through ctypes, repeated for %.0f s" % (n, budget_s)}
 
 
+def cpu_baseline_dict(cp, dictionary, budget_s=10.0):
+    """Config 5: libzstd with the shared dictionary, one thread (ZSTD_decompress_usingDict through ctypes; the per-call
+    overhead of the binding is part of the figure), on as many files as fit the time budget."""
+    import oracle
+    if not oracle.LibZstd.available():
+        return {"value": None, "unit": "GiB/s", "cores": 1, "kind": "reference", "sample": "no libzstd on this host"}
+    t0 = time.time(); done = 0; n = 0
+    while time.time() - t0 < budget_s and n < cp.nfiles:
+        out = oracle.LibZstd.decompress(cp.comp_file(n).tobytes(), int(cp.raw_sizes[n]), dictionary=dictionary)
+        assert not isinstance(out, int) and len(out) == int(cp.raw_sizes[n])
+        done += len(out); n += 1
+    tt = time.time() - t0
+    return {"value": round(done / tt / GIB, 3), "unit": "GiB/s", "cores": 1, "kind": "reference",
+            "impl": "libzstd %s ZSTD_decompress_usingDict via ctypes" % oracle.LibZstd.version(),
+            "sample": "first %d files of the workload, one thread (%.1f s)" % (n, tt)}
+
+
 def recorded_traffic(workload):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
@@ -154,16 +176,21 @@ def main():
     mzd.init([local_rank])  # raises when the HIP library / GPU is missing: no fallback
 
     kind, cfg_id, kind_mod, desc = WORKLOADS[args.workload]
-    nfiles = args.files or (10000 if args.workload == "cfg4" else 1000)
+    nfiles = args.files or {"cfg4": 10000, "cfg4lu": 10000, "cfg5": 50000}.get(args.workload, 1000)
     sizes = file_sizes(args.workload, nfiles, rank, world)
-    cp = corpus.build_corpus(kind, cfg_id, sizes, first_index=rank, stride=world, level=args.level, kind_mod=kind_mod)
+    dictionary, dict_id = None, 0
+    if args.workload == "cfg5":  # trained on the first 4 000 records, 110 KiB cap; the same dictionary on every rank
+        tr = np.random.RandomState(55).randint(300, 3001, size=4000)
+        dictionary = corpus.train_dict(kind, cfg_id, [int(x) for x in tr], cap=112640)
+        dict_id = mzd.load_dict(dictionary)
+    cp = corpus.build_corpus(kind, cfg_id, sizes, first_index=rank, stride=world, level=args.level, kind_mod=kind_mod, dictionary=dictionary)
     C = int(cp.comp_sizes.sum()); U = int(cp.raw_sizes.sum())
 
     comp_d = torch.from_numpy(cp.comp).to(dev)  # cp.comp carries >= 64 bytes of zero padding (MZD_SRC_PADDING)
     out_offs = cp.raw_offs
     out_d = torch.zeros(int(out_offs[-1] + cp.raw_sizes[-1]) + 64, dtype=torch.uint8, device=dev)
     jobs = mzd.api.make_jobs([comp_d.data_ptr() + int(o) for o in cp.comp_offs], cp.comp_sizes,
-                             [out_d.data_ptr() + int(o) for o in out_offs], cp.raw_sizes)
+                             [out_d.data_ptr() + int(o) for o in out_offs], cp.raw_sizes, [dict_id] * cp.nfiles if dict_id else None)
     batch = mzd.Batch(0, jobs)
     stream = torch.cuda.Stream(dev)  # a real (non-NULL) stream: the kernel and the timing events share it
     sp = stream.cuda_stream
@@ -238,7 +265,7 @@ def main():
                          "algorithmic_bytes_per_launch": C + U},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cp, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(cp, args.cpu_seconds) if dictionary is None else cpu_baseline_dict(cp, dictionary, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     batch.free()
     if world > 1:

@@ -39,6 +39,10 @@ def lib():
         L.corpus_build.restype = C.c_int
         L.corpus_build.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.corpus_build_dict.restype = C.c_int
+        L.corpus_build_dict.argtypes = L.corpus_build.argtypes + [C.c_void_p, C.c_size_t]
+        L.corpus_train_dict.restype = C.c_long
+        L.corpus_train_dict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint]
         _lib = L
     return _lib
 
@@ -79,7 +83,7 @@ class Corpus:
         return self.comp[o:o + n]
 
 
-def build_corpus(kind, cfg_id, sizes, first_index=0, stride=1, level=3, checksum=True, kind_mod=0, nthreads=None, align=16):
+def build_corpus(kind, cfg_id, sizes, first_index=0, stride=1, level=3, checksum=True, kind_mod=0, nthreads=None, align=16, dictionary=None):
     """Generate + compress len(sizes) files with indices first_index + i*stride.  kind_mod>0 cycles kinds kind..kind+kind_mod-1 by index
     (the Silesia-proxy mix).  Compressed frames are packed at `align`-byte boundaries."""
     L = lib()
@@ -103,8 +107,10 @@ def build_corpus(kind, cfg_id, sizes, first_index=0, stride=1, level=3, checksum
     comp_sizes = np.zeros(n, dtype=np.uint64)
     if nthreads is None:
         nthreads = min(os.cpu_count() or 1, 32)
-    rc = L.corpus_build(k, kind_mod, cfg_id, first_index, stride, n, raw_offs.ctypes.data, sizes.ctypes.data, raw.ctypes.data,
-                        tmp.ctypes.data, tmp_offs.ctypes.data, comp_sizes.ctypes.data, level, 1 if checksum else 0, nthreads)
+    dbuf = np.frombuffer(bytes(dictionary), dtype=np.uint8) if dictionary else None
+    rc = L.corpus_build_dict(k, kind_mod, cfg_id, first_index, stride, n, raw_offs.ctypes.data, sizes.ctypes.data, raw.ctypes.data,
+                             tmp.ctypes.data, tmp_offs.ctypes.data, comp_sizes.ctypes.data, level, 1 if checksum else 0, nthreads,
+                             dbuf.ctypes.data if dbuf is not None else None, len(dbuf) if dbuf is not None else 0)
     if rc != 0:
         raise RuntimeError("corpus_build failed: %d" % rc)
     a = np.uint64(align - 1)
@@ -116,3 +122,17 @@ def build_corpus(kind, cfg_id, sizes, first_index=0, stride=1, level=3, checksum
         o, t, c = int(comp_offs[i]), int(tmp_offs[i]), int(comp_sizes[i])
         comp[o:o + c] = tmp[t:t + c]
     return Corpus(raw, raw_offs, sizes, comp, comp_offs, comp_sizes)
+
+
+def train_dict(kind, cfg_id, sizes, cap=112640, first_index=0):
+    """ZDICT_trainFromBuffer on the files first_index .. of a config (the first 4 000 records, 110 KiB cap)."""
+    L = lib()
+    if L.corpus_open_zstd(None) != 0:
+        raise RuntimeError("no libzstd shared object found")
+    blob = b"".join(gen(kind, cfg_id, first_index + i, int(s)) for i, s in enumerate(sizes))
+    szs = (C.c_size_t * len(sizes))(*[int(s) for s in sizes])
+    buf = C.create_string_buffer(cap)
+    r = L.corpus_train_dict(buf, cap, blob, szs, len(sizes))
+    if r < 0:
+        raise RuntimeError("ZDICT_trainFromBuffer failed (%d)" % r)
+    return buf.raw[:r]

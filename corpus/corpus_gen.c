@@ -186,6 +186,8 @@ static size_t (*p_freeCCtx)(void*);
 static size_t (*p_CCtx_setParameter)(void*, int, int);
 static size_t (*p_compress2)(void*, void*, size_t, const void*, size_t);
 static const char* (*p_versionString)(void);
+static size_t (*p_CCtx_loadDictionary)(void*, const void*, size_t); /* optional (config 5) */
+static size_t (*p_trainFromBuffer)(void*, size_t, const void*, const size_t*, unsigned); /* optional */
 #define SYM(v, name) do { *(void**)(&v) = dlsym(H, name); if (!v) return -2; } while (0)
 
 int corpus_open_zstd(const char* path) {
@@ -198,6 +200,8 @@ int corpus_open_zstd(const char* path) {
     SYM(p_isError, "ZSTD_isError"); SYM(p_compressBound, "ZSTD_compressBound"); SYM(p_createCCtx, "ZSTD_createCCtx");
     SYM(p_freeCCtx, "ZSTD_freeCCtx"); SYM(p_CCtx_setParameter, "ZSTD_CCtx_setParameter"); SYM(p_compress2, "ZSTD_compress2");
     SYM(p_versionString, "ZSTD_versionString");
+    *(void**)(&p_CCtx_loadDictionary) = dlsym(H, "ZSTD_CCtx_loadDictionary");
+    *(void**)(&p_trainFromBuffer) = dlsym(H, "ZDICT_trainFromBuffer");
     return 0;
 }
 const char* corpus_zstd_version(void) { return H ? p_versionString() : ""; }
@@ -208,11 +212,16 @@ typedef struct {
     const uint64_t* raw_offs; const uint64_t* raw_sizes; uint8_t* raw;
     uint8_t* comp; const uint64_t* comp_offs; uint64_t* comp_sizes;
     int level, checksum; volatile uint32_t* next; int fail;
+    const uint8_t* dict; size_t dict_len; /* config 5: every file is compressed with this dictionary (or NULL) */
 } build_arg;
 
 static void* build_worker(void* v) {
     build_arg* a = (build_arg*)v;
     void* c = p_createCCtx();
+    if (a->dict && a->dict_len) {
+        p_CCtx_setParameter(c, 100, a->level); /* the dictionary is digested for this level; it stays loaded across compress2 calls */
+        if (!p_CCtx_loadDictionary || p_isError(p_CCtx_loadDictionary(c, a->dict, a->dict_len))) { a->fail = 1; p_freeCCtx(c); return NULL; }
+    }
     for (;;) {
         uint32_t i = __sync_fetch_and_add(a->next, 1);
         if (i >= a->nfiles) break;
@@ -236,17 +245,36 @@ static void* build_worker(void* v) {
  * kind_base + (index % kind_mod) (kind_mod 0 => always kind_base).  raw/comp are caller
  * buffers laid out by raw_offs / comp_offs (comp slots must hold corpus_bound(raw_size)).
  * Each file is ONE frame written like the reference writer: level, checksum, pledged size. */
+int corpus_build_dict(int kind_base, int kind_mod, uint64_t cfg_id, uint64_t first_index, uint64_t stride, uint32_t nfiles,
+                      const uint64_t* raw_offs, const uint64_t* raw_sizes, uint8_t* raw,
+                      uint8_t* comp, const uint64_t* comp_offs, uint64_t* comp_sizes,
+                      int level, int checksum, int nthreads, const uint8_t* dict, size_t dict_len);
 int corpus_build(int kind_base, int kind_mod, uint64_t cfg_id, uint64_t first_index, uint64_t stride, uint32_t nfiles,
                  const uint64_t* raw_offs, const uint64_t* raw_sizes, uint8_t* raw,
                  uint8_t* comp, const uint64_t* comp_offs, uint64_t* comp_sizes,
                  int level, int checksum, int nthreads) {
+    return corpus_build_dict(kind_base, kind_mod, cfg_id, first_index, stride, nfiles, raw_offs, raw_sizes, raw, comp, comp_offs, comp_sizes,
+                             level, checksum, nthreads, NULL, 0);
+}
+
+/* ZDICT_trainFromBuffer over `n` samples laid out back to back; returns the dictionary size or < 0. */
+long corpus_train_dict(uint8_t* dict, size_t cap, const uint8_t* samples, const size_t* sizes, unsigned n) {
+    if (!H || !p_trainFromBuffer) return -1;
+    size_t r = p_trainFromBuffer(dict, cap, samples, sizes, n);
+    return p_isError(r) ? -2 : (long)r;
+}
+
+int corpus_build_dict(int kind_base, int kind_mod, uint64_t cfg_id, uint64_t first_index, uint64_t stride, uint32_t nfiles,
+                      const uint64_t* raw_offs, const uint64_t* raw_sizes, uint8_t* raw,
+                      uint8_t* comp, const uint64_t* comp_offs, uint64_t* comp_sizes,
+                      int level, int checksum, int nthreads, const uint8_t* dict, size_t dict_len) {
     if (!H) return -1;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
     pthread_t th[64]; build_arg args[64]; volatile uint32_t next = 0;
     for (int t = 0; t < nthreads; t++) {
         build_arg a = {kind_base, kind_mod, cfg_id, first_index, stride ? stride : 1, nfiles, raw_offs, raw_sizes, raw, comp, comp_offs, comp_sizes,
-                       level, checksum, &next, 0};
+                       level, checksum, &next, 0, dict, dict_len};
         args[t] = a;
         pthread_create(&th[t], NULL, build_worker, &args[t]);
     }

@@ -110,6 +110,7 @@ struct Ctl {
     uint32_t dict_content_len;
     const uint8_t* dict_content;
     // the task (one block of one file) and what its predecessor published
+    uint32_t lds_dict_fse, lds_dict_huf;            // driver 1: dictionary (handle) whose FSE / Huffman tables sit unmodified in LDS, or 0
     uint32_t t_valid, task, in_frame, with_dict;
     uint32_t pred_ready;                            // the predecessor's state is in pred_* (LDS flag of the block pipeline)
     int32_t pred_err;
@@ -1269,6 +1270,12 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     const uint64_t cap = u64(cx.cap), frame_start = u64(cx.frame_start);
     const uint32_t dict_len = u32(cx.dict_len), nlit_all = u32(cx.nlit), lit_streams = u32(cx.lit_streams);
     const uint4* const plan = (const uint4*)(uintptr_t)u64((uint64_t)(uintptr_t)cx.plan);
+    const uint8_t* const dict_end = (const uint8_t*)(uintptr_t)u64((uint64_t)(uintptr_t)cx.dict + cx.dict_len); // one past the dictionary content (or null)
+    // where an old match's bytes are: in the output, or -- before the frame start -- in the dictionary
+    auto match_src = [&](int32_t rel_src, uint64_t run_pos) -> const uint8_t* {
+        const int64_t at = (int64_t)run_pos + rel_src - (int64_t)frame_start; // relative to the frame start
+        return at >= 0 ? dst + frame_start + at : dict_end + at;
+    };
     uint64_t opos = *opos_io;
     uint32_t lpos = 0;
     CSTAMP_DECL;
@@ -1327,7 +1334,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         const uint8_t* const b1 = stagebuf(ri.buf1);
         const uint8_t* const b2 = stagebuf(ri.buf2);
         const uint32_t rel_m = r.rel_out + r.ll;
-        if (__any(r.kind == 5)) copy_short(r.kind == 5 ? r.ml : 0u, GlobalLd{dst + ri.run_pos + r.rel_src}, LdsSt{sb + rel_m});
+        if (__any(r.kind == 5)) copy_short(r.kind == 5 ? r.ml : 0u, GlobalLd{match_src(r.rel_src, ri.run_pos)}, LdsSt{sb + rel_m});
         CSTAMP(4);
         // everything whose source is in LDS, in rounds: a copy may start once the output below `ready_at` is complete,
         // and the output is complete up to the match of the first sequence that is still pending
@@ -1407,8 +1414,12 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         lpos += __builtin_amdgcn_readlane(incl_l, 63);
         if (!wait_lits(lpos)) return MZD_E_CORRUPT; // a literal stream failed (the error is posted)
         const uint64_t mdst = opos + ex_t + ll; // absolute match destination
+        // a match that starts before the frame reads the dictionary (config 5: most matches of a small record do).  When
+        // its whole source lies there it is an ordinary old match with another base address; one that runs from the
+        // dictionary into the output takes the long path.
         const bool in_dict = valid && off > mdst - frame_start;
-        const bool islong = valid && (ll > kShort || ml > kShort || in_dict);
+        const bool dict_whole = in_dict && off - (mdst - frame_start) >= ml;
+        const bool islong = valid && (ll > kShort || ml > kShort || (in_dict && !dict_whole));
         const uint64_t longmask = __ballot(islong);
 
         uint32_t a = 0;
@@ -1462,6 +1473,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 const int32_t lim1 = v1 ? (int32_t)T1 : 0, lim2 = lim1 + ((v1 && v2) ? (int32_t)T2 : 0);
                 N.kind = 1;
                 if (!plain) N.bytewise = true;                                                               // overlapping: replicate byte by byte
+                else if (dict_whole) N.kind = N.ml > 31 ? 5 : 4;                                             // in the dictionary: HBM, like older output
                 else if (N.rel_src >= 0) N.src_lds = NI.buf * kBufStride + (uint32_t)N.rel_src;              // inside this run
                 else if (pe_ < 0) N.bytewise = true;                                                         // straddles the run start
                 else if (v1 && pd <= lim1) N.src_lds = NI.buf1 * kBufStride + (uint32_t)(lim1 - pd);         // inside the previous run
@@ -1474,7 +1486,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             //      stay in flight during the long part of the previous run
             if (haveR) finish_regs(R, RI);
             if (!NI.bigl) regs_load<3>(N.ll, GlobalLd{lit + my_lit}, pfL);
-            regs_load<3>(N.kind == 4 ? N.ml : 0u, GlobalLd{dst + run_pos + N.rel_src}, pfO);
+            regs_load<3>(N.kind == 4 ? N.ml : 0u, GlobalLd{match_src(N.rel_src, run_pos)}, pfO);
             if (haveR) finish_rest(R, RI);
             R = N; RI = NI; haveR = true;
             v2 = v1; T2 = T1; v1 = true; T1 = NI.T; runno++;
@@ -1783,6 +1795,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
+    if (tid == 0) { c.lds_dict_fse = 0; c.lds_dict_huf = 0; }
 
     for (;;) {
         if (tid == 0) c.job = atomicAdd(&a.counter[0], 1u);
@@ -1818,10 +1831,18 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
             if (action == 3) { // dictionary: entropy tables, repeat offsets and content
                 const DevDict* dd = &a.dicts[job_dict - 1];
                 if (dd->formatted) {
-                    for (int i = tid; i < 512; i += kWG) { S.ll[i] = dd->ll[i]; S.ml[i] = dd->ml[i]; }
-                    for (int i = tid; i < 256; i += kWG) S.of[i] = dd->of[i];
-                    for (int i = tid; i < 2048; i += kWG) S.huf[i] = dd->huf[i];
+                    // Config 5 (many small frames, one dictionary): a workgroup keeps the dictionary's tables resident in LDS
+                    // from file to file -- such frames use them as they are (repeat-mode tables, treeless literals), so the
+                    // 14 KB copy happens once per workgroup, not once per file.  Any block that rebuilds a table clears the mark.
+                    const bool have_fse = c.lds_dict_fse == job_dict, have_huf = c.lds_dict_huf == job_dict;
+                    __syncthreads();
+                    if (!have_fse) {
+                        for (int i = tid; i < 512; i += kWG) { S.ll[i] = dd->ll[i]; S.ml[i] = dd->ml[i]; }
+                        for (int i = tid; i < 256; i += kWG) S.of[i] = dd->of[i];
+                    }
+                    if (!have_huf) for (int i = tid; i < 2048; i += kWG) S.huf[i] = dd->huf[i];
                     if (tid == 0) {
+                        c.lds_dict_fse = job_dict; c.lds_dict_huf = job_dict;
                         c.al[0] = dd->al[0]; c.al[1] = dd->al[1]; c.al[2] = dd->al[2];
                         c.huf_log = dd->huf_log; c.huf_valid = 1; c.fse_valid = 1;
                         c.rep[0] = dd->rep[0]; c.rep[1] = dd->rep[1]; c.rep[2] = dd->rep[2];
@@ -1923,6 +1944,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                         if (lane == 0) flag_store(&c.seq_parsed, 1);
                         TFIN(6);
                         if (get_seq() && nseq) {
+                            if (lane == 0 && (c.mode[0] != 3 || c.mode[1] != 3 || c.mode[2] != 3)) c.lds_dict_fse = 0; // no longer the dictionary's
                             build_tables_wave(lane);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) flag_store(&c.tables_ready, 1);
@@ -1970,7 +1992,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                             }
                             if (wave == 1) { // weights: serial (lane 0); table: the whole wavefront
                                 int used = 1;
-                                if (lane == 0) used = read_huf_weights_staged(1024, c.huf_tree_len);
+                                if (lane == 0) { c.lds_dict_huf = 0; used = read_huf_weights_staged(1024, c.huf_tree_len); } // (the table is no longer a dictionary's)
                                 used = __builtin_amdgcn_readfirstlane(used);
                                 TFIN(7);
                                 int hr = used <= 0 ? MZD_E_CORRUPT : finish_huf_table_wave(lane);

@@ -156,6 +156,33 @@ def test_seeded_corpus_vs_oracle(kind, level):
 
 
 @needs_zstd
+def test_config5_shape_shared_dictionary():
+    """BASELINE config 5 in small: records of 300..3000 B compressed with one trained dictionary (treeless literals,
+    repeat-mode tables: the dictionary's tables stay resident in LDS from file to file), interleaved with plain frames
+    (which rebuild tables, so the residency marks must be dropped and restored) and with frames of a second dictionary."""
+    rng = np.random.RandomState(5)
+    sizes = [int(x) for x in rng.randint(300, 3001, size=3000)]
+    d1 = corpus.train_dict("json", 5, sizes[:1500])
+    d2 = corpus.train_dict("text", 6, [2000] * 600, cap=40000)
+    c1 = corpus.build_corpus("json", 5, sizes, dictionary=d1)
+    c2 = corpus.build_corpus("text", 6, sizes[:500], dictionary=d2)
+    c0 = corpus.build_corpus("json", 9, sizes[:500])
+    h1, h2 = mzd.load_dict(d1), mzd.load_dict(d2)
+    srcs, caps, dids, want = [], [], [], []
+    for i in range(len(sizes)):
+        srcs.append(c1.comp_file(i).tobytes()); caps.append(sizes[i]); dids.append(h1); want.append(c1.raw_file(i).tobytes())
+        if i % 6 == 0 and i // 6 < 500:
+            k = i // 6
+            srcs.append(c0.comp_file(k).tobytes()); caps.append(sizes[k]); dids.append(0); want.append(c0.raw_file(k).tobytes())
+            srcs.append(c2.comp_file(k).tobytes()); caps.append(sizes[k]); dids.append(h2); want.append(c2.raw_file(k).tobytes())
+    res = mzd.decode_batch(srcs, caps, dids)
+    bad = [(i, st) for i, ((st, out), w) in enumerate(zip(res, want)) if st != 0 or out != w]
+    assert not bad, bad[:10]
+    rc, out = oracle.decode(srcs[0], cap=caps[0], dictionary=d1)
+    assert rc == 0 and out == want[0]
+
+
+@needs_zstd
 def test_config2_shape_device_resident():
     """BASELINE config 2 shape, scaled down to 64 files: 128 KiB single-block JSON frames decoded
     from HBM to HBM through mzd_decode_batch_device; checked against the generator's bytes."""
