@@ -1939,6 +1939,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                     //   wave 2  K2 literals (streams 2,3), then K7 hashing behind the copier
                     //   wave 3  K4b field conversion + repeat offsets + positions (the plan), behind the walker
                     if (wave == 0) {
+                        __builtin_amdgcn_s_setprio(MZD_PRIO_WALK); // header parse, tables and walk are one serial chain: the block's critical path
                         if (lane == 0) parse_seq_header(S.stage + 256, seq_len);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) flag_store(&c.seq_parsed, 1);
@@ -1962,6 +1963,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                             STAMP(5);
                             TFIN(0);
                         }
+                        __builtin_amdgcn_s_setprio(0);
                         huf_helper();
                     } else if (wave == 3) {
                         if (get_seq() && nseq) {
@@ -2364,6 +2366,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                 //   wave 2  K2 literals (other streams), then K7 hashing behind the copier
                 //   wave 3  publishes the tables for the successor, K4b field conversion + repeat offsets + positions (the plan)
                 if (wave == 0) {
+                    __builtin_amdgcn_s_setprio(MZD_PRIO_WALK); // header parse, tables and walk are one serial chain: the block's critical path
                     if (lane == 0) parse_seq_header(S.stage + 256, seq_len);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0) flag_store(&c.seq_parsed, 1);
@@ -2398,6 +2401,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                         STAMP(5);
                         TFIN(0);
                     }
+                    __builtin_amdgcn_s_setprio(0);
                     huf_helper();
                 } else if (wave == 3) {
                     const bool seq_ok = get_seq();
