@@ -261,7 +261,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
                          "traffic": recorded_traffic(args.workload),
-                         "kernel": "mzd_decode_kernel", "kernel_ms_avg": round(kernel_ms, 4), "kernel_ms_last_lib_events": round(last_ms, 4),
+                         "kernel": "mzd_decode_kernel_tasks" if int(cp.raw_sizes.max()) > 131072 else "mzd_decode_kernel_files", "kernel_ms_avg": round(kernel_ms, 4), "kernel_ms_last_lib_events": round(last_ms, 4),
                          "algorithmic_bytes_per_launch": C + U},
         }
         if world == 1 and not args.no_cpu_baseline:
