@@ -673,15 +673,31 @@ __device__ __noinline__ void wg_fill(uint8_t* d, uint32_t byte, uint32_t n, int 
 }
 
 // 64 lanes replicate the `off` bytes before d over d[0..n)  (a match whose source overlaps its
-// destination: byte k = pattern[k mod off])
+// destination: byte k = pattern[k mod off]).  Long ones (zero pages, sparse files: one match can be a
+// whole block) are not done 64 bytes at a time: once at least 4 KiB of the pattern exist, byte k equals byte
+// k - P for any multiple P of off, so the rest is plain 16-byte-per-lane copying from one period back, a period at a
+// time (each period is complete -- and its stores have landed -- before the next one reads it).
 __device__ __noinline__ void wave_pattern(uint8_t* d, uint32_t off, uint32_t n, int lane) {
     const uint8_t* pat = d - off;
-    uint32_t idx = (uint32_t)lane % off;
-    uint32_t step = 64u % off;
-    for (uint32_t k = lane; k < n; k += 64) {
-        d[k] = pat[idx];
-        idx += step;
-        if (idx >= off) idx -= off;
+    uint32_t period = off, done = 0;
+    if (off < 4096) {
+        period = ((4096 + off - 1) / off) * off;
+        const uint32_t head = n < period ? n : period;
+        uint32_t idx = (uint32_t)lane % off;
+        const uint32_t step = 64u % off;
+        for (uint32_t k = lane; k < head; k += 64) {
+            d[k] = pat[idx];
+            idx += step;
+            if (idx >= off) idx -= off;
+        }
+        done = head;
+        wg_fence();
+    }
+    while (done < n) {
+        const uint32_t chunk = n - done < period ? n - done : period;
+        wave_copy(d + done, d + done - period, chunk, lane);
+        done += chunk;
+        wg_fence();
     }
 }
 
