@@ -126,6 +126,34 @@ def test_both_drivers_decode_every_vector(driver, monkeypatch):
 
 @needs_zstd
 @pytest.mark.parametrize("driver", ["1", "2"])
+def test_corrupted_multi_block_files_report_the_oracles_error(driver, monkeypatch):
+    """Single-byte mutations in every block of multi-block frames (and truncations, and too-small outputs): the status
+    must be the oracle's class -- with block tasks an error has to travel from the task that finds it to the task that
+    closes the file, in stream order -- and a decode that still succeeds must produce the oracle's bytes."""
+    monkeypatch.setenv("MZD_DRIVER", driver)
+    rng = np.random.RandomState(77)
+    cases = []
+    for kind, size in (("json", 600000), ("text", 400000), ("xray", 300000), ("repeats", 500000)):
+        cp = corpus.build_corpus(kind, 21, [size])
+        good = cp.comp_file(0).tobytes()
+        for _ in range(24):
+            b = bytearray(good)
+            pos = int(rng.randint(0, len(b)))
+            b[pos] ^= int(rng.randint(1, 256))
+            cases.append((bytes(b), size))
+        for cut in (len(good) - 1, len(good) - 5, len(good) // 2, 40):
+            cases.append((good[:cut], size))
+        for cap in (size - 1, size // 2, 150000, 10):
+            cases.append((good, cap))
+    res = mzd.decode_batch([c for c, _ in cases], [cap for _, cap in cases])
+    for i, ((comp, cap), (st, out)) in enumerate(zip(cases, res)):
+        rc, want = oracle.decode(comp, cap=cap)
+        assert st == rc, (i, cap, st, rc)
+        assert st != 0 or out == want, i
+
+
+@needs_zstd
+@pytest.mark.parametrize("driver", ["1", "2"])
 def test_multi_block_corpus_both_drivers(driver, monkeypatch):
     """Seeded files of 4 KiB .. 1 MiB (up to 8 blocks, treeless literals and repeat tables between them) in one batch."""
     monkeypatch.setenv("MZD_DRIVER", driver)
