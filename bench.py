@@ -9,7 +9,11 @@ single-block JSON frames written like the reference's writer (level 3, checksum,
 src/main.rs:781-791).  With N GPUs every rank takes files r, r+N, r+2N, ... of an N x 1000-file
 corpus (file i -> GPU i mod N, no collective; weak scaling).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg4lu] [--files F]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg4lu|cfg5] [--files F]
+
+The other workloads are BASELINE's remaining configurations (parity cases with a selectable bench line): cfg3 the
+Silesia-proxy mix, cfg4 10 000 x 4 KiB files, cfg4lu 10 000 files log-uniform 4 KiB..1 MiB (multi-block frames:
+the block-task driver), cfg5 50 000 small records with one shared dictionary.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      HBM bound.  achieved = algorithmic bytes per launch (sum of compressed bytes read once

@@ -3,7 +3,7 @@ Races between tasks (hand-over of tables / repeat offsets / positions / checksum
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fuse_zstd_amd as mzd, corpus
-os.environ["MZD_DRIVER"] = "2"
+os.environ.setdefault("MZD_DRIVER", "2")
 mzd.init()
 rng = random.Random(12345)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
