@@ -1261,14 +1261,39 @@ struct CopyCtx {
 //                                 output older than the previous two runs has landed.
 // The HBM reads of a run (its literals and its old matches) are issued one run AHEAD (software
 // pipeline: prepare(run k+1), then finish(run k)), so their latency hides behind the LDS work.
-struct RunRegs { // one lane's share of a prepared run
-    uint32_t ll, ml, off, rel_out;  // ll = ml = 0 on lanes outside the run
-    int32_t rel_src;                // match source relative to the run start
-    uint32_t kind;                  // 0 none, 1 LDS (this run or the two before it), 4 HBM (prefetched), 5 HBM (> 31 bytes, loaded at finish)
-    uint32_t src_lds;               // kind 1, plain copy: byte offset of the source inside S.stage
-    int32_t ready_at;               // kind 1: run-relative output position that must be complete first (INT32_MIN: nothing)
-    bool bytewise;                  // kind 1: overlapping match or a source that straddles buffers: byte by byte
+// Literal runs of 65..~2000 bytes inside a staged run: one after the other, all 64 lanes copy 16 bytes each from the
+// literal buffer (HBM) into the staging buffer (LDS; not 16-byte aligned in general: two 8-byte stores per lane).
+// Out of line: its registers must not count against the copier's main loop.
+__device__ __noinline__ void medium_literals(const uint8_t* lit, uint8_t* sb, uint32_t ll, uint32_t my_lit, uint32_t rel_out, int lane) {
+    uint64_t med = __ballot(ll > kShort);
+    while (med) {
+        const int sl = __builtin_ctzll(med);
+        const uint32_t n = __builtin_amdgcn_readlane(ll, sl), lp = __builtin_amdgcn_readlane(my_lit, sl), ro = __builtin_amdgcn_readlane(rel_out, sl);
+        const uint8_t* const src_ = lit + lp;
+        lds_p const dst_ = (lds_p)(sb + ro);
+        for (uint32_t k = (uint32_t)lane * 16; k + 16 <= n; k += 1024) {
+            uint64_t v0, v1;
+            __builtin_memcpy(&v0, (gcptr)(src_ + k), 8);
+            __builtin_memcpy(&v1, (gcptr)(src_ + k + 8), 8);
+            __builtin_memcpy(dst_ + k, &v0, 8);
+            __builtin_memcpy(dst_ + k + 8, &v1, 8);
+        }
+        const uint32_t t0 = n & ~15u;
+        if (t0 + (uint32_t)lane < n) dst_[t0 + lane] = *(gcptr)(src_ + t0 + lane);
+        med &= med - 1;
+    }
+}
+
+struct RunRegs { // one lane's share of a prepared run (kept small: two of these are live in the copier's loop)
+    uint32_t ll, ml, rel_out;       // ll = ml = 0 on lanes outside the run
+    int32_t rel_src;                // match source relative to the run start (the offset is rel_out + ll - rel_src)
+    uint32_t meta;                  // bits 0-2 kind: 0 none, 1 LDS (this run or the two before it), 4 HBM (prefetched), 5 HBM (> 31 bytes, loaded at finish)
+                                    // bit 3: kind 1 byte by byte (overlapping match, or a source that straddles buffers); bits 4..: kind 1, plain: byte offset of the source in S.stage
+    int32_t ready_at;               // kind 1: run-relative output position that must be complete first
     uint32_t my_lit;
+    __device__ __forceinline__ uint32_t kind() const { return meta & 7; }
+    __device__ __forceinline__ bool bytewise() const { return (meta & 8) != 0; }
+    __device__ __forceinline__ uint32_t src_lds() const { return meta >> 4; }
 };
 struct RunInfo { // wave-uniform
     uint64_t run_pos; uint32_t T, buf; bool bigl;
@@ -1277,12 +1302,12 @@ struct RunInfo { // wave-uniform
 
 __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint64_t* opos_io, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
-    uint8_t* const dst = cx.dst;
-    const uint8_t* const lit = cx.lit;
     // the context lives in the caller's frame (scratch memory): what the loops use is read once, into scalar
     // registers (wave-uniform; the vector registers are all taken); the rare paths read the rest where they need it
     auto u32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     auto u64 = [&](uint64_t v) -> uint64_t { return (uint64_t)u32((uint32_t)v) | ((uint64_t)u32((uint32_t)(v >> 32)) << 32); };
+    uint8_t* const dst = (uint8_t*)(uintptr_t)u64((uint64_t)(uintptr_t)cx.dst);
+    const uint8_t* const lit = (const uint8_t*)(uintptr_t)u64((uint64_t)(uintptr_t)cx.lit);
     const uint64_t cap = u64(cx.cap), frame_start = u64(cx.frame_start);
     const uint32_t dict_len = u32(cx.dict_len), nlit_all = u32(cx.nlit), lit_streams = u32(cx.lit_streams);
     const uint4* const plan = (const uint4*)(uintptr_t)u64((uint64_t)(uintptr_t)cx.plan);
@@ -1327,21 +1352,25 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     bool v1 = false, v2 = false;
     uint32_t T1 = 0, T2 = 0, runno = 0;
     RunRegs R;  RunInfo RI;  bool haveR = false; // the prepared, unfinished run
-    R.ll = R.ml = 0; R.kind = 0;
+    R.ll = R.ml = 0; R.meta = 0;
     // The prefetched HBM bytes of a run (its literals and its old match bytes, <= 31 each per lane).  One set is
     // enough: the loop stores run k's bytes to LDS (finish_regs), THEN issues run k+1's loads into the same
     // registers, and only then does the long part of run k (rounds, flush), which hides the loads' latency.
     // (The compiler waits with vmcnt(0) wherever the number of loads in flight depends on control flow, so
     // nothing else may be outstanding at the point where the registers are consumed.)
-    CopyRegs<3> pfL, pfO;
+    CopyRegs<2> pfL; // literals: <= 23 bytes per lane (longer runs take the straight-from-HBM path of the run)
+    CopyRegs<3> pfO; // old match bytes: <= 31 per lane
 
     // finishing a prepared run, part 1: the prefetched bytes (literals, old matches) go to the staging buffer
     auto finish_regs = [&](RunRegs& r, const RunInfo& ri) {
         uint8_t* const sb = stagebuf(ri.buf);
         CSTAMP(2);
-        if (ri.bigl) copy_short(r.ll, GlobalLd{lit + r.my_lit}, LdsSt{sb + r.rel_out});
-        else regs_store<3>(r.ll, LdsSt{sb + r.rel_out}, pfL);
-        regs_store<3>(r.kind == 4 ? r.ml : 0u, LdsSt{sb + r.rel_out + r.ll}, pfO);
+        if (ri.bigl) { // some literal runs exceed what the prefetch registers hold: up to 64 bytes per lane straight from HBM ...
+            copy_short(r.ll <= kShort ? r.ll : 0u, GlobalLd{lit + r.my_lit}, LdsSt{sb + r.rel_out});
+            medium_literals(lit, sb, r.ll, r.my_lit, r.rel_out, lane); // ... and the longer ones (noisy data: many runs of 65..2000 literals) by all 64 lanes
+        }
+        else regs_store<2>(r.ll, LdsSt{sb + r.rel_out}, pfL);
+        regs_store<3>(r.kind() == 4 ? r.ml : 0u, LdsSt{sb + r.rel_out + r.ll}, pfO);
         CSTAMP(3);
     };
     // part 2: LDS -> LDS copies in rounds, flush
@@ -1350,20 +1379,21 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         const uint8_t* const b1 = stagebuf(ri.buf1);
         const uint8_t* const b2 = stagebuf(ri.buf2);
         const uint32_t rel_m = r.rel_out + r.ll;
-        if (__any(r.kind == 5)) copy_short(r.kind == 5 ? r.ml : 0u, GlobalLd{match_src(r.rel_src, ri.run_pos)}, LdsSt{sb + rel_m});
+        if (__any(r.kind() == 5)) copy_short(r.kind() == 5 ? r.ml : 0u, GlobalLd{match_src(r.rel_src, ri.run_pos)}, LdsSt{sb + rel_m});
         CSTAMP(4);
         // everything whose source is in LDS, in rounds: a copy may start once the output below `ready_at` is complete,
         // and the output is complete up to the match of the first sequence that is still pending
-        bool pending = r.kind == 1;
+        bool pending = r.kind() == 1;
         uint64_t pm = __ballot(pending);
         while (pm) {
             const int first = __builtin_ctzll(pm);
             const int32_t hwm = (int32_t)__builtin_amdgcn_readlane(rel_m, first);
             const bool ready = pending && r.ready_at <= hwm;
-            const bool fast = ready && !r.bytewise;
-            copy_short(fast ? r.ml : 0u, LdsLd{S.stage + r.src_lds}, LdsSt{sb + rel_m});
-            if (__any(ready && r.bytewise)) {
-                if (ready && r.bytewise) {
+            const bool fast = ready && !r.bytewise();
+            copy_short(fast ? r.ml : 0u, LdsLd{S.stage + r.src_lds()}, LdsSt{sb + rel_m});
+            if (__any(ready && r.bytewise())) {
+                if (ready && r.bytewise()) {
+                    const uint32_t off_ = rel_m - (uint32_t)r.rel_src;
                     uint32_t idx = 0;
                     for (uint32_t k = 0; k < r.ml; k++) {
                         const int32_t p = r.rel_src + (int32_t)idx;
@@ -1375,7 +1405,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                         else bv = *(const __attribute__((address_space(1))) uint8_t*)(dst + ri.run_pos + p);
                         sb[rel_m + k] = bv;
                         idx++;
-                        if (idx == r.off) idx = 0;
+                        if (idx == off_) idx = 0;
                     }
                 }
             }
@@ -1435,7 +1465,9 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         // dictionary into the output takes the long path.
         const bool in_dict = valid && off > mdst - frame_start;
         const bool dict_whole = in_dict && off - (mdst - frame_start) >= ml;
-        const bool islong = valid && (ll > kShort || ml > kShort || (in_dict && !dict_whole));
+        // literal runs of up to ~2 KiB stay inside a run (the wavefront copies them into the staging buffer together);
+        // only longer ones, long matches and matches that leave the dictionary go the direct way
+        const bool islong = valid && (ll > kStage - kShort || ml > kShort || (in_dict && !dict_whole));
         const uint64_t longmask = __ballot(islong);
 
         uint32_t a = 0;
@@ -1475,10 +1507,10 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             NI.buf = runno % 3; NI.buf1 = (runno + 2) % 3; NI.buf2 = (runno + 1) % 3;
             NI.v1 = v1; NI.v2 = v2; NI.T1 = T1; NI.T2 = T2;
             const bool act = (uint32_t)lane >= a && (uint32_t)lane < b;
-            N.ll = act ? ll : 0; N.ml = act ? ml : 0; N.off = off; N.rel_out = ex_t - base_t; N.my_lit = my_lit;
+            N.ll = act ? ll : 0; N.ml = act ? ml : 0; N.rel_out = ex_t - base_t; N.my_lit = my_lit;
             const uint32_t rel_m = N.rel_out + N.ll;
             N.rel_src = (int32_t)rel_m - (int32_t)off; // off < 2^31 (validated against the window by the planner)
-            N.kind = 0; N.src_lds = 0; N.bytewise = false;
+            uint32_t kind = 0, src_lds = 0; bool bytewise = false;
             // a copy from LDS may start once the output below source start + min(ml, off) is complete
             // (never positive for sources that lie entirely in the two previous runs)
             N.ready_at = N.rel_src + (int32_t)(N.ml < off ? N.ml : off);
@@ -1487,22 +1519,23 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 const int32_t pd = -N.rel_src;          // distance of the source start before the run start
                 const int32_t pe_ = pd - (int32_t)N.ml; // distance of the source end before the run start (>= 0: entirely older)
                 const int32_t lim1 = v1 ? (int32_t)T1 : 0, lim2 = lim1 + ((v1 && v2) ? (int32_t)T2 : 0);
-                N.kind = 1;
-                if (!plain) N.bytewise = true;                                                               // overlapping: replicate byte by byte
-                else if (dict_whole) N.kind = N.ml > 31 ? 5 : 4;                                             // in the dictionary: HBM, like older output
-                else if (N.rel_src >= 0) N.src_lds = NI.buf * kBufStride + (uint32_t)N.rel_src;              // inside this run
-                else if (pe_ < 0) N.bytewise = true;                                                         // straddles the run start
-                else if (v1 && pd <= lim1) N.src_lds = NI.buf1 * kBufStride + (uint32_t)(lim1 - pd);         // inside the previous run
-                else if (v1 && v2 && pe_ >= lim1 && pd <= lim2) N.src_lds = NI.buf2 * kBufStride + (uint32_t)(lim2 - pd); // inside the run before it
-                else if (pe_ >= lim2 && run_pos - (uint64_t)pe_ + 8 <= cap) N.kind = N.ml > 31 ? 5 : 4;   // older: HBM (may over-read 7 bytes)
-                else N.bytewise = true;                                                                       // straddles two buffers / ends at the buffer end
+                kind = 1;
+                if (!plain) bytewise = true;                                                               // overlapping: replicate byte by byte
+                else if (dict_whole) kind = N.ml > 31 ? 5 : 4;                                             // in the dictionary: HBM, like older output
+                else if (N.rel_src >= 0) src_lds = NI.buf * kBufStride + (uint32_t)N.rel_src;              // inside this run
+                else if (pe_ < 0) bytewise = true;                                                         // straddles the run start
+                else if (v1 && pd <= lim1) src_lds = NI.buf1 * kBufStride + (uint32_t)(lim1 - pd);         // inside the previous run
+                else if (v1 && v2 && pe_ >= lim1 && pd <= lim2) src_lds = NI.buf2 * kBufStride + (uint32_t)(lim2 - pd); // inside the run before it
+                else if (pe_ >= lim2 && run_pos - (uint64_t)pe_ + 8 <= cap) kind = N.ml > 31 ? 5 : 4;   // older: HBM (may over-read 7 bytes)
+                else bytewise = true;                                                                       // straddles two buffers / ends at the buffer end
             }
-            NI.bigl = __any(N.ll > 31);
+            N.meta = kind | (bytewise ? 8u : 0u) | (src_lds << 4);
+            NI.bigl = __any(N.ll > 23);
             // ---- the previous run's prefetched bytes leave the registers; this run's loads take their place and
             //      stay in flight during the long part of the previous run
             if (haveR) finish_regs(R, RI);
-            if (!NI.bigl) regs_load<3>(N.ll, GlobalLd{lit + my_lit}, pfL);
-            regs_load<3>(N.kind == 4 ? N.ml : 0u, GlobalLd{match_src(N.rel_src, run_pos)}, pfO);
+            if (!NI.bigl) regs_load<2>(N.ll, GlobalLd{lit + my_lit}, pfL);
+            regs_load<3>(N.kind() == 4 ? N.ml : 0u, GlobalLd{match_src(N.rel_src, run_pos)}, pfO);
             if (haveR) finish_rest(R, RI);
             R = N; RI = NI; haveR = true;
             v2 = v1; T2 = T1; v1 = true; T1 = NI.T; runno++;
