@@ -4,21 +4,26 @@
 // libzstd 1.5.6 via zstd-sys, reference Cargo.lock:2371-2396), written from the format
 // (RFC 8878) for 64-lane wavefronts.  Not a port of libzstd.
 //
-// Mapping: one workgroup (4 wavefronts) owns one file; a persistent grid pulls files from a
-// work queue.  Per compressed block:
-//   K0  headers                 lane 0                                         (A.1, A.2)
-//   K1  Huffman weights/table   lane 0 decodes the weights, 256 lanes fill     (A.4)
-//   K2  Huffman literals        one wavefront per stream, 64 lanes per stream by
-//                               self-synchronising sub-stream decode + ballot/scan offsets
-//   K3  FSE tables x3           three wavefronts, one table each               (A.3)
-//   K4  FSE sequence decode     one wavefront, wave-uniform; tables in LDS; the backward
-//                               bitstream streamed through an LDS ring by coalesced
-//                               16-B/lane loads                                 (A.5)
-//   K5  sequence execute        one wavefront, 64 sequences per step: scan for positions,
-//                               literal copies, multi-round match resolution    (A.5)
+// Mapping: one workgroup (4 wavefronts, ~34 KB of LDS, 4 workgroups per CU) decodes one block at a time in a
+// persistent grid.  Two drivers share the block pipeline:
+//   mzd_decode_kernel_files   a workgroup owns a file and walks its frames and blocks in order (launches in which
+//                             no file can have more than one block);
+//   mzd_decode_kernel_tasks   one block per task: the blocks of a frame run on different workgroups, the state
+//                             between them (tables, repeat offsets, output position, checksum) is handed over in
+//                             task order.
+// Per compressed block, one role per wavefront, connected by LDS flags and unbounded HBM queues:
+//   K0  headers                 lane 0, from LDS copies; the sequence header inside wavefront 0's role   (A.1, A.2)
+//   K1  Huffman tree            lane 0 decodes the weights, the wavefront validates, ranks and fills      (A.4)
+//   K2  Huffman literals        64 lanes per stream by self-synchronising sub-stream decode (memoized entry
+//                               offsets) + DPP scan for the output offsets; streams handed out by a queue
+//   K3  FSE tables x3           one wavefront, ballot-rank symbol spread                                  (A.3)
+//   K4a FSE state walk          wavefront 0: the serial chain, tables + bitstream ring in LDS, 8-byte records (A.5)
+//   K4b plan                    wavefront 3: fields, symbolic repeat offsets (DPP scan), positions, validation
+//   K5  sequence execute        wavefront 1: runs of <= 64 sequences staged in LDS, prefetched HBM sources,
+//                               LDS->LDS matches in rounds, 16-byte coalesced flushes                     (A.5)
 //   K6  raw / RLE blocks        256 lanes, coalesced
-//   K7  XXH64                   4 lanes (one per accumulator) + lane 0 tail     (A.6)
-// Everything is integer/byte work bound by latency and HBM, so there is no MFMA here.
+//   K7  XXH64                   wavefront 2 behind the copier, groups of 8 stripes                         (A.6)
+// Everything is integer/byte work bound by latency and instruction issue, so there is no MFMA here.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
