@@ -184,6 +184,27 @@ def test_seeded_corpus_vs_oracle(kind, level):
 
 
 @needs_zstd
+@pytest.mark.parametrize("driver", ["1", "2"])
+def test_multi_block_frames_with_a_dictionary(driver, monkeypatch):
+    """Frames of several blocks compressed WITH a dictionary: the first block starts from the dictionary's tables and
+    repeat offsets, later blocks inherit tables from their predecessors (block tasks: through the file's table area)
+    and matches may reach through earlier blocks into the dictionary content."""
+    monkeypatch.setenv("MZD_DRIVER", driver)
+    sizes = [150000, 400000, 131073, 3000, 262144, 700000]
+    d = corpus.train_dict("json", 12, [2500] * 2000)
+    cp = corpus.build_corpus("json", 12, sizes, dictionary=d, first_index=5000)
+    h = mzd.load_dict(d)
+    srcs = [cp.comp_file(i).tobytes() for i in range(len(sizes))]
+    res = mzd.decode_batch(srcs, sizes, [h] * len(sizes))
+    for i, (st, out) in enumerate(res):
+        assert st == 0 and out == cp.raw_file(i).tobytes(), (i, sizes[i], st)
+    rc, out = oracle.decode(srcs[1], cap=sizes[1], dictionary=d)
+    assert rc == 0 and out == cp.raw_file(1).tobytes()
+    st, _ = mzd.decode(srcs[1], sizes[1])  # the same frame without its dictionary
+    assert st == oracle.decode(srcs[1], cap=sizes[1])[0] != 0
+
+
+@needs_zstd
 def test_config5_shape_shared_dictionary():
     """BASELINE config 5 in small: records of 300..3000 B compressed with one trained dictionary (treeless literals,
     repeat-mode tables: the dictionary's tables stay resident in LDS from file to file), interleaved with plain frames
