@@ -244,3 +244,48 @@ def test_concurrent_opens_are_decoded_in_batches():
         assert files == n and batches <= n // 4, log  # sixteen session threads feed one batcher: many files per launch
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_real_mount_when_the_container_allows_it(data_dir):
+    """Where /dev/fuse exists and mount(2) is permitted (the build container: root; not the GPU box) the daemon is
+    mounted for real and the KERNEL is the client: names, sizes and refusals as the reference's mount shows them.
+    Without a GPU an open fails with EFAULT ("Bad address") -- exactly what a decode failure looks like through the mount."""
+    import time
+    import torch
+    if not os.path.exists("/dev/fuse") or os.geteuid() != 0:
+        pytest.skip("no /dev/fuse or not root")
+    d, vecs = data_dir
+    build_daemon()
+    mnt = tempfile.mkdtemp(prefix="mzd_mnt_")
+    proc = subprocess.Popen([BIN, "--data-dir", d, "--mount", mnt, "--threads", "2"], stderr=subprocess.PIPE)
+    try:
+        for _ in range(50):
+            if os.path.ismount(mnt) or proc.poll() is not None:
+                break
+            time.sleep(0.1)
+        if not os.path.ismount(mnt):
+            pytest.skip("mount(2) is not permitted here")
+        assert sorted(os.listdir(mnt)) == sorted(["json_4k", "json_128k", "json_1m", "ref_writer_01", "multi_frame_skippable", "sub", "broken"])
+        assert os.listdir(os.path.join(mnt, "sub")) == ["inner"]
+        st = os.stat(os.path.join(mnt, "json_4k"))
+        assert (st.st_mode & 0o777) == 0o666
+        with pytest.raises(OSError) as ei:
+            open(os.path.join(mnt, "nope"), "rb")
+        assert ei.value.errno == errno.ENOENT
+        with pytest.raises(OSError) as ei:
+            open(os.path.join(mnt, "newfile"), "wb")
+        assert ei.value.errno == errno.EROFS
+        if torch.cuda.is_available():
+            assert open(os.path.join(mnt, "json_128k"), "rb").read() == vecs["json_128k"].expected()
+            assert os.stat(os.path.join(mnt, "json_128k")).st_size == len(vecs["json_128k"].expected())
+        else:
+            with pytest.raises(OSError) as ei:
+                open(os.path.join(mnt, "json_4k"), "rb").read()
+            assert ei.value.errno == errno.EFAULT
+    finally:
+        subprocess.call(["umount", "-l", mnt])
+        try:
+            proc.communicate(timeout=20)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+        shutil.rmtree(mnt, ignore_errors=True)
