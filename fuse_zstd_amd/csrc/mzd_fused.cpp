@@ -41,6 +41,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <list>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -60,6 +61,8 @@ struct Decoded { // the decoded bytes of one inode, shared by all its open handl
 struct Options {
     std::string data_dir, mount_point;
     int fd = -1, threads = 4, batch_us = 200, batch_max = 256;
+    int ahead = 0;          // decode-ahead: on a miss, also decode the next `ahead` files of the directory (0 = off)
+    size_t cache_mb = 256;  // bytes the decode-ahead cache may hold
 };
 
 uint64_t be64(const uint8_t* p) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[i]; return v; }
@@ -79,6 +82,18 @@ public:
         std::unique_lock<std::mutex> lk(it->mu);
         it->cv.wait(lk, [&] { return it->done; });
         return it->out;
+    }
+    // several files at once (decode-ahead): all are queued before anything is waited for, so they share a launch
+    std::vector<std::shared_ptr<Decoded>> decode_many(std::vector<std::vector<uint8_t>> srcs) {
+        std::vector<std::shared_ptr<Item>> its;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (auto& sv : srcs) { auto it = std::make_shared<Item>(); it->src = std::move(sv); q_.push_back(it); its.push_back(it); }
+        }
+        cv_.notify_all();
+        std::vector<std::shared_ptr<Decoded>> out;
+        for (auto& it : its) { std::unique_lock<std::mutex> lk(it->mu); it->cv.wait(lk, [&] { return it->done; }); out.push_back(it->out); }
+        return out;
     }
     uint64_t files() const { return files_; }
     uint64_t batches() const { return batches_; }
@@ -242,19 +257,27 @@ public:
             auto it = by_ino_.find(ino);
             if (it != by_ino_.end()) d = it->second.lock();
         }
+        if (!d) d = cache_take(ino); // decoded ahead of this open
         if (!d) {
-            std::vector<uint8_t> src;
-            int fd = ::open(abs(rel).c_str(), O_RDONLY);
-            if (fd < 0) return errno;
-            struct stat st;
-            if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { int e = errno ? errno : EISDIR; close(fd); return e; }
-            src.resize((size_t)st.st_size);
-            size_t got = 0;
-            while (got < src.size()) { ssize_t r = ::read(fd, src.data() + got, src.size() - got); if (r <= 0) break; got += (size_t)r; }
-            close(fd);
-            if (got != src.size()) return EIO;
-            d = batcher_.decode(std::move(src));
+            // the file itself, and -- with decode-ahead -- the next files of its directory: sequential readers (fio's
+            // parallel-files pattern, tar, grep -r) will ask for them next, and a launch is cheaper per file the more it holds
+            std::vector<std::string> rels{rel};
+            if (opt_.ahead > 0) for (auto& r : followers(rel, (size_t)opt_.ahead)) rels.push_back(r);
+            std::vector<std::vector<uint8_t>> srcs;
+            std::vector<std::string> got;
+            for (size_t i = 0; i < rels.size(); i++) {
+                std::vector<uint8_t> src;
+                int e = slurp(abs(rels[i]), &src);
+                if (e) { if (i == 0) return e; continue; }
+                srcs.push_back(std::move(src)); got.push_back(rels[i]);
+            }
+            auto outs = batcher_.decode_many(std::move(srcs));
+            d = outs[0];
+            for (size_t i = 1; i < outs.size(); i++)
+                if (outs[i]->status == MZD_OK) cache_put(inode_for(got[i]), outs[i]);
             if (d->status != MZD_OK) return EFAULT; // reference src/main.rs:467: every decode failure
+        }
+        {
             uint8_t b[8];
             put_be64(b, d->bytes.size());
             (void)setxattr(abs(rel).c_str(), "user.real_size", b, 8, 0);
@@ -270,6 +293,68 @@ public:
         handles_[*fh] = d;
         return 0;
     }
+    static int slurp(const std::string& path, std::vector<uint8_t>* out) {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return errno;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { int e = errno ? errno : EISDIR; close(fd); return e; }
+        out->resize((size_t)st.st_size);
+        size_t got = 0;
+        while (got < out->size()) { ssize_t r = ::read(fd, out->data() + got, out->size() - got); if (r <= 0) break; got += (size_t)r; }
+        close(fd);
+        return got == out->size() ? 0 : EIO;
+    }
+    // the next `n` .zst files after `rel` in its directory (name order) that are neither open nor cached
+    std::vector<std::string> followers(const std::string& rel, size_t n) {
+        const size_t slash = rel.rfind('/');
+        const std::string dir = slash == std::string::npos ? "" : rel.substr(0, slash), base = slash == std::string::npos ? rel : rel.substr(slash + 1);
+        std::vector<std::string> names;
+        if (DIR* dp = opendir(abs(dir).c_str())) {
+            while (dirent* de = ::readdir(dp)) {
+                std::string nm = de->d_name;
+                if (nm.size() > 4 && nm.compare(nm.size() - 4, 4, ".zst") == 0 && nm > base) names.push_back(nm);
+            }
+            closedir(dp);
+        }
+        std::sort(names.begin(), names.end());
+        std::vector<std::string> out;
+        for (auto& nm : names) {
+            if (out.size() >= n) break;
+            const std::string r = (dir.empty() ? "" : dir + "/") + nm;
+            const uint64_t ino = inode_for(r);
+            std::lock_guard<std::mutex> lk(mu_);
+            auto it = by_ino_.find(ino);
+            if ((it != by_ino_.end() && !it->second.expired()) || cache_idx_.count(ino)) continue;
+            out.push_back(r);
+        }
+        return out;
+    }
+    std::shared_ptr<Decoded> cache_take(uint64_t ino) {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = cache_idx_.find(ino);
+        if (it == cache_idx_.end()) return nullptr;
+        auto d = it->second->second;
+        cache_bytes_ -= d->bytes.size();
+        cache_.erase(it->second);
+        cache_idx_.erase(it);
+        hits_++;
+        return d;
+    }
+    void cache_put(uint64_t ino, std::shared_ptr<Decoded> d) {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (cache_idx_.count(ino)) return;
+        cache_.emplace_front(ino, d);
+        cache_idx_[ino] = cache_.begin();
+        cache_bytes_ += d->bytes.size();
+        while (cache_bytes_ > opt_.cache_mb * (1u << 20) && cache_.size() > 1) { // oldest out
+            auto& last = cache_.back();
+            cache_bytes_ -= last.second->bytes.size();
+            cache_idx_.erase(last.first);
+            cache_.pop_back();
+        }
+    }
+public:
+    uint64_t hits() const { return hits_; }
     std::shared_ptr<Decoded> handle(uint64_t fh) {
         std::lock_guard<std::mutex> lk(mu_);
         auto it = handles_.find(fh);
@@ -288,6 +373,10 @@ private:
     std::map<uint64_t, std::weak_ptr<Decoded>> by_ino_;
     std::map<uint64_t, std::shared_ptr<Decoded>> handles_;
     uint64_t next_fh_ = 1, ino_idx_ = UINT64_MAX - 1;
+    std::list<std::pair<uint64_t, std::shared_ptr<Decoded>>> cache_; // decoded ahead, not opened yet (newest first)
+    std::map<uint64_t, std::list<std::pair<uint64_t, std::shared_ptr<Decoded>>>::iterator> cache_idx_;
+    size_t cache_bytes_ = 0;
+    std::atomic<uint64_t> hits_{0};
 };
 
 // ---- the session: requests in, replies out
@@ -455,7 +544,7 @@ private:
 };
 
 int usage() {
-    fprintf(stderr, "usage: mzd_fused --data-dir DIR (--mount DIR | --fd N) [--threads T] [--batch-us U] [--batch-max B]\n");
+    fprintf(stderr, "usage: mzd_fused --data-dir DIR (--mount DIR | --fd N) [--threads T] [--batch-us U] [--batch-max B] [--ahead N] [--cache-mb M]\n");
     return 2;
 }
 
@@ -472,6 +561,8 @@ int main(int argc, char** argv) {
         else if (a == "--threads") o.threads = atoi(val());
         else if (a == "--batch-us") o.batch_us = atoi(val());
         else if (a == "--batch-max") o.batch_max = atoi(val());
+        else if (a == "--ahead") o.ahead = atoi(val());
+        else if (a == "--cache-mb") o.cache_mb = (size_t)atol(val());
         else return usage();
     }
     if (o.data_dir.empty() || (o.mount_point.empty() && o.fd < 0)) return usage();
@@ -495,7 +586,8 @@ int main(int argc, char** argv) {
         std::vector<std::thread> th;
         for (int t = 0; t < o.threads; t++) th.emplace_back([&] { s.serve(); });
         for (auto& t : th) t.join();
-        fprintf(stderr, "mzd_fused: %llu files decoded in %llu batches\n", (unsigned long long)fs.batcher().files(), (unsigned long long)fs.batcher().batches());
+        fprintf(stderr, "mzd_fused: %llu files decoded in %llu batches, %llu opens served from decode-ahead\n", (unsigned long long)fs.batcher().files(),
+                (unsigned long long)fs.batcher().batches(), (unsigned long long)fs.hits());
     }
     if (o.fd < 0) umount2(o.mount_point.c_str(), MNT_DETACH);
     mzd_shutdown();

@@ -34,10 +34,10 @@ def build_daemon():
 
 
 class FakeKernel:
-    def __init__(self, data_dir, threads=4, batch_us=2000):
+    def __init__(self, data_dir, threads=4, batch_us=2000, extra=()):
         build_daemon()
         self.k, d = socket.socketpair(socket.AF_UNIX, socket.SOCK_SEQPACKET)
-        self.proc = subprocess.Popen([BIN, "--data-dir", data_dir, "--fd", str(d.fileno()), "--threads", str(threads), "--batch-us", str(batch_us)],
+        self.proc = subprocess.Popen([BIN, "--data-dir", data_dir, "--fd", str(d.fileno()), "--threads", str(threads), "--batch-us", str(batch_us)] + list(extra),
                                      pass_fds=[d.fileno()], stderr=subprocess.PIPE)
         d.close()
         self.k.settimeout(60)
@@ -240,8 +240,8 @@ def test_concurrent_opens_are_decoded_in_batches():
             assert k.read(inos[i], fhs[i], 0, 1 << 20)[1] == cp.raw_file(i).tobytes(), i
         rc, log = k.close()
         assert rc == 0
-        files, batches = [int(x) for x in log.split("mzd_fused:")[-1].split() if x.isdigit()]
-        assert files == n and batches <= n // 4, log  # sixteen session threads feed one batcher: many files per launch
+        files, batches, hits = [int(x) for x in log.split("mzd_fused:")[-1].replace(",", " ").split() if x.isdigit()]
+        assert files == n and batches <= n // 4 and hits == 0, log  # sixteen session threads feed one batcher: many files per launch
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -293,3 +293,32 @@ def test_real_mount_when_the_container_allows_it(data_dir):
         except subprocess.TimeoutExpired:
             proc.kill()
         shutil.rmtree(mnt, ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_decode_ahead_serves_a_sequential_reader_from_few_launches():
+    """One reader opening the files of a directory one after the other (tar, grep -r, one fio job): with --ahead N a miss
+    decodes the next N files of the directory in the same launch, the following opens are served from that."""
+    import corpus
+    if not corpus.have_zstd():
+        pytest.skip("no libzstd to build a corpus with")
+    d = tempfile.mkdtemp(prefix="mzd_fused_seq_")
+    try:
+        n = 64
+        cp = corpus.build_corpus("json", 43, [4096 + 131 * i for i in range(n)])
+        for i in range(n):
+            with open(os.path.join(d, "f%03d.zst" % i), "wb") as f:
+                f.write(cp.comp_file(i).tobytes())
+        k = FakeKernel(d, threads=2, batch_us=100, extra=["--ahead", "15"])
+        for i in range(n):
+            err, ino, _ = k.lookup(1, "f%03d" % i)
+            err, fh = k.open(ino)
+            assert err == 0
+            assert k.read(ino, fh, 0, 1 << 20)[1] == cp.raw_file(i).tobytes(), i
+            assert k.getattr(ino)[1][1] == int(cp.raw_sizes[i])
+            assert k.release(ino, fh) == 0
+        rc, log = k.close()
+        files, batches, hits = [int(x) for x in log.split("mzd_fused:")[-1].replace(",", " ").split() if x.isdigit()]
+        assert rc == 0 and files == n and batches == n // 16 and hits == n - n // 16, log
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
