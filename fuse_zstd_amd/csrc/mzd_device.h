@@ -99,7 +99,7 @@ struct KernelArgs {
     uint32_t* counter;    // see above; zeroed per launch
     uint8_t* lit_scratch; // kLitStride bytes per workgroup
     uint4* seq_scratch;   // kSeqStride uint4 per workgroup
-    uint2* walk_scratch;  // kSeqStride uint2 per workgroup (state-walk records)
+    uint4* walk_scratch;  // kSeqStride uint4 per workgroup (state-walk records: LL, ML, OF state offsets, read head - 32)
     const DevDict* dicts;
     uint32_t ndicts;
     DebugSlot* debug;     // gridDim.x entries

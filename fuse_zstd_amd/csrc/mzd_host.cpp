@@ -43,7 +43,7 @@ struct Device {
     uint32_t max_wg = 0;
     uint8_t* lit_scratch = nullptr;
     uint4* seq_scratch = nullptr;
-    uint2* walk_scratch = nullptr;
+    uint4* walk_scratch = nullptr;
     DebugSlot* debug = nullptr;
     uint32_t* counter = nullptr; // [0] tickets, [1] task << 12 | slot of the last compressed block of job 0, [2] pushes, [3] files finished
     FileState* fstate = nullptr;  // per file of a launch: what a block task hands to its successor
@@ -97,7 +97,7 @@ int init_device(Device& d, int hip_id) {
     d.max_wg = (uint32_t)(cus * per_cu);
     HIPCHK(hipMalloc(&d.lit_scratch, (size_t)d.max_wg * kLitStride));
     HIPCHK(hipMalloc(&d.seq_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
-    HIPCHK(hipMalloc(&d.walk_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint2)));
+    HIPCHK(hipMalloc(&d.walk_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
     HIPCHK(hipMalloc(&d.debug, (size_t)d.max_wg * sizeof(DebugSlot)));
     HIPCHK(hipMemset(d.debug, 0, (size_t)d.max_wg * sizeof(DebugSlot)));
     HIPCHK(hipMalloc(&d.counter, 64));

@@ -115,6 +115,7 @@ struct Ctl {
     uint32_t dict_content_len;
     const uint8_t* dict_content;
     // the task (one block of one file) and what its predecessor published
+    uint32_t huf_pre;                               // driver 1: this block's Huffman table was built ahead (pre_parse_next)
     uint32_t lds_dict_fse, lds_dict_huf;            // driver 1: dictionary (handle) whose FSE / Huffman tables sit unmodified in LDS, or 0
     uint32_t t_valid, task, in_frame, with_dict;
     uint32_t pred_ready;                            // the predecessor's state is in pred_* (LDS flag of the block pipeline)
@@ -147,6 +148,10 @@ struct __attribute__((aligned(16))) Shared {
     uint32_t wtab[64];  // sym | nb << 8 | base << 16
     uint8_t weights[256];
     Ctl c;
+    // driver 1, files of one block: while the copier and the hasher finish file A, the idle walking wavefront takes the
+    // next file and parses its headers into `c2` (header bytes staged in a free part of the ring)
+    Ctl c2;
+    uint32_t pre_job, pre_valid; // the job taken ahead (kNoJob: none) and whether c2 holds its parsed first block
 };
 
 // The workgroup's LDS image.  File scope, so that every device function addresses it with DS
@@ -318,7 +323,7 @@ __device__ void rle_seq_table(uint64_t* tab, uint32_t s, int kind) { tab[0] = pa
 // ------------------------------------------------------------------------------------ K1
 // Huffman tree description (A.4) -> S.weights[0..nw), S.c.huf_log.  Lane 0.  Returns bytes used or < 0.
 template <class LD>
-__device__ __forceinline__ int read_huf_weights_t(LD ld, uint32_t n) {
+__device__ __forceinline__ int read_huf_weights_t(LD ld, uint32_t n, uint16_t* next) { // `next`: 512 bytes of scratch for the weights' FSE table build
     if (n < 1) return MZD_E_CORRUPT;
     auto byte_at = [&](uint32_t o) -> uint32_t { return (uint32_t)(ld(o) & 0xFF); };
     // bits [bitpos, bitpos+nb) of the little-endian integer made of bytes [base, base+len); indices < 0 read as 0; nb <= 16
@@ -353,7 +358,6 @@ __device__ __forceinline__ int read_huf_weights_t(LD ld, uint32_t n) {
         if (hdr <= 0) return MZD_E_CORRUPT;
         // tiny FSE table (<= 64 entries) built in place
         uint32_t size = 1u << log, high = size;
-        uint16_t* next = (uint16_t*)(void*)(S.stage + 1536); // the copier's staging buffer is idle until the literals exist ([256, 512) holds the sequence header, [1024, 1161) the tree)
         for (uint32_t s = 0; s < nsym; s++)
             if (S.wnorm[s] == -1) { high--; S.wtab[high] = s; next[s] = 1; }
         uint32_t step = (size >> 1) + (size >> 3) + 3, pos = 0, mask = size - 1;
@@ -412,8 +416,17 @@ __device__ __forceinline__ int read_huf_weights_t(LD ld, uint32_t n) {
     S.c.huf_nw = nw; // the implied last weight, the validation and the table come from finish_huf_table_wave
     return used;
 }
-__device__ __noinline__ int read_huf_weights(const uint8_t* src, uint32_t n) { return read_huf_weights_t(HbmBytes{src}, n); }               // dictionary (HBM)
-__device__ __noinline__ int read_huf_weights_staged(uint32_t stage_off, uint32_t n) { return read_huf_weights_t(StageBytes{stage_off}, n); } // a block's tree, staged in LDS
+// (scratch: the copier's staging buffer is idle until the literals exist; [256, 512) holds the sequence header, [1024, 1161) the tree)
+__device__ __noinline__ int read_huf_weights(const uint8_t* src, uint32_t n) { return read_huf_weights_t(HbmBytes{src}, n, (uint16_t*)(void*)(S.stage + 1536)); }               // dictionary (HBM)
+struct RingBytes { // offset into S.ring
+    uint32_t base;
+    __device__ __forceinline__ uint64_t operator()(uint32_t o) const { uint64_t v; __builtin_memcpy(&v, &S.ring[base + o], 8); return v; }
+};
+__device__ __noinline__ int read_ncount_ring(uint32_t ring_off, uint32_t n, int max_log, int max_sym, int16_t* norm, uint32_t* nsym_out, uint32_t* log_out) {
+    return read_ncount_t(RingBytes{ring_off}, n, max_log, max_sym, norm, nsym_out, log_out);
+}
+__device__ __noinline__ int read_huf_weights_ring(uint32_t ring_off, uint32_t n) { return read_huf_weights_t(RingBytes{ring_off}, n, (uint16_t*)(void*)(S.ring + ring_off + 256)); } // a tree staged in the ring (pre_parse_next)
+__device__ __noinline__ int read_huf_weights_staged(uint32_t stage_off, uint32_t n) { return read_huf_weights_t(StageBytes{stage_off}, n, (uint16_t*)(void*)(S.stage + 1536)); } // a block's tree, staged in LDS
 
 
 // ------------------------------------------------------------------------------------ K2
@@ -848,13 +861,101 @@ __device__ __forceinline__ uint64_t ring_read64(uint32_t e) {
     return v;
 }
 
-// walk record: x = LL state offset | ML state offset << 12 ; y = (g-bit position - 32) | OF state offset << 21
+// walk record (uint4): LL, ML, OF state offsets, g-bit position - 32 -- the walker's state as it stands
 //   (state offsets are byte offsets into the tables: 8 * state)
 constexpr uint32_t kWalkBatch = 32; // sequences between two ring checks (<= 89 bits each)
 
 constexpr uint32_t kWalkFin = 0x80000000u;
+constexpr uint32_t kNoJob = 0xFFFFFFFFu;
+#ifndef MZD_PRE_PRIO
+#define MZD_PRE_PRIO 2
+#endif
+#ifndef MZD_HUF_PRE
+#define MZD_HUF_PRE 0
+#endif
+constexpr uint32_t kPreStage = 2304;        // S.ring[2304 .. 3072): between the Huffman segments of the two helper wavefronts
+constexpr uint32_t kInRing = 0x80000000u;   // parse_seq_header: the staged header lies in S.ring, not in S.stage
 
-__device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint2* walk, uint32_t* prog, int lane) {
+// The hot form of the chain, hand-scheduled: runs of kWalkGroup steps until n steps are done, or a group met a
+// sequence wider than its window (slack < 0: the group is void, the caller takes it again carefully from {sx, sy}, the
+// packed state at the group's start), or the read head comes within one group of the lowest resident ring chunk
+// (Gm < thresh: the caller refills).  A lone wavefront issues in order, ~5 cycles an instruction, and the four LDS reads
+// return through a 64 B/clk path (32 clks): a step is the 12 chain instructions + the reads' round trip, ~137 cycles
+// (tools/micro/asm_micro.hip); whatever the chain does not need -- the record store, packing the next record, the
+// slack bookkeeping, publishing progress -- sits behind the reads, in the shadow of their latency.  Same arithmetic
+// as the careful C++ step.  Progress (records visible to the planner: all but the newest kWalkLag stores have landed) is
+// published once per group.  Registers: v[48:55] the three entries and the window, v[64:71] temporaries, v[80:81]
+// the packed record (all caller-saved in the AMDGPU calling convention).  Table and ring addresses are immediates:
+// S must start at LDS address 0 (checked by the caller, which otherwise keeps the C++ form).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kWalkGroup = 8;
+constexpr uint32_t kWalkLag = 32;
+#define MZD_SDWA_B1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+// v[84:87] = {LL, ML, OF state offsets, read head - 32}: the record of a step is its state, stored as it stands
+#define MZD_WALK_STEP(SH, RECOFF, TAIL) \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_add3_u32 v64, v49, v51, v53\n"                 /* nbBits sums | total bits << 8 | ... */ \
+    "v_add_u32_e32 v65, v49, v51\n"                   /* bit offset of the LL field: nbO + nbM (low 5 bits) */ \
+    "v_sub_u32_sdwa " SH ", %[av], v64" MZD_SDWA_B1   /* window bits below what this sequence consumes */ \
+    "v_sub_u32_sdwa v87, v87, v64" MZD_SDWA_B1 \
+    "v_lshrrev_b64 v[66:67], " SH ", v[54:55]\n" \
+    "v_lshrrev_b32_e32 v71, 3, v87\n" \
+    "v_bfe_u32 v64, v66, 0, v49\n" \
+    "v_bfe_u32 v69, v66, v49, v51\n" \
+    "v_bfe_u32 v70, v66, v65, v53\n" \
+    "v_lshl_add_u32 v86, v64, 3, v48\n" \
+    "v_lshl_add_u32 v85, v69, 3, v50\n" \
+    "v_lshl_add_u32 v84, v70, 3, v52\n" \
+    "ds_read_b64 v[48:49], v86 offset:%[oO]\n" \
+    "ds_read_b64 v[50:51], v85 offset:%[oM]\n" \
+    "ds_read_b64 v[52:53], v84 offset:%[oL]\n" \
+    "v_and_b32_e32 v71, 0x1ffc, v71\n" \
+    "ds_read2_b32 v[54:55], v71 offset1:1\n" \
+    "global_store_dwordx4 %[woff], v[84:87], %[base] offset:" RECOFF "\n" /* the NEXT step's record: the state as it is now */ \
+    "v_and_or_b32 %[av], v87, 31, 32\n" \
+    TAIL
+#define MZD_WALK_SLACK "v_min3_i32 %[slack], %[slack], %[sa], %[sb]\n"
+__device__ __forceinline__ void walk_run_asm(uint32_t& vL, uint32_t& vM, uint32_t& vO, uint32_t& Gm, uint32_t& woff, int32_t& slack, uint32_t& n,
+                                             int32_t pv, uint4& start, int32_t thresh, uint32_t prog_lds,
+                                             __attribute__((address_space(1))) uint8_t* gwalk) {
+    static_assert(kRingBytes - 4 == 0x1ffc && offsetof(Shared, ring) == 0, "the window address mask / the ring's place are spelled out in MZD_WALK_STEP");
+    static_assert(kWalkGroup == 8 && kWalkLag == 32, "spelled out below");
+    uint32_t av, sa, sb;
+    asm volatile(
+        "v_mov_b32_e32 v84, %[vL]\n v_mov_b32_e32 v85, %[vM]\n v_mov_b32_e32 v86, %[vO]\n v_mov_b32_e32 v87, %[Gm]\n"
+        "v_lshrrev_b32_e32 v71, 3, v87\n"
+        "ds_read_b64 v[48:49], v86 offset:%[oO]\n"
+        "ds_read_b64 v[50:51], v85 offset:%[oM]\n"
+        "ds_read_b64 v[52:53], v84 offset:%[oL]\n"
+        "v_and_b32_e32 v71, 0x1ffc, v71\n"
+        "ds_read2_b32 v[54:55], v71 offset1:1\n"
+        "global_store_dwordx4 %[woff], v[84:87], %[base]\n" // the first step's record
+        "v_and_or_b32 %[av], v87, 31, 32\n"
+        "1:\n"
+        "v_mov_b32_e32 %[s0], v84\n v_mov_b32_e32 %[s1], v85\n v_mov_b32_e32 %[s2], v86\n v_mov_b32_e32 %[s3], v87\n" // the group's starting state (the reads are in flight)
+        MZD_WALK_STEP("%[sa]", "16", "")
+        MZD_WALK_STEP("%[sb]", "32", MZD_WALK_SLACK "s_waitcnt vmcnt(32)\n v_max_i32_e32 v69, 0, %[pv]\n ds_write_b32 %[prog], v69\n v_add_u32_e32 %[pv], 8, %[pv]\n") // publish
+        MZD_WALK_STEP("%[sa]", "48", "")
+        MZD_WALK_STEP("%[sb]", "64", MZD_WALK_SLACK)
+        MZD_WALK_STEP("%[sa]", "80", "")
+        MZD_WALK_STEP("%[sb]", "96", MZD_WALK_SLACK)
+        MZD_WALK_STEP("%[sa]", "112", "")
+        MZD_WALK_STEP("%[sb]", "128", MZD_WALK_SLACK "v_add_u32_e32 %[woff], 128, %[woff]\n v_subrev_u32_e32 v69, %[thresh], v87\n v_min_i32_e32 v69, v69, %[slack]\n v_cmp_gt_i32_e32 vcc, 0, v69\n")
+        "s_sub_u32 %[n], %[n], 8\n"
+        "s_cbranch_vccnz 2f\n"
+        "s_cmp_lg_u32 %[n], 0\n"
+        "s_cbranch_scc1 1b\n"
+        "2:\n"
+        "s_waitcnt lgkmcnt(0)\n" // (the reads issued by the last step: nothing may be in flight into v[48:55] past this block)
+        "v_mov_b32_e32 %[vL], v84\n v_mov_b32_e32 %[vM], v85\n v_mov_b32_e32 %[vO], v86\n v_mov_b32_e32 %[Gm], v87\n"
+        : [vL] "+v"(vL), [vM] "+v"(vM), [vO] "+v"(vO), [Gm] "+v"(Gm), [woff] "+v"(woff), [slack] "+v"(slack), [av] "=&v"(av), [n] "+s"(n),
+          [pv] "+v"(pv), [s0] "=&v"(start.x), [s1] "=&v"(start.y), [s2] "=&v"(start.z), [s3] "=&v"(start.w), [sa] "=&v"(sa), [sb] "=&v"(sb)
+        : [base] "s"(gwalk), [thresh] "s"(thresh), [prog] "v"(prog_lds),
+          [oL] "n"(offsetof(Shared, ll)), [oM] "n"(offsetof(Shared, ml)), [oO] "n"(offsetof(Shared, of))
+        : "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v84", "v85", "v86", "v87", "vcc", "scc", "memory");
+}
+
+__device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint4* walk, uint32_t* prog, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
     // a global (not flat) pointer: flat stores would also count on lgkmcnt, i.e. sit in the LDS waits below
     __attribute__((address_space(1))) uint8_t* gwalk;
@@ -898,81 +999,80 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
     const uint8_t* const tO = reinterpret_cast<const uint8_t*>(S.of);
     uint32_t i = 0;
     const uint32_t nupd = nseq - 1; // sequences followed by a state update
-    while (i < nupd) {
-        // keep the ring kWalkBatch sequences ahead of the read head (uniform branch, once per batch)
-        {
-            uint32_t e = __builtin_amdgcn_readfirstlane((G + 7) >> 3);
-            while (st.lowest > 0 && (int32_t)e - (int32_t)(kWalkBatch * 12 + 24) < st.lowest * kChunk) {
-                st.lowest--;
-                ring_load_chunk(st, st.lowest, lane);
-            }
-        }
-        const uint32_t stop = i + kWalkBatch < nupd ? i + kWalkBatch : nupd;
-        uint32_t Gm = G - 32; // the loop carries the read head minus 32 (saves an add per sequence)
-        int32_t slack = 64;   // minimum over the batch of (window bits - bits needed)
-        // One step of the chain.  CAREFUL = false is the hot form: no branch at all; it only notes (in
-        // `slack`) that some sequence had more bits than its window holds (long extra-bit fields: about
-        // one sequence in thousands).  The batch is then redone with CAREFUL = true, which moves the
-        // window down a dword at a time.  (A branch on freshly loaded LDS data costs ~35 cycles per
-        // sequence on a lone wavefront; micro-benchmarked.)
-        auto step = [&](auto careful) {
-            uint64_t eL, eM, eO;
-            __builtin_memcpy(&eL, tL + vL, 8);
-            __builtin_memcpy(&eM, tM + vM, 8);
-            __builtin_memcpy(&eO, tO + vO, 8);
-            // window: the 8 ring bytes at the 4-byte aligned address whose 64 bits end above the read head
-            // (two aligned dwords; an unaligned 8-byte LDS read costs ~40 cycles more)
-            const uint32_t u = Gm; // read head - 32
-            uint32_t ra = (u >> 3) & (kRingBytes - 4);
-            uint64_t X;
+    const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)S.ring == 0; // (walk_run_asm spells LDS addresses out)
+    const uint32_t prog_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)prog;
+    uint32_t Gm = G - 32; // the loop carries the read head minus 32 (saves an add per sequence)
+    // One careful step of the chain: the window moves down a dword at a time until the sequence fits (long extra-bit
+    // fields: about one sequence in hundreds).  The hot form (walk_run_asm) has no such branch -- a branch on freshly
+    // loaded LDS data costs ~35 cycles per sequence on a lone wavefront -- it only notes that a group met such a sequence.
+    auto careful_step = [&]() {
+        uint64_t eL, eM, eO;
+        __builtin_memcpy(&eL, tL + vL, 8);
+        __builtin_memcpy(&eM, tM + vM, 8);
+        __builtin_memcpy(&eO, tO + vO, 8);
+        // window: the 8 ring bytes at the 4-byte aligned address whose 64 bits end above the read head
+        // (two aligned dwords; an unaligned 8-byte LDS read costs ~40 cycles more)
+        const uint32_t u = Gm; // read head - 32
+        uint32_t ra = (u >> 3) & (kRingBytes - 4);
+        uint64_t X;
+        __builtin_memcpy(&X, &S.ring[ra], 8);
+        *(__attribute__((address_space(1))) u32x4*)(gwalk + woff) = u32x4{vL, vM, vO, Gm};
+        woff += 16;
+        const uint32_t hL = (uint32_t)(eL >> 32), hM = (uint32_t)(eM >> 32), hO = (uint32_t)(eO >> 32);
+        const uint32_t total = ((hL + hM + hO) >> 8) & 0xFF;
+        uint32_t av = (u & 31) | 32; // bits of the window below the read head: 32..63
+        while (__builtin_amdgcn_ballot_w64(total > av) != 0) {
+            ra = (ra - 4) & (kRingBytes - 4);
             __builtin_memcpy(&X, &S.ring[ra], 8);
-            *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = (uint64_t)(vL | (vM << 12)) | ((uint64_t)(Gm | (vO << 21)) << 32);
-            woff += 8;
-            asm volatile("" : "+v"(X)); // keep all four LDS reads in flight together
-            const uint32_t hL = (uint32_t)(eL >> 32), hM = (uint32_t)(eM >> 32), hO = (uint32_t)(eO >> 32);
-            const uint32_t total = ((hL + hM + hO) >> 8) & 0xFF;
-            uint32_t av = (u & 31) | 32; // bits of the window below the read head: 32..63
-            if (decltype(careful)::value) {
-                while (__builtin_amdgcn_ballot_w64(total > av) != 0) {
-                    ra = (ra - 4) & (kRingBytes - 4);
-                    __builtin_memcpy(&X, &S.ring[ra], 8);
-                    av += 32;
-                }
-            } else {
-                slack = min((int32_t)(av - total), slack); // goes negative when a sequence does not fit its window
-            }
-            // fresh state bits sit at the bottom of what this sequence consumes: OF lowest, then ML, then LL
-            // (at most 26 bits together: one 64-bit shift, then 32-bit field extracts)
-            const uint32_t Y = (uint32_t)(X >> ((av - total) & 63));
-            const uint32_t bO = __builtin_amdgcn_ubfe(Y, 0, hO);           // width = nbBits, the low bits of the entry
-            const uint32_t bM = __builtin_amdgcn_ubfe(Y, hO, hM);          // offset nbO (low 5 bits)
-            const uint32_t bL = __builtin_amdgcn_ubfe(Y, hO + hM, hL);     // offset nbO + nbM
-            vO = (uint32_t)eO + (bO << 3);
-            vM = (uint32_t)eM + (bM << 3);
-            vL = (uint32_t)eL + (bL << 3);
-            Gm -= total;
-        };
-        const uint32_t sL = vL, sM = vM, sO = vO, sG = Gm, sW = woff, i0 = i;
-        slack = 64;
-        for (; i + 4 <= stop; i += 4) { step(std::false_type{}); step(std::false_type{}); step(std::false_type{}); step(std::false_type{}); }
-        for (; i < stop; i++) step(std::false_type{});
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(slack < 0) != 0, 0)) {
-            vL = sL; vM = sM; vO = sO; Gm = sG; woff = sW;
-            for (i = i0; i < stop; i++) step(std::true_type{});
+            av += 32;
         }
-        G = Gm + 32;
-        if ((int32_t)(G - Gzero) < 0) return MZD_E_CORRUPT; // over-read
-        // publish the batch BEFORE this one: all but the newest kWalkBatch stores have landed
-        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        if (lane == 0 && i >= kWalkBatch) flag_store(prog, i - kWalkBatch);
+        // fresh state bits sit at the bottom of what this sequence consumes: OF lowest, then ML, then LL
+        // (at most 26 bits together: one 64-bit shift, then 32-bit field extracts)
+        const uint32_t Y = (uint32_t)(X >> ((av - total) & 63));
+        const uint32_t bO = __builtin_amdgcn_ubfe(Y, 0, hO);           // width = nbBits, the low bits of the entry
+        const uint32_t bM = __builtin_amdgcn_ubfe(Y, hO, hM);          // offset nbO (low 5 bits)
+        const uint32_t bL = __builtin_amdgcn_ubfe(Y, hO + hM, hL);     // offset nbO + nbM
+        vO = (uint32_t)eO + (bO << 3);
+        vM = (uint32_t)eM + (bM << 3);
+        vL = (uint32_t)eL + (bL << 3);
+        Gm -= total;
+    };
+    constexpr int32_t kLook = (int32_t)(kWalkGroup * 12 + 24) * 8; // bits a group can consume (<= 89 a sequence) + the window above the head
+    while (i < nupd) {
+        // keep the ring one group ahead of the read head
+        while (st.lowest > 0 && (int32_t)Gm < st.lowest * (int32_t)(kChunk * 8) + kLook) {
+            st.lowest--;
+            ring_load_chunk(st, st.lowest, lane);
+        }
+        const uint32_t left = nupd - i;
+        if (lds_at_zero && left >= kWalkGroup) {
+            uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(left & ~(kWalkGroup - 1));
+            const uint32_t n0 = n;
+            const int32_t thresh = __builtin_amdgcn_readfirstlane(st.lowest > 0 ? st.lowest * (int32_t)(kChunk * 8) + kLook : INT32_MIN / 2);
+            int32_t slack = 64; // minimum over a group of (window bits - bits needed)
+            uint4 start;
+            walk_run_asm(vL, vM, vO, Gm, woff, slack, n, (int32_t)i - (int32_t)kWalkLag, start, thresh, prog_lds, gwalk);
+            i += n0 - n;
+            if (__builtin_amdgcn_ballot_w64(slack < 0) != 0) { // the last group is void: once more from its start, carefully
+                i -= kWalkGroup; woff -= 16 * kWalkGroup;
+                vL = start.x; vM = start.y; vO = start.z; Gm = start.w;
+                for (uint32_t k = 0; k < kWalkGroup; k++) careful_step();
+                i += kWalkGroup;
+            }
+        } else {
+            const uint32_t stop = left < kWalkGroup ? nupd : i + kWalkGroup;
+            for (; i < stop; i++) careful_step();
+        }
+        if ((int32_t)(Gm + 32 - Gzero) < 0) return MZD_E_CORRUPT; // over-read
     }
+    G = Gm + 32;
     // last sequence: extra bits only
     {
         uint64_t eL, eM, eO;
         __builtin_memcpy(&eL, tL + vL, 8);
         __builtin_memcpy(&eM, tM + vM, 8);
         __builtin_memcpy(&eO, tO + vO, 8);
-        *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = (uint64_t)(vL | (vM << 12)) | ((uint64_t)((G - 32) | (vO << 21)) << 32);
+        *(__attribute__((address_space(1))) u32x4*)(gwalk + woff) = u32x4{vL, vM, vO, G - 32};
         uint32_t extra = (uint32_t)(eL >> 56) + (uint32_t)(eM >> 56) + (uint32_t)(eO >> 56);
         if (G - Gzero != extra) return MZD_E_CORRUPT; // the bitstream must be consumed exactly
     }
@@ -1090,7 +1190,7 @@ __device__ __forceinline__ void copy_short(uint32_t n, LD ld, ST st) { // n <= 6
 constexpr uint32_t kPlanFin = 0x80000000u;
 
 struct PlanCtx { // what the planning wavefront needs
-    const uint2* walk;       // state-walk records of the block (HBM scratch)
+    const uint4* walk;       // state-walk records of the block (HBM scratch)
     const uint8_t* seq_sp;   // the block's sequence bitstream
     const uint32_t* prog;    // walker progress (LDS)
     uint32_t nlit;
@@ -1137,10 +1237,10 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         return (pg & ~kWalkFin) >= need;
     };
     struct Win { uint32_t hL, hM, hO, G; uint64_t bO, bM, bL; }; // entry words + raw 8-byte windows of one sequence
-    auto load_rec = [&](uint32_t idx) -> uint2 { return idx < nseq ? cx.walk[idx] : make_uint2(0, 0); };
-    auto issue_bits = [&](uint2 w, bool live, Win& o) {
-        const uint32_t vL = w.x & 0xFFF, vM = w.x >> 12, vO = w.y >> 21;
-        o.G = (w.y & 0x1FFFFF) + 32; // records carry the read head - 32
+    auto load_rec = [&](uint32_t idx) -> uint4 { return idx < nseq ? cx.walk[idx] : make_uint4(0, 0, 0, 0); };
+    auto issue_bits = [&](uint4 w, bool live, Win& o) {
+        const uint32_t vL = w.x, vM = w.y, vO = w.z;
+        o.G = w.w + 32; // records carry the read head - 32
         o.hL = (uint32_t)(S.ll[vL >> 3] >> 32); o.hM = (uint32_t)(S.ml[vM >> 3] >> 32); o.hO = (uint32_t)(S.of[vO >> 3] >> 32);
         o.bO = 0; o.bM = 0; o.bL = 0;
         if (live) {
@@ -1150,7 +1250,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         }
     };
     if (!wait_walker(128)) return MZD_E_CORRUPT;
-    uint2 recA = load_rec((uint32_t)lane), recB = load_rec(64 + (uint32_t)lane); // chunks 0 and 1
+    uint4 recA = load_rec((uint32_t)lane), recB = load_rec(64 + (uint32_t)lane); // chunks 0 and 1
     Win win;
     issue_bits(recA, (uint32_t)lane < nseq, win);
     uint32_t chunk = 0;
@@ -1163,7 +1263,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         if (lane == 0) flag_store(&S.c.plan_prog, chunk);
         // stage 1: records of chunk k+2, bit windows of chunk k+1 (recB arrived an iteration ago)
         if (!wait_walker(base + 192)) return MZD_E_CORRUPT; // the walker failed (it posted the error) or never got there
-        const uint2 recC = load_rec(base + 128 + (uint32_t)lane);
+        const uint4 recC = load_rec(base + 128 + (uint32_t)lane);
         Win next;
         issue_bits(recB, base + 64 + (uint32_t)lane < nseq, next);
         // stage 2: fields of chunk k from the windows issued an iteration ago
@@ -1656,8 +1756,7 @@ __device__ __noinline__ uint64_t xxh_finish(uint64_t v, const uint8_t* p, uint64
 }
 
 // ------------------------------------------------------------------------------------ K0 + block driver
-__device__ __noinline__ void parse_frame_or_skip(const uint8_t* src, uint64_t n, const DevDict* dicts, uint32_t ndicts, uint32_t job_dict) {
-    Ctl& c = S.c;
+__device__ __noinline__ void parse_frame_or_skip(Ctl& c, const uint8_t* src, uint64_t n, const DevDict* dicts, uint32_t ndicts, uint32_t job_dict) {
     uint64_t pos = c.pos;
     if (pos >= n) { c.action = 2; return; }
     if (n - pos < 4) { c.err = MZD_E_TRUNCATED; return; }
@@ -1706,8 +1805,7 @@ __device__ __noinline__ void parse_frame_or_skip(const uint8_t* src, uint64_t n,
     if (dd) c.action = 3; // frame with dictionary: tables are copied in by the workgroup
 }
 
-__device__ __noinline__ void parse_block_header(const uint8_t* src, uint64_t n) {
-    Ctl& c = S.c;
+__device__ __noinline__ void parse_block_header(Ctl& c, const uint8_t* src, uint64_t n) {
     if (n - c.pos < 3) { c.err = MZD_E_TRUNCATED; return; }
     uint32_t bh = ld24(src + c.pos);
     c.pos += 3;
@@ -1719,8 +1817,7 @@ __device__ __noinline__ void parse_block_header(const uint8_t* src, uint64_t n) 
 }
 
 // literals section header (+ Huffman weights).  Lane 0.
-__device__ __noinline__ void parse_literals(const uint8_t* b, uint32_t n) {
-    Ctl& c = S.c;
+__device__ __noinline__ void parse_literals(Ctl& c, const uint8_t* b, uint32_t n) {
     uint32_t type = b[0] & 3, sf = (b[0] >> 2) & 3;
     uint32_t regen, comp = 0, hs, streams = 0;
     c.lit_type = type;
@@ -1776,8 +1873,8 @@ __device__ __noinline__ void parse_literals(const uint8_t* b, uint32_t n) {
 
 // sequences section header: nbSeq, modes, table descriptions.  Lane 0 of the walking wavefront, while other
 // wavefronts already work on the literals (errors are posted first-wins).
-__device__ __noinline__ void parse_seq_header(const uint8_t* b, uint32_t n) {
-    Ctl& c = S.c;
+// `stage_off`: where `b` lies inside S.stage (the normalized-count reader addresses the staging area by offset)
+__device__ __noinline__ void parse_seq_header(Ctl& c, const uint8_t* b, uint32_t n, uint32_t stage_off) {
     if (n < 1) { post_err(&c.err, MZD_E_CORRUPT); return; }
     const uint8_t* p = b;
     const uint8_t* end = b + n;
@@ -1800,7 +1897,9 @@ __device__ __noinline__ void parse_seq_header(const uint8_t* b, uint32_t n) {
             c.nsym[t] = *p++; // the symbol itself
         } else if (m == 2) {
             // the header was staged at S.stage + 256 by the caller
-            int used = read_ncount_staged(256 + (uint32_t)(p - b), (uint32_t)(end - p), max_log[t], max_sym[t], S.norm[t], &c.nsym[t], &c.al[t]);
+            const uint32_t at = (stage_off & ~kInRing) + (uint32_t)(p - b);
+            int used = (stage_off & kInRing) ? read_ncount_ring(at, (uint32_t)(end - p), max_log[t], max_sym[t], S.norm[t], &c.nsym[t], &c.al[t])
+                                             : read_ncount_staged(at, (uint32_t)(end - p), max_log[t], max_sym[t], S.norm[t], &c.nsym[t], &c.al[t]);
             if (used <= 0) { post_err(&c.err, MZD_E_CORRUPT); return; }
             p += used;
         } else if (m == 3) {
@@ -1838,6 +1937,65 @@ __device__ __noinline__ void build_tables_wave(int lane) {
 #define WG_SNAPSHOT(...) do { __syncthreads(); __VA_ARGS__; __syncthreads(); } while (0)
 
 
+// Driver 1, by the walking wavefront once its own work on a file's last block is done: take the next file and parse
+// the headers of its first block (frame header, block header, literals header, sequence header with its three
+// normalized-count descriptions: ~60 K cycles of serial parsing) into S.c2, so that the workgroup finds them ready
+// when the copier and the hasher are through with the current file.  Only the plain case is prepared (one frame start,
+// a compressed first block, no error); anything else leaves pre_valid = 0 and the file is parsed the normal way.
+__device__ __noinline__ void pre_parse_next(const KernelArgs& a, int lane) {
+    Ctl& c2 = S.c2;
+    uint32_t j2 = 0;
+    if (lane == 0) { j2 = atomicAdd(&a.counter[0], 1u); S.pre_job = j2; S.pre_valid = 0; }
+    j2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j2);
+    if (j2 >= a.njobs) return;
+    const uint8_t* const src = a.jobs[j2].src;
+    const uint64_t n = a.jobs[j2].src_len;
+    const uint32_t job_dict = a.jobs[j2].dict;
+    if (lane == 0) {
+        c2.pos = 0; c2.out = 0; c2.err = 0; c2.action = 0; c2.btype = 0; c2.diag_slow = 0;
+        if (job_dict > a.ndicts) c2.err = MZD_E_DICT;
+        else parse_frame_or_skip(c2, src, n, a.dicts, a.ndicts, job_dict);
+        if (!c2.err && (c2.action == 0 || c2.action == 3)) {
+            if (c2.action == 3 && a.dicts[job_dict - 1].formatted) { c2.huf_valid = 1; c2.fse_valid = 1; } // (the tables themselves are loaded by the workgroup)
+            parse_block_header(c2, src, n);
+        } else if (!c2.err) c2.err = MZD_E_PARAM; // skippable frame / end of file: not prepared
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (c2.err || c2.btype != 2) return; // (wave-uniform: every lane reads the same words)
+    const uint64_t pos0 = c2.pos;
+    const uint32_t bsize = c2.bsize;
+    uint8_t* const ps = S.ring + kPreStage;
+    for (uint32_t k = (uint32_t)lane; k < bsize && k < 256; k += 64) ps[k] = src[pos0 + k];
+    if (lane == 0) parse_literals(c2, ps, bsize);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (c2.err) return;
+    const uint64_t seq_off = c2.seq_off;
+    const uint32_t seq_len = c2.seq_len;
+    for (uint32_t k = (uint32_t)lane; k < seq_len && k < 256; k += 64) ps[256 + k] = src[seq_off + k];
+    if (lane == 0) { c2.huf_pre = 0; parse_seq_header(c2, ps + 256, seq_len, kInRing | (kPreStage + 256)); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (c2.err) return;
+    TFIN(10);
+    if (MZD_HUF_PRE && c2.lit_type == 2) { // the Huffman tree too: its weights are another ~65 K cycles of serial decoding, and they gate the copier
+        const uint32_t tl = c2.huf_tree_len; // <= 129 bytes
+        for (uint32_t k = (uint32_t)lane; k < tl + 8; k += 64) ps[512 + k] = k < tl ? src[pos0 + c2.huf_tree_off + k] : 0;
+        int used = 1;
+        if (lane == 0) used = read_huf_weights_ring(kPreStage + 512, tl); // (scratch: ring[kPreStage + 768, + 512))
+        used = __builtin_amdgcn_readfirstlane(used);
+        if (used > 0) {
+            // the table itself replaces the current file's: not before that file's literal streams are all decoded
+            Ctl& c = S.c;
+            if (c.lit_type < 2 || spin_ge(&c.streams_done, c.streams, &c.err)) {
+                if (lane == 0) c.lds_dict_huf = 0; // (whatever happens next, S.huf stops being a dictionary's table)
+                if (finish_huf_table_wave(lane) == 0 && lane == 0) { c2.huf_pre = 1; c2.huf_log = c.huf_log; c2.huf_nw = c.huf_nw; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    TFIN(11);
+    if (lane == 0) S.pre_valid = 1;
+}
+
 // ---- driver 1: one workgroup decodes a whole file, block after block.  Used when no file of the launch can have more
 // than one block (every output capacity <= 128 KiB): nothing is forked, nothing is published, the file's state
 // stays in registers and LDS.
@@ -1845,16 +2003,20 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* const lit_buf = a.lit_scratch + (size_t)blockIdx.x * kLitStride;
     uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
-    uint2* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
+    uint4* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
-    if (tid == 0) { c.lds_dict_fse = 0; c.lds_dict_huf = 0; }
+    if (tid == 0) { c.lds_dict_fse = 0; c.lds_dict_huf = 0; S.pre_job = kNoJob; S.pre_valid = 0; }
 
     for (;;) {
-        if (tid == 0) c.job = atomicAdd(&a.counter[0], 1u);
+        if (tid == 0) { // the file the walking wavefront took ahead (pre_parse_next), or the next one of the queue
+            if (S.pre_job != kNoJob) { c.job = S.pre_job; c.t_valid = S.pre_valid; S.pre_job = kNoJob; S.pre_valid = 0; }
+            else { c.job = atomicAdd(&a.counter[0], 1u); c.t_valid = 0; }
+        }
         uint32_t j;
-        WG_SNAPSHOT(j = c.job);
+        bool pre; // the first block's headers are already parsed (in S.c2)
+        WG_SNAPSHOT(j = c.job; pre = c.t_valid != 0);
         if (j >= a.njobs) break;
         const uint8_t* const src = a.jobs[j].src;
         const uint64_t n = a.jobs[j].src_len;
@@ -1862,7 +2024,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
         const uint64_t cap = a.jobs[j].dst_cap;
         const uint32_t job_dict = a.jobs[j].dict;
         if (tid == 0) {
-            c.pos = 0; c.out = 0; c.err = 0; c.action = 0; c.diag_slow = 0;
+            if (pre) { const uint32_t lf = c.lds_dict_fse, lh = c.lds_dict_huf; c = S.c2; c.lds_dict_fse = lf; c.lds_dict_huf = c.huf_pre ? 0u : lh; c.job = j; }
+            else { c.pos = 0; c.out = 0; c.err = 0; c.action = 0; c.huf_pre = 0; }
+            c.diag_slow = 0;
 #ifdef MZD_STAMPS
             for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = 0;
 #endif
@@ -1876,7 +2040,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
 
         // ---------------- frames (K0)
         while (true) {
-            if (tid == 0 && !c.err) parse_frame_or_skip(src, n, a.dicts, a.ndicts, job_dict);
+            const bool frame_pre = pre; // (only the first frame of the file can have been prepared)
+            if (tid == 0 && !c.err && !frame_pre) parse_frame_or_skip(c, src, n, a.dicts, a.ndicts, job_dict);
             WG_SNAPSHOT(err = c.err; action = c.action);
             if (err || action == 2) break;
             if (action == 1) continue; // skippable frame
@@ -1888,7 +2053,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                     // Config 5 (many small frames, one dictionary): a workgroup keeps the dictionary's tables resident in LDS
                     // from file to file -- such frames use them as they are (repeat-mode tables, treeless literals), so the
                     // 14 KB copy happens once per workgroup, not once per file.  Any block that rebuilds a table clears the mark.
-                    const bool have_fse = c.lds_dict_fse == job_dict, have_huf = c.lds_dict_huf == job_dict;
+                    const bool own_huf = frame_pre && c.huf_pre; // the first block's own tree is built already: it replaces the dictionary's
+                    const bool have_fse = c.lds_dict_fse == job_dict, have_huf = own_huf || c.lds_dict_huf == job_dict;
                     __syncthreads();
                     if (!have_fse) {
                         for (int i = tid; i < 512; i += kWG) { S.ll[i] = dd->ll[i]; S.ml[i] = dd->ml[i]; }
@@ -1896,9 +2062,11 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                     }
                     if (!have_huf) for (int i = tid; i < 2048; i += kWG) S.huf[i] = dd->huf[i];
                     if (tid == 0) {
-                        c.lds_dict_fse = job_dict; c.lds_dict_huf = job_dict;
-                        c.al[0] = dd->al[0]; c.al[1] = dd->al[1]; c.al[2] = dd->al[2];
-                        c.huf_log = dd->huf_log; c.huf_valid = 1; c.fse_valid = 1;
+                        c.lds_dict_fse = job_dict; c.lds_dict_huf = own_huf ? 0u : job_dict;
+                        // (a prepared first block has its sequence header parsed already: only repeat-mode tables take the dictionary's log)
+                        for (int t_ = 0; t_ < 3; t_++) if (!frame_pre || c.mode[t_] == 3) c.al[t_] = dd->al[t_];
+                        if (!own_huf) c.huf_log = dd->huf_log;
+                        c.huf_valid = 1; c.fse_valid = 1;
                         c.rep[0] = dd->rep[0]; c.rep[1] = dd->rep[1]; c.rep[2] = dd->rep[2];
                     }
                 }
@@ -1908,7 +2076,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
             // ---------------- blocks
             uint32_t last = 0;
             while (true) {
-                if (tid == 0) parse_block_header(src, n);
+                const bool block_pre = pre;
+                pre = false;
+                if (tid == 0 && !block_pre) parse_block_header(c, src, n);
                 uint32_t btype = 0, bsize = 0;
                 uint64_t out0 = 0, pos0 = 0;
                 WG_SNAPSHOT(err = c.err; btype = c.btype; bsize = c.bsize; last = c.last; out0 = c.out; pos0 = c.pos);
@@ -1933,22 +2103,26 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                     // the three normalized-count headers) are staged in LDS first, so that lane 0's byte-wise
                     // parsing does not pay an HBM round trip per byte.
                     TSTART();
-                    for (uint32_t k = tid; k < bsize && k < 256; k += kWG) S.stage[k] = blk[k];
-                    __syncthreads();
+                    if (!block_pre) {
+                        for (uint32_t k = tid; k < bsize && k < 256; k += kWG) S.stage[k] = blk[k];
+                        __syncthreads();
+                    }
                     if (tid == 0) {
                         c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = out0;
                         c.next_stream = 0; c.streams_done = 0; c.streams_mask = 0;
                         c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.seq_parsed = 0;
                         c.rep_op[0] = 0 | (1 << 2) | (2 << 4); c.rep_op[1] = 0; c.rep_op[2] = 0; c.rep_op[3] = 0;
-                        parse_literals(S.stage, bsize);
+                        if (!block_pre) parse_literals(c, S.stage, bsize);
                     }
                     uint32_t lit_type = 0, nlit = 0, streams = 0, nseq = 0, seq_len = 0;
                     uint64_t lit_off = 0, seq_off = 0;
                     WG_SNAPSHOT(err = c.err; lit_type = c.lit_type; nlit = c.nlit; streams = c.streams; lit_off = c.lit_off;
                                 seq_off = c.seq_off; seq_len = c.seq_len);
                     if (err) break;
-                    for (uint32_t k = tid; k < seq_len && k < 256; k += kWG) S.stage[256 + k] = src[seq_off + k];
-                    __syncthreads();
+                    if (!block_pre) {
+                        for (uint32_t k = tid; k < seq_len && k < 256; k += kWG) S.stage[256 + k] = src[seq_off + k];
+                        __syncthreads();
+                    }
                     STAMP(1);
                     // The sequence header (three normalized-count descriptions: a serial bit parse) is read by lane 0 of
                     // the walking wavefront INSIDE the pipeline, so the literal side (Huffman tree, streams) starts at once.
@@ -1994,7 +2168,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                     //   wave 3  K4b field conversion + repeat offsets + positions (the plan), behind the walker
                     if (wave == 0) {
                         __builtin_amdgcn_s_setprio(MZD_PRIO_WALK); // header parse, tables and walk are one serial chain: the block's critical path
-                        if (lane == 0) parse_seq_header(S.stage + 256, seq_len);
+                        if (lane == 0 && !block_pre) parse_seq_header(c, S.stage + 256, seq_len, 256);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) flag_store(&c.seq_parsed, 1);
                         TFIN(6);
@@ -2019,6 +2193,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                         }
                         __builtin_amdgcn_s_setprio(0);
                         huf_helper();
+                        if (last && pos0 + bsize + (hashing ? 4u : 0u) == n) { __builtin_amdgcn_s_setprio(MZD_PRE_PRIO); pre_parse_next(a, lane); __builtin_amdgcn_s_setprio(0); } // this block closes the file: the next file's headers, meanwhile
                     } else if (wave == 3) {
                         if (get_seq() && nseq) {
                             int rc = MZD_E_CORRUPT;
@@ -2042,11 +2217,11 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                         // at the copier's priority, the remaining streams just below
                         if (wave == 1) __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); else __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
                         if (lit_type == 2) { // K1: the Huffman tree (from an LDS copy of its description), by wavefront 1
-                            if (wave == 1) {
+                            if (wave == 1 && block_pre && c.huf_pre) { // the table was built ahead, with the headers
+                                if (lane == 0) { c.huf_valid = 1; flag_store(&c.huf_fill, 2); }
+                            } else if (wave == 1) { // weights: serial (lane 0); table: the whole wavefront
                                 const uint32_t tl = c.huf_tree_len; // <= 129 bytes
                                 for (uint32_t k = (uint32_t)lane; k < tl + 8; k += 64) S.stage[1024 + k] = k < tl ? blk[c.huf_tree_off + k] : 0;
-                            }
-                            if (wave == 1) { // weights: serial (lane 0); table: the whole wavefront
                                 int used = 1;
                                 if (lane == 0) { c.lds_dict_huf = 0; used = read_huf_weights_staged(1024, c.huf_tree_len); } // (the table is no longer a dictionary's)
                                 used = __builtin_amdgcn_readfirstlane(used);
@@ -2201,7 +2376,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* const lit_buf = a.lit_scratch + (size_t)blockIdx.x * kLitStride;
     uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
-    uint2* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
+    uint4* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
@@ -2265,7 +2440,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         bool frame_first = false;
         if (!in_frame) {
             for (;;) {
-                if (tid == 0 && !c.err) parse_frame_or_skip(src, n, a.dicts, a.ndicts, job_dict);
+                if (tid == 0 && !c.err) parse_frame_or_skip(c, src, n, a.dicts, a.ndicts, job_dict);
                 WG_SNAPSHOT(err = c.err; action = c.action);
                 if (err || action != 1) break; // 1: a skippable frame was skipped, look again
             }
@@ -2292,7 +2467,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         uint32_t btype = 0, bsize = 0, last = 0;
         uint64_t pos0 = 0;
         if (have_block) {
-            if (tid == 0) parse_block_header(src, n);
+            if (tid == 0) parse_block_header(c, src, n);
             WG_SNAPSHOT(err = c.err; btype = c.btype; bsize = c.bsize; last = c.last; pos0 = c.pos);
             if (err) have_block = false;
         }
@@ -2359,7 +2534,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                 c.next_stream = 0; c.streams_done = 0; c.streams_mask = 0;
                 c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.seq_parsed = 0;
                 c.rep_op[0] = 0 | (1 << 2) | (2 << 4); c.rep_op[1] = 0; c.rep_op[2] = 0; c.rep_op[3] = 0; // identity: a block without sequences
-                parse_literals(S.stage, bsize);
+                parse_literals(c, S.stage, bsize);
             }
             uint32_t lit_type = 0, nlit = 0, streams = 0, nseq = 0, seq_len = 0;
             uint64_t lit_off = 0, seq_off = 0;
@@ -2421,7 +2596,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                 //   wave 3  publishes the tables for the successor, K4b field conversion + repeat offsets + positions (the plan)
                 if (wave == 0) {
                     __builtin_amdgcn_s_setprio(MZD_PRIO_WALK); // header parse, tables and walk are one serial chain: the block's critical path
-                    if (lane == 0) parse_seq_header(S.stage + 256, seq_len);
+                    if (lane == 0) parse_seq_header(c, S.stage + 256, seq_len, 256);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0) flag_store(&c.seq_parsed, 1);
                     TFIN(6);

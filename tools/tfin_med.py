@@ -1,0 +1,21 @@
+"""Diagnostic: medians of the per-workgroup role finish times (libmzd_tfin.so / MZD_DIAG_SO).  Not a benchmark."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fuse_zstd_amd.api as api
+api._SO = os.path.join(os.path.dirname(api._SO), os.environ.get("MZD_DIAG_SO", "libmzd_tfin.so"))
+import fuse_zstd_amd as mzd, corpus
+import numpy as np
+mzd.init()
+kind, size, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+cp = corpus.build_corpus(kind, 2, [size] * n)
+srcs = [cp.comp_file(i).tobytes() for i in range(n)]
+for rep in range(2):
+    res = mzd.decode_batch(srcs, [size] * n)
+assert all(st == 0 for st, _ in res)
+buf = (C.c_uint64 * (12 * 2048))()
+ns = api.lib().mzd_debug_tfin_all(0, buf, 2048)
+arr = np.frombuffer(buf, dtype=np.uint64)[: ns * 12].reshape(ns, 12).astype(np.float64)
+arr = arr[arr[:, 0] > 0]
+names = ["walker", "copier", "hasher", "planner", "lit stream 1", "tables", "headers", "huf weights", "huf table", "copier start", "slot10", "slot11"]
+print("kernel ms", mzd.last_kernel_ms(0), "wgs", len(arr))
+print("; ".join("%s %.0fK" % (nm, np.median(arr[:, k]) / 1e3) for k, nm in enumerate(names)))
