@@ -115,7 +115,6 @@ struct Ctl {
     uint32_t dict_content_len;
     const uint8_t* dict_content;
     // the task (one block of one file) and what its predecessor published
-    uint32_t huf_pre;                               // driver 1: this block's Huffman table was built ahead (pre_parse_next)
     uint32_t lds_dict_fse, lds_dict_huf;            // driver 1: dictionary (handle) whose FSE / Huffman tables sit unmodified in LDS, or 0
     uint32_t t_valid, task, in_frame, with_dict;
     uint32_t pred_ready;                            // the predecessor's state is in pred_* (LDS flag of the block pipeline)
@@ -400,7 +399,24 @@ __device__ __forceinline__ int read_huf_weights_t(LD ld, uint32_t n, uint16_t* n
         bpos -= (int32_t)log; uint32_t s1 = bits(bpos, (int)log);
         bpos -= (int32_t)log; uint32_t s2 = bits(bpos, (int)log);
         int ok = 0;
-        for (;;) { // two interleaved states; ends when the stream is over-read
+        // Two interleaved states.  While a pair of weights cannot exhaust the stream (<= 6 bits each), both entries and the
+        // 8 stream bytes below the read point are read together: two weights per LDS round trip, no branch on their values.
+        while (bpos >= 12 && nw <= 252) {
+            const uint32_t e1 = S.wtab[s1], e2 = S.wtab[s2];
+            int32_t bi = (bpos - 56) >> 3;
+            bi = bi < 0 ? 0 : bi;
+            const uint64_t W = ld(bs + (uint32_t)bi); // stream bits [8 bi, 8 bi + 64): the read point lies 12..63 bits up
+            const uint32_t nb1 = (e1 >> 8) & 0xFF, nb2 = (e2 >> 8) & 0xFF;
+            const uint32_t h = (uint32_t)bpos - (uint32_t)bi * 8;
+            const uint32_t both = (uint32_t)(W >> (h - nb1 - nb2)); // state 1's fresh bits above state 2's
+            const uint16_t two = (uint16_t)((e1 & 0xFF) | ((e2 & 0xFF) << 8));
+            __builtin_memcpy(w + nw, &two, 2); // (nw is even here)
+            nw += 2;
+            s1 = (e1 >> 16) + ((both >> nb2) & ((1u << nb1) - 1));
+            s2 = (e2 >> 16) + (both & ((1u << nb2) - 1));
+            bpos -= (int32_t)(nb1 + nb2);
+        }
+        for (;;) { // the tail, a weight at a time; ends when the stream is over-read
             if (nw > 253) break;
             uint32_t e = S.wtab[s1];
             w[nw++] = (uint8_t)e; int nb = (e >> 8) & 0xFF; bpos -= nb; s1 = (e >> 16) + bits(bpos, nb);
@@ -425,7 +441,6 @@ struct RingBytes { // offset into S.ring
 __device__ __noinline__ int read_ncount_ring(uint32_t ring_off, uint32_t n, int max_log, int max_sym, int16_t* norm, uint32_t* nsym_out, uint32_t* log_out) {
     return read_ncount_t(RingBytes{ring_off}, n, max_log, max_sym, norm, nsym_out, log_out);
 }
-__device__ __noinline__ int read_huf_weights_ring(uint32_t ring_off, uint32_t n) { return read_huf_weights_t(RingBytes{ring_off}, n, (uint16_t*)(void*)(S.ring + ring_off + 256)); } // a tree staged in the ring (pre_parse_next)
 __device__ __noinline__ int read_huf_weights_staged(uint32_t stage_off, uint32_t n) { return read_huf_weights_t(StageBytes{stage_off}, n, (uint16_t*)(void*)(S.stage + 1536)); } // a block's tree, staged in LDS
 
 
@@ -863,15 +878,11 @@ __device__ __forceinline__ uint64_t ring_read64(uint32_t e) {
 
 // walk record (uint4): LL, ML, OF state offsets, g-bit position - 32 -- the walker's state as it stands
 //   (state offsets are byte offsets into the tables: 8 * state)
-constexpr uint32_t kWalkBatch = 32; // sequences between two ring checks (<= 89 bits each)
 
 constexpr uint32_t kWalkFin = 0x80000000u;
 constexpr uint32_t kNoJob = 0xFFFFFFFFu;
 #ifndef MZD_PRE_PRIO
 #define MZD_PRE_PRIO 2
-#endif
-#ifndef MZD_HUF_PRE
-#define MZD_HUF_PRE 0
 #endif
 constexpr uint32_t kPreStage = 2304;        // S.ring[2304 .. 3072): between the Huffman segments of the two helper wavefronts
 constexpr uint32_t kInRing = 0x80000000u;   // parse_seq_header: the staged header lies in S.ring, not in S.stage
@@ -1972,27 +1983,11 @@ __device__ __noinline__ void pre_parse_next(const KernelArgs& a, int lane) {
     const uint64_t seq_off = c2.seq_off;
     const uint32_t seq_len = c2.seq_len;
     for (uint32_t k = (uint32_t)lane; k < seq_len && k < 256; k += 64) ps[256 + k] = src[seq_off + k];
-    if (lane == 0) { c2.huf_pre = 0; parse_seq_header(c2, ps + 256, seq_len, kInRing | (kPreStage + 256)); }
+    if (lane == 0) parse_seq_header(c2, ps + 256, seq_len, kInRing | (kPreStage + 256));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (c2.err) return;
-    TFIN(10);
-    if (MZD_HUF_PRE && c2.lit_type == 2) { // the Huffman tree too: its weights are another ~65 K cycles of serial decoding, and they gate the copier
-        const uint32_t tl = c2.huf_tree_len; // <= 129 bytes
-        for (uint32_t k = (uint32_t)lane; k < tl + 8; k += 64) ps[512 + k] = k < tl ? src[pos0 + c2.huf_tree_off + k] : 0;
-        int used = 1;
-        if (lane == 0) used = read_huf_weights_ring(kPreStage + 512, tl); // (scratch: ring[kPreStage + 768, + 512))
-        used = __builtin_amdgcn_readfirstlane(used);
-        if (used > 0) {
-            // the table itself replaces the current file's: not before that file's literal streams are all decoded
-            Ctl& c = S.c;
-            if (c.lit_type < 2 || spin_ge(&c.streams_done, c.streams, &c.err)) {
-                if (lane == 0) c.lds_dict_huf = 0; // (whatever happens next, S.huf stops being a dictionary's table)
-                if (finish_huf_table_wave(lane) == 0 && lane == 0) { c2.huf_pre = 1; c2.huf_log = c.huf_log; c2.huf_nw = c.huf_nw; }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    }
-    TFIN(11);
+    // (Building the Huffman table ahead as well was tried and measured slower: the ~65 K cycles of weight decoding then
+    //  queue behind this wavefront's own walk instead of running beside it on the copying wavefront.)
     if (lane == 0) S.pre_valid = 1;
 }
 
@@ -2024,8 +2019,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
         const uint64_t cap = a.jobs[j].dst_cap;
         const uint32_t job_dict = a.jobs[j].dict;
         if (tid == 0) {
-            if (pre) { const uint32_t lf = c.lds_dict_fse, lh = c.lds_dict_huf; c = S.c2; c.lds_dict_fse = lf; c.lds_dict_huf = c.huf_pre ? 0u : lh; c.job = j; }
-            else { c.pos = 0; c.out = 0; c.err = 0; c.action = 0; c.huf_pre = 0; }
+            if (pre) { const uint32_t lf = c.lds_dict_fse, lh = c.lds_dict_huf; c = S.c2; c.lds_dict_fse = lf; c.lds_dict_huf = lh; c.job = j; }
+            else { c.pos = 0; c.out = 0; c.err = 0; c.action = 0; }
             c.diag_slow = 0;
 #ifdef MZD_STAMPS
             for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = 0;
@@ -2053,8 +2048,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                     // Config 5 (many small frames, one dictionary): a workgroup keeps the dictionary's tables resident in LDS
                     // from file to file -- such frames use them as they are (repeat-mode tables, treeless literals), so the
                     // 14 KB copy happens once per workgroup, not once per file.  Any block that rebuilds a table clears the mark.
-                    const bool own_huf = frame_pre && c.huf_pre; // the first block's own tree is built already: it replaces the dictionary's
-                    const bool have_fse = c.lds_dict_fse == job_dict, have_huf = own_huf || c.lds_dict_huf == job_dict;
+                    const bool have_fse = c.lds_dict_fse == job_dict, have_huf = c.lds_dict_huf == job_dict;
                     __syncthreads();
                     if (!have_fse) {
                         for (int i = tid; i < 512; i += kWG) { S.ll[i] = dd->ll[i]; S.ml[i] = dd->ml[i]; }
@@ -2062,11 +2056,10 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                     }
                     if (!have_huf) for (int i = tid; i < 2048; i += kWG) S.huf[i] = dd->huf[i];
                     if (tid == 0) {
-                        c.lds_dict_fse = job_dict; c.lds_dict_huf = own_huf ? 0u : job_dict;
+                        c.lds_dict_fse = job_dict; c.lds_dict_huf = job_dict;
                         // (a prepared first block has its sequence header parsed already: only repeat-mode tables take the dictionary's log)
                         for (int t_ = 0; t_ < 3; t_++) if (!frame_pre || c.mode[t_] == 3) c.al[t_] = dd->al[t_];
-                        if (!own_huf) c.huf_log = dd->huf_log;
-                        c.huf_valid = 1; c.fse_valid = 1;
+                        c.huf_log = dd->huf_log; c.huf_valid = 1; c.fse_valid = 1;
                         c.rep[0] = dd->rep[0]; c.rep[1] = dd->rep[1]; c.rep[2] = dd->rep[2];
                     }
                 }
@@ -2217,9 +2210,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                         // at the copier's priority, the remaining streams just below
                         if (wave == 1) __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); else __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
                         if (lit_type == 2) { // K1: the Huffman tree (from an LDS copy of its description), by wavefront 1
-                            if (wave == 1 && block_pre && c.huf_pre) { // the table was built ahead, with the headers
-                                if (lane == 0) { c.huf_valid = 1; flag_store(&c.huf_fill, 2); }
-                            } else if (wave == 1) { // weights: serial (lane 0); table: the whole wavefront
+                            if (wave == 1) { // weights: serial (lane 0); table: the whole wavefront
                                 const uint32_t tl = c.huf_tree_len; // <= 129 bytes
                                 for (uint32_t k = (uint32_t)lane; k < tl + 8; k += 64) S.stage[1024 + k] = k < tl ? blk[c.huf_tree_off + k] : 0;
                                 int used = 1;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k(const uint64_t* tabs, const uint8_t* ri
         "s_sub_u32 %[n], %[n], 4\n s_cmp_lg_u32 %[n], 0\n s_cbranch_scc1 1b\n s_waitcnt lgkmcnt(0)\n" \
         : [vL] "+v"(vL), [vM] "+v"(vM), [vO] "+v"(vO), [Gm] "+v"(Gm), [woff] "+v"(woff), [slack] "+v"(slack), [av] "+v"(av), [n] "+s"(n) \
         : [base] "s"(gw), [oL] "n"(offsetof(Sh, ll)), [oM] "n"(offsetof(Sh, ml)), [oO] "n"(offsetof(Sh, of)) \
-        : "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v80", "v81", "scc", "memory")
+        : "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v80", "v81", "scc", "memory", "s20", "s21", "s22", "s23")
     if (V == 0) BODY(WAIT CRIT READS STORE REST);          // the product's step
     if (V == 1) BODY(WAIT CRIT READS REST);                // no record store
     if (V == 2) BODY(WAIT CRIT READS AVONLY);              // chain only
@@ -123,6 +123,19 @@ __global__ __launch_bounds__(256) void k(const uint64_t* tabs, const uint8_t* ri
     if (V == 24) { asm volatile("s_mov_b64 exec, 0xffff"); BODY(CRIT AVONLY); }
     if (V == 25) { asm volatile("s_mov_b64 exec, 1"); BODY(CRIT AVONLY); }
     if (V == 26) { asm volatile("s_mov_b32 exec_hi, 0"); BODY(WAIT CRIT READS STORE REST); }
+    if (V == 30) BODY("v_lshrrev_b64 v[66:67], v68, v[54:55]\n v_lshrrev_b64 v[66:67], v66, v[54:55]\n v_lshrrev_b64 v[66:67], v66, v[54:55]\n v_lshrrev_b64 v[66:67], v66, v[54:55]\n"); // 4 dependent 64-bit shifts
+    if (V == 31) BODY("v_alignbit_b32 v66, v55, v54, v68\n v_alignbit_b32 v66, v55, v54, v66\n v_alignbit_b32 v66, v55, v54, v66\n v_alignbit_b32 v66, v55, v54, v66\n"); // 4 dependent alignbits
+    if (V == 32) BODY("v_lshrrev_b64 v[66:67], v68, v[54:55]\n v_lshrrev_b64 v[64:65], v68, v[54:55]\n v_lshrrev_b64 v[70:71], v68, v[54:55]\n v_lshrrev_b64 v[48:49], v68, v[54:55]\n"); // 4 independent 64-bit shifts
+    if (V == 33) BODY("v_alignbit_b32 v66, v55, v54, v68\n v_alignbit_b32 v64, v55, v54, v68\n v_alignbit_b32 v70, v55, v54, v68\n v_alignbit_b32 v48, v55, v54, v68\n");
+    if (V == 34) BODY("v_add3_u32 v66, v55, v54, v68\n v_add3_u32 v64, v55, v54, v68\n v_add3_u32 v70, v55, v54, v68\n v_add3_u32 v48, v55, v54, v68\n");
+    if (V == 35) BODY("v_add_u32_e32 v66, v55, v54\n v_add_u32_e32 v64, v55, v54\n v_add_u32_e32 v70, v55, v54\n v_add_u32_e32 v48, v55, v54\n");
+    if (V == 36) BODY("v_add_u32_e32 v66, v66, v54\n v_add_u32_e32 v66, v66, v54\n v_add_u32_e32 v66, v66, v54\n v_add_u32_e32 v66, v66, v54\n");
+    if (V == 37) BODY("v_add_u32_e64 v66, v55, v54\n v_add_u32_e64 v64, v55, v54\n v_add_u32_e64 v70, v55, v54\n v_add_u32_e64 v48, v55, v54\n");
+    if (V == 38) BODY("v_and_b32_e32 v66, 0x1ffc, v54\n v_and_b32_e32 v64, 0x1ffc, v54\n v_and_b32_e32 v70, 0x1ffc, v54\n v_and_b32_e32 v48, 0x1ffc, v54\n"); // e32 + literal
+    if (V == 39) BODY("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n");
+    if (V == 40) BODY("s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1\n");
+    if (V == 41) BODY("s_add_u32 s20, s20, 1\n s_add_u32 s20, s20, 1\n s_add_u32 s20, s20, 1\n s_add_u32 s20, s20, 1\n");
+    if (V == 42) BODY("v_add3_u32 v66, v66, v54, v68\n v_add3_u32 v66, v66, v54, v68\n v_add3_u32 v66, v66, v54, v68\n v_add3_u32 v66, v66, v54, v68\n");
     if (V == 9) BODY(STEP2(STORE REST));
     if (V == 10) BODY(STEP3(STORE REST));
     if (V == 11) BODY(STEP2(AVONLY));
@@ -150,6 +163,6 @@ int main(int argc, char** argv) {
 #define RUN(V, what) { for (int r = 0; r < 2; r++) { hipLaunchKernelGGL(k<V>, dim3(grid), dim3(256), 0, 0, tabs, ring, nseq, out, cyc); hipDeviceSynchronize(); } \
                  double s = 0; for (int b = 0; b < grid; b++) s += cyc[b]; printf("%-60s %.1f cycles/step\n", what, s / grid / nseq); }
     RUN(0, "full step") RUN(1, "no record store") RUN(2, "chain only") RUN(3, "four reads + wait") RUN(4, "one b64 read + wait")
-    RUN(12,"four reads, tables b32") RUN(13,"four b32") RUN(14,"one b32") RUN(15,"two b64") RUN(16,"one b128") RUN(17,"one read2_b64") RUN(20,"full, exec 16 lanes") RUN(21,"full, exec 1 lane") RUN(22,"four reads, 16 lanes") RUN(23,"four reads, 1 lane") RUN(24,"ALU, 16 lanes") RUN(25,"ALU, 1 lane") RUN(26,"full, 32 lanes") RUN(9, "new order, window last + lgkmcnt(1)") RUN(10, "new order, window first") RUN(11, "new order, window last, chain only") RUN(5, "ALU part alone") RUN(6, "2 VALU + read chase") RUN(7, "full + 4 s_nop in the shadow") RUN(8, "full + 4 s_nop on the chain")
+    RUN(12,"four reads, tables b32") RUN(13,"four b32") RUN(14,"one b32") RUN(15,"two b64") RUN(16,"one b128") RUN(17,"one read2_b64") RUN(20,"full, exec 16 lanes") RUN(21,"full, exec 1 lane") RUN(22,"four reads, 16 lanes") RUN(23,"four reads, 1 lane") RUN(24,"ALU, 16 lanes") RUN(25,"ALU, 1 lane") RUN(26,"full, 32 lanes") RUN(30,"4 dep lshr64 (x4 per iter)") RUN(31,"4 dep alignbit") RUN(32,"4 indep lshr64") RUN(33,"4 indep alignbit") RUN(34,"4 indep add3") RUN(35,"4 indep add e32") RUN(36,"4 dep add e32") RUN(37,"4 indep add e64") RUN(38,"4 indep and e32+literal") RUN(39,"4 s_nop") RUN(40,"4 indep s_add") RUN(41,"4 dep s_add") RUN(42,"4 dep add3") RUN(9, "new order, window last + lgkmcnt(1)") RUN(10, "new order, window first") RUN(11, "new order, window last, chain only") RUN(5, "ALU part alone") RUN(6, "2 VALU + read chase") RUN(7, "full + 4 s_nop in the shadow") RUN(8, "full + 4 s_nop on the chain")
     return 0;
 }
