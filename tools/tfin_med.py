@@ -7,10 +7,19 @@ import fuse_zstd_amd as mzd, corpus
 import numpy as np
 mzd.init()
 kind, size, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-cp = corpus.build_corpus(kind, 2, [size] * n)
-srcs = [cp.comp_file(i).tobytes() for i in range(n)]
-for rep in range(2):
-    res = mzd.decode_batch(srcs, [size] * n)
+if kind == "cfg5":  # the shared-dictionary shape of bench.py --workload cfg5
+    sizes = [int(x) for x in np.random.RandomState(55).randint(300, 3001, size=n)]
+    d = corpus.train_dict("json", 5, [int(x) for x in np.random.RandomState(55).randint(300, 3001, size=4000)], cap=112640)
+    did = mzd.load_dict(d)
+    cp = corpus.build_corpus("json", 5, sizes, dictionary=d)
+    srcs = [cp.comp_file(i).tobytes() for i in range(n)]
+    for rep in range(2):
+        res = mzd.decode_batch(srcs, sizes, dict_ids=[did] * n)
+else:
+    cp = corpus.build_corpus(kind, 2, [size] * n)
+    srcs = [cp.comp_file(i).tobytes() for i in range(n)]
+    for rep in range(2):
+        res = mzd.decode_batch(srcs, [size] * n)
 assert all(st == 0 for st, _ in res)
 buf = (C.c_uint64 * (12 * 2048))()
 ns = api.lib().mzd_debug_tfin_all(0, buf, 2048)
