@@ -157,6 +157,9 @@ class LibZstd:
                 L.zref_time_oneshot_mt.restype = C.c_double
                 L.zref_time_oneshot_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint64)]
+                L.zref_time_oneshot_mt_dict.restype = C.c_double
+                L.zref_time_oneshot_mt_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p,
+                                                        C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         return cls._ok
 
     @staticmethod

@@ -44,6 +44,9 @@ static size_t (*p_initDStream)(void*);
 static size_t (*p_compressStream2)(void*, z_out*, z_in*, int);
 static size_t (*p_trainFromBuffer)(void*, size_t, const void*, const size_t*, unsigned);
 static unsigned long long (*p_getFrameContentSize)(const void*, size_t);
+static void* (*p_createDDict)(const void*, size_t);
+static size_t (*p_freeDDict)(void*);
+static size_t (*p_decompress_usingDDict)(void*, void*, size_t, const void*, size_t, const void*);
 
 #define SYM(v, name) do { *(void**)(&v) = dlsym(H, name); if (!v) return -2; } while (0)
 
@@ -62,6 +65,7 @@ int zref_open(const char* path) {
     SYM(p_decompress_usingDict, "ZSTD_decompress_usingDict"); SYM(p_decompressStream, "ZSTD_decompressStream");
     SYM(p_initDStream, "ZSTD_initDStream"); SYM(p_compressStream2, "ZSTD_compressStream2");
     SYM(p_trainFromBuffer, "ZDICT_trainFromBuffer"); SYM(p_getFrameContentSize, "ZSTD_getFrameContentSize");
+    SYM(p_createDDict, "ZSTD_createDDict"); SYM(p_freeDDict, "ZSTD_freeDDict"); SYM(p_decompress_usingDDict, "ZSTD_decompress_usingDDict");
     return 0;
 }
 
@@ -193,6 +197,7 @@ typedef struct {
     const uint8_t* blob; const uint64_t* offs; const uint64_t* sizes; unsigned nfiles, ntasks;
     uint8_t* out; const uint64_t* out_offs; const uint64_t* out_caps;
     volatile unsigned* next; uint64_t bytes; int fail;
+    const void* ddict; /* config 5: a digested dictionary shared by all workers (NULL: none) */
 } mt_arg;
 
 static void* mt_worker(void* v) {
@@ -208,7 +213,8 @@ static void* mt_worker(void* v) {
         if (t >= a->ntasks) break;
         unsigned i = t % a->nfiles; /* pass number = t / nfiles */
         uint8_t* dst = t < a->nfiles ? a->out + a->out_offs[i] : priv;
-        size_t r = p_decompressDCtx(d, dst, (size_t)a->out_caps[i], a->blob + a->offs[i], (size_t)a->sizes[i]);
+        size_t r = a->ddict ? p_decompress_usingDDict(d, dst, (size_t)a->out_caps[i], a->blob + a->offs[i], (size_t)a->sizes[i], a->ddict)
+                            : p_decompressDCtx(d, dst, (size_t)a->out_caps[i], a->blob + a->offs[i], (size_t)a->sizes[i]);
         if (p_isError(r)) { a->fail = 1; break; }
         a->bytes += r;
     }
@@ -219,9 +225,9 @@ static void* mt_worker(void* v) {
 
 /* B2: nthreads workers created ONCE, `passes` passes over the files (one file per task, reused DCtx per
  * thread, one-shot decode into out[]).  Returns seconds; *bytes = decompressed bytes of all passes. */
-double zref_time_oneshot_mt(const uint8_t* blob, const uint64_t* offs, const uint64_t* sizes, unsigned nfiles,
-                            uint8_t* out, const uint64_t* out_offs, const uint64_t* out_caps, unsigned nthreads, unsigned passes,
-                            uint64_t* bytes) {
+static double time_oneshot_mt(const uint8_t* blob, const uint64_t* offs, const uint64_t* sizes, unsigned nfiles,
+                              uint8_t* out, const uint64_t* out_offs, const uint64_t* out_caps, unsigned nthreads, unsigned passes,
+                              uint64_t* bytes, const void* ddict) {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 512) nthreads = 512;
     if (passes < 1) passes = 1;
@@ -229,7 +235,7 @@ double zref_time_oneshot_mt(const uint8_t* blob, const uint64_t* offs, const uin
     volatile unsigned next = 0;
     double t0 = now_s();
     for (unsigned t = 0; t < nthreads; t++) {
-        mt_arg a = {blob, offs, sizes, nfiles, nfiles * passes, out, out_offs, out_caps, &next, 0, 0};
+        mt_arg a = {blob, offs, sizes, nfiles, nfiles * passes, out, out_offs, out_caps, &next, 0, 0, ddict};
         args[t] = a;
         pthread_create(&th[t], NULL, mt_worker, &args[t]);
     }
@@ -238,4 +244,19 @@ double zref_time_oneshot_mt(const uint8_t* blob, const uint64_t* offs, const uin
     double t1 = now_s();
     *bytes = fail ? 0 : total;
     return t1 - t0;
+}
+double zref_time_oneshot_mt(const uint8_t* blob, const uint64_t* offs, const uint64_t* sizes, unsigned nfiles,
+                            uint8_t* out, const uint64_t* out_offs, const uint64_t* out_caps, unsigned nthreads, unsigned passes,
+                            uint64_t* bytes) {
+    return time_oneshot_mt(blob, offs, sizes, nfiles, out, out_offs, out_caps, nthreads, passes, bytes, NULL);
+}
+/* the same with one dictionary for every file (config 5), digested once outside the timed region (ZSTD_createDDict) */
+double zref_time_oneshot_mt_dict(const uint8_t* blob, const uint64_t* offs, const uint64_t* sizes, unsigned nfiles,
+                                 uint8_t* out, const uint64_t* out_offs, const uint64_t* out_caps, unsigned nthreads, unsigned passes,
+                                 uint64_t* bytes, const void* dict, size_t dict_len) {
+    void* dd = p_createDDict(dict, dict_len);
+    if (!dd) { *bytes = 0; return 0.0; }
+    double t = time_oneshot_mt(blob, offs, sizes, nfiles, out, out_offs, out_caps, nthreads, passes, bytes, dd);
+    p_freeDDict(dd);
+    return t;
 }
