@@ -532,6 +532,9 @@ __device__ __noinline__ int finish_huf_table_wave(int lane) {
 // A walk reads the stream through a 64-bit window loaded once per five symbols (5 * 11 bits <= 57).
 constexpr int32_t kSegBits = 64 * 248; // 31 bytes per lane: lane windows fall into different LDS banks
 
+#ifndef MZD_HUF_MINC
+#define MZD_HUF_MINC 16
+#endif
 __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int lane) {
     if (sl == 0) return MZD_E_CORRUPT;
     uint32_t last = sp[sl - 1];
@@ -556,7 +559,7 @@ __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint
         }
         const int32_t seg_bias = 16 - (int32_t)blo; // stream byte j lives at seg[j + seg_bias] (the index is formed first: a pointer below `seg` would be out of bounds)
         int32_t C = (s1 - s0 + 63) / 64;
-        if (C < 32) C = 32;
+        if (C < MZD_HUF_MINC) C = MZD_HUF_MINC;
         int32_t q0 = s0 + lane * C, q1 = q0 + C;
         if (q0 > s1) q0 = s1;
         if (q1 > s1) q1 = s1;
