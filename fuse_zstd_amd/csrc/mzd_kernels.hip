@@ -53,7 +53,7 @@ namespace mzd {
 #define TTASK() do { if (tid == 0) S.ttask = __builtin_readcyclecounter(); } while (0)
 #define TTASK_END() do { if (tid == 0) S.tfin[11] = __builtin_readcyclecounter() - S.ttask; } while (0)
 #define TCOUNT(k, v) do { if (lane == 0) atomicAdd((unsigned long long*)&S.tfin[k], (unsigned long long)(v)); } while (0)
-#define TFIN_FLUSH() do { if (tid == 0 && a.debug) for (int k_ = 0; k_ < 12; k_++) a.debug[blockIdx.x].tfin[k_] = S.tfin[k_]; } while (0)
+#define TFIN_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 12; k_++) a.debug[blockIdx.x].tfin[k_] = S.tfin[k_]; } } while (0)
 #else
 #define TFIN(k)
 #define TCOUNT(k, v)
@@ -151,6 +151,10 @@ struct __attribute__((aligned(16))) Shared {
     // next file and parses its headers into `c2` (header bytes staged in a free part of the ring)
     Ctl c2;
     uint32_t pre_job, pre_valid; // the job taken ahead (kNoJob: none) and whether c2 holds its parsed first block
+    // driver 1: the small fields of the dictionary the workgroup used last (config 5: every file names the same one --
+    // reading them from HBM again for each file costs a round trip per dependent load)
+    struct { uint32_t id, formatted, al[3], huf_log, rep[3], content_len; const uint8_t* content; } dcache;
+    struct { const uint8_t* src; uint64_t n; uint8_t* dst; uint64_t cap; uint32_t dict; } pj; // the job table entry of pre_job (read once, by pre_parse_next)
 };
 
 // The workgroup's LDS image.  File scope, so that every device function addresses it with DS
@@ -2002,6 +2006,7 @@ __device__ __noinline__ void pre_parse_next(const KernelArgs& a, int lane) {
     const uint8_t* const src = a.jobs[j2].src;
     const uint64_t n = a.jobs[j2].src_len;
     const uint32_t job_dict = a.jobs[j2].dict;
+    if (lane == 0) { S.pj.src = src; S.pj.n = n; S.pj.dst = a.jobs[j2].dst; S.pj.cap = a.jobs[j2].dst_cap; S.pj.dict = job_dict; }
     if (lane == 0) {
         c2.pos = 0; c2.out = 0; c2.err = 0; c2.action = 0; c2.btype = 0; c2.diag_slow = 0;
         if (job_dict > a.ndicts) c2.err = MZD_E_DICT;
@@ -2042,24 +2047,31 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
-    if (tid == 0) { c.lds_dict_fse = 0; c.lds_dict_huf = 0; S.pre_job = kNoJob; S.pre_valid = 0; }
+    if (tid == 0) { c.lds_dict_fse = 0; c.lds_dict_huf = 0; S.pre_job = kNoJob; S.pre_valid = 0; S.dcache.id = 0; }
 
     for (;;) {
+        TTASK();
         if (tid == 0) { // the file the walking wavefront took ahead (pre_parse_next), or the next one of the queue
-            if (S.pre_job != kNoJob) { c.job = S.pre_job; c.t_valid = S.pre_valid; S.pre_job = kNoJob; S.pre_valid = 0; }
+            if (S.pre_job != kNoJob) { c.job = S.pre_job; c.t_valid = S.pre_valid | 2u; S.pre_job = kNoJob; S.pre_valid = 0; } // (bit 1: S.pj holds the job's table entry)
             else { c.job = atomicAdd(&a.counter[0], 1u); c.t_valid = 0; }
         }
-        uint32_t j;
-        bool pre; // the first block's headers are already parsed (in S.c2)
-        WG_SNAPSHOT(j = c.job; pre = c.t_valid != 0);
+        uint32_t j, tv, lf = 0, lh = 0;
+        WG_SNAPSHOT(j = c.job; tv = c.t_valid; lf = c.lds_dict_fse; lh = c.lds_dict_huf);
+        bool pre = (tv & 1) != 0; // the first block's headers are already parsed (in S.c2)
         if (j >= a.njobs) break;
-        const uint8_t* const src = a.jobs[j].src;
-        const uint64_t n = a.jobs[j].src_len;
-        uint8_t* const dst = a.jobs[j].dst;
-        const uint64_t cap = a.jobs[j].dst_cap;
-        const uint32_t job_dict = a.jobs[j].dict;
+        const bool stashed = (tv & 2) != 0;
+        const uint8_t* const src = stashed ? S.pj.src : a.jobs[j].src;
+        const uint64_t n = stashed ? S.pj.n : a.jobs[j].src_len;
+        uint8_t* const dst = stashed ? S.pj.dst : a.jobs[j].dst;
+        const uint64_t cap = stashed ? S.pj.cap : a.jobs[j].dst_cap;
+        const uint32_t job_dict = stashed ? S.pj.dict : a.jobs[j].dict;
+        if (pre) { // the prepared control block replaces the current one: by all threads, a dword each (what must survive was read above)
+            static_assert(sizeof(Ctl) % 4 == 0, "copied by dwords");
+            for (uint32_t k = (uint32_t)tid; k < sizeof(Ctl) / 4; k += kWG) reinterpret_cast<uint32_t*>(&c)[k] = reinterpret_cast<const uint32_t*>(&S.c2)[k];
+            __syncthreads();
+        }
         if (tid == 0) {
-            if (pre) { const uint32_t lf = c.lds_dict_fse, lh = c.lds_dict_huf; c = S.c2; c.lds_dict_fse = lf; c.lds_dict_huf = lh; c.job = j; }
+            if (pre) { c.lds_dict_fse = lf; c.lds_dict_huf = lh; c.job = j; }
             else { c.pos = 0; c.out = 0; c.err = 0; c.action = 0; }
             c.diag_slow = 0;
 #ifdef MZD_STAMPS
@@ -2084,7 +2096,13 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
             const bool hashing = c.has_cksum != 0; // stable for the whole frame
             if (action == 3) { // dictionary: entropy tables, repeat offsets and content
                 const DevDict* dd = &a.dicts[job_dict - 1];
-                if (dd->formatted) {
+                if (tid == 0 && S.dcache.id != job_dict) {
+                    S.dcache.formatted = dd->formatted; S.dcache.huf_log = dd->huf_log; S.dcache.content_len = dd->content_len; S.dcache.content = dd->content;
+                    for (int t_ = 0; t_ < 3; t_++) { S.dcache.al[t_] = dd->al[t_]; S.dcache.rep[t_] = dd->rep[t_]; }
+                    S.dcache.id = job_dict;
+                }
+                __syncthreads();
+                if (S.dcache.formatted) {
                     // Config 5 (many small frames, one dictionary): a workgroup keeps the dictionary's tables resident in LDS
                     // from file to file -- such frames use them as they are (repeat-mode tables, treeless literals), so the
                     // 14 KB copy happens once per workgroup, not once per file.  Any block that rebuilds a table clears the mark.
@@ -2098,14 +2116,13 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                     if (tid == 0) {
                         c.lds_dict_fse = job_dict; c.lds_dict_huf = job_dict;
                         // (a prepared first block has its sequence header parsed already: only repeat-mode tables take the dictionary's log)
-                        for (int t_ = 0; t_ < 3; t_++) if (!frame_pre || c.mode[t_] == 3) c.al[t_] = dd->al[t_];
-                        c.huf_log = dd->huf_log; c.huf_valid = 1; c.fse_valid = 1;
-                        c.rep[0] = dd->rep[0]; c.rep[1] = dd->rep[1]; c.rep[2] = dd->rep[2];
+                        for (int t_ = 0; t_ < 3; t_++) if (!frame_pre || c.mode[t_] == 3) c.al[t_] = S.dcache.al[t_];
+                        c.huf_log = S.dcache.huf_log; c.huf_valid = 1; c.fse_valid = 1;
+                        c.rep[0] = S.dcache.rep[0]; c.rep[1] = S.dcache.rep[1]; c.rep[2] = S.dcache.rep[2];
                     }
                 }
-                if (tid == 0) { c.dict_content = dd->content; c.dict_content_len = dd->content_len; }
+                if (tid == 0) { c.dict_content = S.dcache.content; c.dict_content_len = S.dcache.content_len; }
             }
-
             // ---------------- blocks
             uint32_t last = 0;
             while (true) {
@@ -2345,11 +2362,12 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
             if (err) break;
             if (has_ck) {
                 if (wave == 2) {
+                    const uint32_t stored = ld32(src + pos_now); // (issued before the digest is closed: its round trip overlaps)
                     xxh_advance(xv, xstripes, (out_now - fout0) / 32, dst + fout0, lane);
                     uint64_t h = xxh_finish(xv, dst + fout0, out_now - fout0, lane);
                     if (lane == 0) {
 #ifndef MZD_EXP_NOHASH
-                        if ((uint32_t)h != ld32(src + pos_now)) c.err = MZD_E_CHECKSUM;
+                        if ((uint32_t)h != stored) c.err = MZD_E_CHECKSUM;
 #endif
                         c.pos = pos_now + 4;
                     }
@@ -2361,6 +2379,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
         }
         if (tid == 0) { a.jobs[j].out_len = c.out; a.jobs[j].status = c.err; }
         STAMP_FLUSH();
+        TTASK_END();
         TFIN_FLUSH();
         __syncthreads();
     }

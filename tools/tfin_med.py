@@ -25,6 +25,6 @@ buf = (C.c_uint64 * (12 * 2048))()
 ns = api.lib().mzd_debug_tfin_all(0, buf, 2048)
 arr = np.frombuffer(buf, dtype=np.uint64)[: ns * 12].reshape(ns, 12).astype(np.float64)
 arr = arr[arr[:, 0] > 0]
-names = ["walker", "copier", "hasher", "planner", "lit stream 1", "tables", "headers", "huf weights", "huf table", "copier start", "slot10", "slot11"]
+names = ["walker", "copier", "hasher", "planner", "lit stream 1", "tables", "headers", "huf weights", "huf table", "copier start", "file start -> block start", "file start -> file end"]
 print("kernel ms", mzd.last_kernel_ms(0), "wgs", len(arr))
 print("; ".join("%s %.0fK" % (nm, np.median(arr[:, k]) / 1e3) for k, nm in enumerate(names)))
