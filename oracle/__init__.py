@@ -163,13 +163,20 @@ class LibZstd:
         return cls._ok
 
     @staticmethod
+    def _opened():
+        """lib() once libzstd is open behind the shim (its entry points are NULL before zref_open)."""
+        if not LibZstd.available():
+            raise RuntimeError("no libzstd shared object on this machine")
+        return lib()
+
+    @staticmethod
     def version():
         return lib().zref_version().decode()
 
     @staticmethod
     def compress_simple(data, level=0):
         """zstd::bulk::compress(data, level) (reference tests/convert.rs:15-43)."""
-        data = bytes(data); L = lib()
+        data = bytes(data); L = LibZstd._opened()
         cap = L.zref_bound(len(data)); buf = C.create_string_buffer(cap)
         r = L.zref_compress_simple(buf, cap, data, len(data), level)
         assert r >= 0
@@ -178,7 +185,7 @@ class LibZstd:
     @staticmethod
     def compress(data, level=3, checksum=True, content_size=True, window_log=0, dictionary=None):
         """The reference writer's settings by default (src/main.rs:781-791)."""
-        data = bytes(data); L = lib()
+        data = bytes(data); L = LibZstd._opened()
         cap = L.zref_bound(len(data)) + 64; buf = C.create_string_buffer(cap)
         flags = (1 if checksum else 0) | (0 if content_size else 2)
         d = bytes(dictionary) if dictionary else None
@@ -188,7 +195,7 @@ class LibZstd:
 
     @staticmethod
     def compress_stream(data, level=3, checksum=True, chunk=0, flush_each=False):
-        data = bytes(data); L = lib()
+        data = bytes(data); L = LibZstd._opened()
         cap = L.zref_bound(len(data)) + 64 + 16 * (len(data) // max(chunk, 1) + 1 if chunk else 1)
         buf = C.create_string_buffer(cap)
         r = L.zref_compress_stream(buf, cap, data, len(data), level, 1 if checksum else 0, chunk, 1 if flush_each else 0)
@@ -198,7 +205,7 @@ class LibZstd:
     @staticmethod
     def decompress(src, cap, stream8k=False, dictionary=None):
         """Returns bytes, or a negative int (libzstd error code) on failure."""
-        src = bytes(src); L = lib()
+        src = bytes(src); L = LibZstd._opened()
         buf = C.create_string_buffer(max(int(cap), 1))
         if dictionary is not None:
             d = bytes(dictionary)
@@ -211,7 +218,7 @@ class LibZstd:
 
     @staticmethod
     def train_dict(samples, cap):
-        L = lib()
+        L = LibZstd._opened()
         blob = b"".join(samples)
         sizes = (C.c_size_t * len(samples))(*[len(s) for s in samples])
         buf = C.create_string_buffer(cap)

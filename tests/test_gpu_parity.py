@@ -126,6 +126,36 @@ def test_both_drivers_decode_every_vector(driver, monkeypatch):
 
 @needs_zstd
 @pytest.mark.parametrize("driver", ["1", "2"])
+def test_every_single_byte_mutation_of_small_frames_matches_oracle(driver, monkeypatch):
+    """The fuzz corpus of SURVEY.md row N3 on the device: EVERY byte of several small frames (Huffman + FSE blocks, a
+    raw-literal block, an RLE-heavy one, levels 3 and 19) flipped three ways, ~10 000 mutants in one launch.  For each
+    mutant the status must be the oracle's and, where both accept, the bytes too -- a mutant must never hang, fault or
+    write outside its output buffer (every job gets its own buffer: a stray write shows up as a neighbour's mismatch)."""
+    monkeypatch.setenv("MZD_DRIVER", driver)
+    Z = oracle.LibZstd
+    frames = []
+    for kind, seed, size, level in (("json", 12, 700, 3), ("json", 13, 2500, 19), ("text", 14, 2000, 3), ("repeats", 15, 3000, 3),
+                                    ("int32", 16, 1200, 3), ("random", 17, 300, 3)):
+        raw = corpus.gen(kind, seed, 1, size)
+        frames.append((Z.compress(raw, level, True), size))
+    cases = []
+    for comp, size in frames:
+        for pos in range(len(comp)):
+            for flip in (0x01, 0x80, 0xFF):
+                m = bytearray(comp)
+                m[pos] ^= flip
+                cases.append((bytes(m), size + 64))
+    res = mzd.decode_batch([c for c, _ in cases], [cap for _, cap in cases])
+    bad = []
+    for i, ((comp, cap), (st, out)) in enumerate(zip(cases, res)):
+        rc, want = oracle.decode(comp, cap=cap)
+        if st != rc or (st == 0 and out != want):
+            bad.append((i, st, rc))
+    assert not bad, (len(bad), bad[:10])
+
+
+@needs_zstd
+@pytest.mark.parametrize("driver", ["1", "2"])
 def test_corrupted_multi_block_files_report_the_oracles_error(driver, monkeypatch):
     """Single-byte mutations in every block of multi-block frames (and truncations, and too-small outputs): the status
     must be the oracle's class -- with block tasks an error has to travel from the task that finds it to the task that
