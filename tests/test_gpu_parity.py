@@ -128,7 +128,7 @@ def test_both_drivers_decode_every_vector(driver, monkeypatch):
 @pytest.mark.parametrize("driver", ["1", "2"])
 def test_every_single_byte_mutation_of_small_frames_matches_oracle(driver, monkeypatch):
     """The fuzz corpus of SURVEY.md row N3 on the device: EVERY byte of several small frames (Huffman + FSE blocks, a
-    raw-literal block, an RLE-heavy one, levels 3 and 19) flipped three ways, ~10 000 mutants in one launch.  For each
+    raw-literal block, an RLE-heavy one, levels 3 and 19) flipped three ways, every truncation, and every output capacity of one frame: ~14 000 cases in one launch.  For each
     mutant the status must be the oracle's and, where both accept, the bytes too -- a mutant must never hang, fault or
     write outside its output buffer (every job gets its own buffer: a stray write shows up as a neighbour's mismatch)."""
     monkeypatch.setenv("MZD_DRIVER", driver)
@@ -145,6 +145,11 @@ def test_every_single_byte_mutation_of_small_frames_matches_oracle(driver, monke
                 m = bytearray(comp)
                 m[pos] ^= flip
                 cases.append((bytes(m), size + 64))
+        for cut in range(len(comp)):  # every truncation
+            cases.append((comp[:cut], size + 64))
+    comp0, size0 = frames[0]
+    for cap in range(size0 + 2):      # every output capacity up to one more than needed
+        cases.append((comp0, cap))
     res = mzd.decode_batch([c for c, _ in cases], [cap for _, cap in cases])
     bad = []
     for i, ((comp, cap), (st, out)) in enumerate(zip(cases, res)):
