@@ -143,7 +143,8 @@ struct __attribute__((aligned(16))) Shared {
     uint16_t huf[2048]; // sym | len << 8
     int16_t norm[3][64];
     uint16_t next[3][64];
-    int16_t wnorm[256]; // FSE table of the Huffman weights
+    alignas(16) int16_t wnorm[256]; // FSE table of the Huffman weights.  wnorm + wtab + weights (1 KiB, contiguous) double as the
+                                    // copier's literal scratch (kLitScratch): the copying wavefront is the one that decodes the weights, earlier
     uint32_t wtab[64];  // sym | nb << 8 | base << 16
     uint8_t weights[256];
     Ctl c;
@@ -1066,7 +1067,10 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         if (lds_at_zero && left >= kWalkGroup) {
             uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(left & ~(kWalkGroup - 1));
             const uint32_t n0 = n;
-            const int32_t thresh = __builtin_amdgcn_readfirstlane(st.lowest > 0 ? st.lowest * (int32_t)(kChunk * 8) + kLook : INT32_MIN / 2);
+            // (the whole stream resident: the run still ends at the first group that read past the stream's start -- a corrupt
+            //  stream: published records must never carry a position outside the stream, the planner addresses HBM with them;
+            //  records younger than kWalkLag are not published, so stopping at the group's end is early enough)
+            const int32_t thresh = __builtin_amdgcn_readfirstlane(st.lowest > 0 ? st.lowest * (int32_t)(kChunk * 8) + kLook : (int32_t)Gzero - 32);
             int32_t slack = 64; // minimum over a group of (window bits - bits needed)
             uint4 start;
             walk_run_asm(vL, vM, vO, Gm, woff, slack, n, (int32_t)i - (int32_t)kWalkLag, start, thresh, prog_lds, gwalk);
@@ -1418,8 +1422,11 @@ struct RunRegs { // one lane's share of a prepared run (kept small: two of these
     __device__ __forceinline__ bool bytewise() const { return (meta & 8) != 0; }
     __device__ __forceinline__ uint32_t src_lds() const { return meta >> 4; }
 };
+constexpr uint32_t kLitScratch = 1024;
 struct RunInfo { // wave-uniform
     uint64_t run_pos; uint32_t T, buf; bool bigl;
+    uint32_t lit0;   // the run's literals: one contiguous piece of the literal buffer starting here ...
+    bool lit_pre;    // ... of at most kLitScratch bytes: prefetched by a coalesced load (16 bytes per lane) and dealt out through LDS
     bool v1, v2; uint32_t T1, T2, buf1, buf2; // the two runs before it
 };
 
@@ -1481,18 +1488,22 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     // registers, and only then does the long part of run k (rounds, flush), which hides the loads' latency.
     // (The compiler waits with vmcnt(0) wherever the number of loads in flight depends on control flow, so
     // nothing else may be outstanding at the point where the registers are consumed.)
-    CopyRegs<2> pfL; // literals: <= 23 bytes per lane (longer runs take the straight-from-HBM path of the run)
+    uint4 pfC = make_uint4(0, 0, 0, 0); // literals: the run's whole piece of the literal buffer, 16 bytes per lane (runs with more than
+                                        // kLitScratch literal bytes read theirs straight from HBM when the run is finished)
+    static_assert(offsetof(Shared, wtab) == offsetof(Shared, wnorm) + 512 && offsetof(Shared, weights) == offsetof(Shared, wnorm) + 768 && offsetof(Shared, wnorm) % 16 == 0, "the literal scratch");
+    uint8_t* const lscr = reinterpret_cast<uint8_t*>(S.wnorm);
     CopyRegs<3> pfO; // old match bytes: <= 31 per lane
 
     // finishing a prepared run, part 1: the prefetched bytes (literals, old matches) go to the staging buffer
     auto finish_regs = [&](RunRegs& r, const RunInfo& ri) {
         uint8_t* const sb = stagebuf(ri.buf);
         CSTAMP(2);
-        if (ri.bigl) { // some literal runs exceed what the prefetch registers hold: up to 64 bytes per lane straight from HBM ...
+        if (ri.lit_pre) { // the prefetched piece goes to the scratch as it is; every lane then takes its own literals out of it
+            *reinterpret_cast<uint4*>(lscr + (uint32_t)lane * 16) = pfC;
+            copy_short(r.ll <= kShort ? r.ll : 0u, LdsLd{lscr + (r.my_lit - ri.lit0)}, LdsSt{sb + r.rel_out});
+        } else // more literal bytes than the scratch holds: up to 64 bytes per lane straight from HBM
             copy_short(r.ll <= kShort ? r.ll : 0u, GlobalLd{lit + r.my_lit}, LdsSt{sb + r.rel_out});
-            medium_literals(lit, sb, r.ll, r.my_lit, r.rel_out, lane); // ... and the longer ones (noisy data: many runs of 65..2000 literals) by all 64 lanes
-        }
-        else regs_store<2>(r.ll, LdsSt{sb + r.rel_out}, pfL);
+        if (ri.bigl) medium_literals(lit, sb, r.ll, r.my_lit, r.rel_out, lane); // literal runs of 65..~2000 bytes (noisy data), one after the other, by all 64 lanes
         regs_store<3>(r.kind() == 4 ? r.ml : 0u, LdsSt{sb + r.rel_out + r.ll}, pfO);
         CSTAMP(3);
     };
@@ -1653,11 +1664,14 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 else bytewise = true;                                                                       // straddles two buffers / ends at the buffer end
             }
             N.meta = kind | (bytewise ? 8u : 0u) | (src_lds << 4);
-            NI.bigl = __any(N.ll > 23);
+            NI.bigl = __any(N.ll > kShort);
+            NI.lit0 = __builtin_amdgcn_readlane(my_lit, a);
+            const uint32_t lit_bytes = __builtin_amdgcn_readlane(my_lit + ll, b - 1) - NI.lit0; // (lanes a .. b-1 are valid: their literals are consecutive)
+            NI.lit_pre = lit_bytes <= kLitScratch;
             // ---- the previous run's prefetched bytes leave the registers; this run's loads take their place and
             //      stay in flight during the long part of the previous run
             if (haveR) finish_regs(R, RI);
-            if (!NI.bigl) regs_load<2>(N.ll, GlobalLd{lit + my_lit}, pfL);
+            if (NI.lit_pre && (uint32_t)lane * 16 < lit_bytes) __builtin_memcpy(&pfC, (gcptr)(lit + NI.lit0 + (uint32_t)lane * 16), 16); // (may read up to 15 bytes past the piece: padded buffers)
             regs_load<3>(N.kind() == 4 ? N.ml : 0u, GlobalLd{match_src(N.rel_src, run_pos)}, pfO);
             if (haveR) finish_rest(R, RI);
             R = N; RI = NI; haveR = true;
