@@ -160,6 +160,30 @@ def test_every_single_byte_mutation_of_small_frames_matches_oracle(driver, monke
 
 
 @needs_zstd
+def test_random_mutations_of_128k_frames_match_oracle():
+    """Single-block frames of the config-2 size (thousands of sequences: the state walk runs through many ring refills,
+    the planner and the copier follow it through HBM queues), 400 random single-byte mutations each.  A corrupt
+    sequence bitstream must end in the oracle's status without any stage acting on positions outside the stream."""
+    rng = np.random.RandomState(91)
+    cases = []
+    for kind, seed in (("json", 31), ("text", 32), ("int32", 33), ("markup", 34)):
+        cp = corpus.build_corpus(kind, seed, [131072])
+        good = cp.comp_file(0).tobytes()
+        for _ in range(400):
+            b = bytearray(good)
+            pos = int(rng.randint(0, len(b)))
+            b[pos] ^= int(rng.randint(1, 256))
+            cases.append((bytes(b), 131072))
+    res = mzd.decode_batch([c for c, _ in cases], [cap for _, cap in cases])
+    bad = []
+    for i, ((comp, cap), (st, out)) in enumerate(zip(cases, res)):
+        rc, want = oracle.decode(comp, cap=cap)
+        if st != rc or (st == 0 and out != want):
+            bad.append((i, st, rc))
+    assert not bad, (len(bad), bad[:10])
+
+
+@needs_zstd
 @pytest.mark.parametrize("driver", ["1", "2"])
 def test_corrupted_multi_block_files_report_the_oracles_error(driver, monkeypatch):
     """Single-byte mutations in every block of multi-block frames (and truncations, and too-small outputs): the status
@@ -171,7 +195,7 @@ def test_corrupted_multi_block_files_report_the_oracles_error(driver, monkeypatc
     for kind, size in (("json", 600000), ("text", 400000), ("xray", 300000), ("repeats", 500000)):
         cp = corpus.build_corpus(kind, 21, [size])
         good = cp.comp_file(0).tobytes()
-        for _ in range(24):
+        for _ in range(120):
             b = bytearray(good)
             pos = int(rng.randint(0, len(b)))
             b[pos] ^= int(rng.randint(1, 256))
