@@ -105,6 +105,7 @@ struct Ctl {
     uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
     uint32_t next_stream, streams_done, streams_mask; // Huffman streams are handed out to whichever wavefront is free; mask: bit k = stream k decoded
     uint32_t tables_ready, plan_prog, copy_prog, plan_lit_used; // walker -> planner -> copier
+    uint32_t plan_too_long; // the plan ends where the block's output passes 128 KiB: the copier, which reports in stream order, gives the verdict
     uint32_t seq_parsed;                           // the sequence header is parsed: nseq, seq_off, seq_len, modes are final
     uint32_t exec_done;                            // the copying wavefront has finished the block
     uint64_t exec_pos;                             // output bytes complete and visible (published by the executor)
@@ -1210,6 +1211,7 @@ __device__ __forceinline__ void copy_short(uint32_t n, LD ld, ST st) { // n <= 6
 }
 
 constexpr uint32_t kPlanFin = 0x80000000u;
+constexpr int kPlanBlockTooLong = -64; // plan_wave: the block's output passes 128 KiB (internal: becomes Ctl::plan_too_long)
 
 struct PlanCtx { // what the planning wavefront needs
     const uint4* walk;       // state-walk records of the block (HBM scratch)
@@ -1341,22 +1343,25 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint32_t incl_t = wave_incl_scan(tot, lane), incl_l = wave_incl_scan(ll, lane);
         const uint32_t chunk_tot = __builtin_amdgcn_readlane(incl_t, 63), chunk_lit = __builtin_amdgcn_readlane(incl_l, 63);
         if (chunk_lit > cx.nlit - lpos) return MZD_E_CORRUPT;
-        if (opos + chunk_tot > kBlockMax) return MZD_E_CORRUPT;
         const uint32_t ex_t = incl_t - tot; // this sequence's output offset inside the 64-chunk
         // the plan of this sequence: {ll, ml, offset, output offset inside the chunk} -> HBM (unbounded, so the
         // planner never waits for the copier, which may still be decoding literals); also what mzd_debug_last_block shows
         if (valid) seqs[i] = make_uint4(ll, ml, off, ex_t);
+        if (opos + chunk_tot > kBlockMax) { // the block's output passes 128 KiB inside this chunk: it is still published -- the copier
+            wg_fence();                    // finds the first offending sequence in stream order -- and it is the plan's last
+            if (lane == 0) flag_store(&S.c.plan_prog, chunk + 1);
+            return kPlanBlockTooLong;
+        }
         opos += chunk_tot;
         lpos += chunk_lit;
     }
     const uint32_t rest = cx.nlit - lpos;
-    if (opos + rest > kBlockMax) return MZD_E_CORRUPT;
     wg_fence();
     if (lane == 0) {
         S.c.rep_op[0] = R.s; S.c.rep_op[1] = (uint32_t)R.v0; S.c.rep_op[2] = (uint32_t)R.v1; S.c.rep_op[3] = (uint32_t)R.v2;
         S.c.plan_lit_used = lpos; flag_store(&S.c.plan_prog, chunk);
     }
-    return 0;
+    return opos + rest > kBlockMax ? kPlanBlockTooLong : 0; // (only the literals after the last sequence pass the limit: every chunk is published)
 }
 
 struct CopyCtx {
@@ -1429,6 +1434,38 @@ struct RunInfo { // wave-uniform
     bool lit_pre;    // ... of at most kLitScratch bytes: prefetched by a coalesced load (16 bytes per lane) and dealt out through LDS
     bool v1, v2; uint32_t T1, T2, buf1, buf2; // the two runs before it
 };
+
+// Errors of the execute stage are reported the way the reference finds them: it decodes ALL sequences of a block (and its
+// literals) before it executes any, and then takes the sequences in order, each checked against the destination's end,
+// then the 128 KiB block limit, then its offset.  Both functions run once, after the copier's loop (cold code).
+// A verdict of the copying wavefront waits until the walker and the literal decoders have theirs (a corrupt bitstream
+// wins: it is posted first) ...
+__device__ __noinline__ int exec_verdict(int rc, uint32_t nseq, uint32_t lit_streams) {
+    for (uint32_t it = 0; it < (1u << 24); it++) {
+        const bool walked = !nseq || (flag_load(&S.c.walk_prog) & kWalkFin) != 0;
+        const bool lits = !lit_streams || __atomic_load_n(&S.c.streams_done, __ATOMIC_RELAXED) >= lit_streams;
+        if ((walked && lits) || __atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return rc;
+}
+// ... and inside the chunk that cannot be executed (sequences base .. base+63 of the plan, read again here) the earliest
+// offending sequence decides.  room / blk_room: bytes left in the destination / under the block limit at the chunk's
+// start; hist: output of the frame + dictionary bytes before the chunk; rep: the block's starting repeat offsets.
+__device__ __noinline__ int chunk_verdict(const uint4* plan, uint32_t base, int lane, uint64_t room, uint32_t blk_room, uint64_t hist,
+                                          uint32_t rep0, uint32_t rep1, uint32_t rep2, uint32_t nseq, uint32_t lit_streams) {
+    const bool valid = base + (uint32_t)lane < nseq;
+    const uint4 pe = valid ? plan[base + (uint32_t)lane] : make_uint4(0, 0, 0, 0);
+    uint32_t off = pe.z;
+    if (off & kOffTag) off = (uint32_t)sel3((off >> 29) & 3, (int32_t)rep0, (int32_t)rep1, (int32_t)rep2) + (off & 0x1FFFFFFFu) - (uint32_t)kOffBias; // (as in copy_wave)
+    const uint32_t ll = pe.x, ml = pe.y, ex_t = pe.w, incl_t = ex_t + ll + ml;
+    const uint64_t over = __ballot(valid && incl_t > room);
+    const uint64_t bad = __ballot(valid && (incl_t > blk_room || off == 0 || off > hist + ex_t + ll));
+    const int fo = over ? __builtin_ctzll(over) : 64, fb = bad ? __builtin_ctzll(bad) : 64;
+    // (a sequence that is both is "destination too small": checked first.  Neither: the plan ended here -- block too long --
+    //  without a sequence of this chunk being at fault, which cannot happen; reported as corrupt)
+    return exec_verdict(fo <= fb && fo < 64 ? MZD_E_DSTSIZE : MZD_E_CORRUPT, nseq, lit_streams);
+}
 
 __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint64_t* opos_io, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
@@ -1567,15 +1604,20 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         if ((uint32_t)lane < nseq) pe_next = plan[lane];
     }
     uint32_t chunk = 0;
+    uint32_t blk_room = kBlockMax; // bytes left under the block limit
+    uint32_t tbase = 0xFFFFFFFFu; // the chunk that cannot be executed (see chunk_verdict)
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
         const uint4 pe = pe_next; // loaded an iteration ago
         CSTAMP(1);
+        bool cut = false; // the plan ends with this chunk (the block's output passes 128 KiB in it)
         if (chunk + 1 < nchunks) { // prefetch the next chunk's plan
-            if (!wait_plan(chunk + 2)) return MZD_E_CORRUPT;
-            CSTAMP(0);
-            const uint32_t j = base + 64 + (uint32_t)lane;
-            pe_next = j < nseq ? plan[j] : make_uint4(0, 0, 0, 0);
+            if (wait_plan(chunk + 2)) {
+                CSTAMP(0);
+                const uint32_t j = base + 64 + (uint32_t)lane;
+                pe_next = j < nseq ? plan[j] : make_uint4(0, 0, 0, 0);
+            } else if (__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED)) cut = true;
+            else return MZD_E_CORRUPT;
         }
         const bool valid = (uint32_t)lane < cnt;
         const uint32_t ll = valid ? pe.x : 0, ml = valid ? pe.y : 0, ex_t = pe.w;
@@ -1587,8 +1629,12 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         }
         const uint32_t incl_t = ex_t + ll + ml;
         const uint32_t chunk_tot = __builtin_amdgcn_readlane(incl_t, cnt - 1);
-        if (chunk_tot > cap - opos) return MZD_E_DSTSIZE;
-        if (__any(valid && (off == 0 || off > (opos + ex_t + ll - frame_start) + dict_len))) return MZD_E_CORRUPT; // beyond the window's history
+        if (chunk_tot > cap - opos || chunk_tot > blk_room || cut ||
+            __any(valid && (off == 0 || off > (opos + ex_t + ll - frame_start) + dict_len))) { // (beyond the window's history)
+            tbase = base;
+            break;
+        }
+        blk_room -= chunk_tot;
         const uint32_t incl_l = wave_incl_scan(ll, lane);
         const uint32_t my_lit = lpos + (incl_l - ll);
         lpos += __builtin_amdgcn_readlane(incl_l, 63);
@@ -1680,6 +1726,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         }
         opos += chunk_tot;
     }
+    if (tbase != 0xFFFFFFFFu) return chunk_verdict(plan, tbase, lane, cap - opos, blk_room, (opos - frame_start) + dict_len, cx.rep[0], cx.rep[1], cx.rep[2], nseq, lit_streams);
     if (haveR) { finish_regs(R, RI); finish_rest(R, RI); }
     // the literals after the last sequence: the planner has validated them once it is finished
     if (nseq) {
@@ -1689,6 +1736,8 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
+        if (__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED)) // only the literals after the last sequence pass the block limit: the destination's end comes first
+            return exec_verdict(cap - *opos_io <= kBlockMax ? MZD_E_DSTSIZE : MZD_E_CORRUPT, nseq, lit_streams);
         if (lpos != __atomic_load_n(&S.c.plan_lit_used, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
         if (nlit_all - lpos > cap - opos) return MZD_E_DSTSIZE;
     } else {
@@ -2174,7 +2223,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                     if (tid == 0) {
                         c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = out0;
                         c.next_stream = 0; c.streams_done = 0; c.streams_mask = 0;
-                        c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.seq_parsed = 0;
+                        c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.plan_too_long = 0; c.seq_parsed = 0;
                         c.rep_op[0] = 0 | (1 << 2) | (2 << 4); c.rep_op[1] = 0; c.rep_op[2] = 0; c.rep_op[3] = 0;
                         if (!block_pre) parse_literals(c, S.stage, bsize);
                     }
@@ -2266,6 +2315,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                                 __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
                                 rc = plan_wave(seqs, nseq, px, lane);
                                 __builtin_amdgcn_s_setprio(0);
+                                if (rc == kPlanBlockTooLong) { rc = 0; if (lane == 0) c.plan_too_long = 1; } // (not an error yet: see copy_wave)
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) {
@@ -2596,7 +2646,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
             if (tid == 0) {
                 c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = 0;
                 c.next_stream = 0; c.streams_done = 0; c.streams_mask = 0;
-                c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.seq_parsed = 0;
+                c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.plan_too_long = 0; c.seq_parsed = 0;
                 c.rep_op[0] = 0 | (1 << 2) | (2 << 4); c.rep_op[1] = 0; c.rep_op[2] = 0; c.rep_op[3] = 0; // identity: a block without sequences
                 parse_literals(c, S.stage, bsize);
             }
@@ -2730,6 +2780,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                             __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
                             rc = plan_wave(seqs, nseq, px, lane);
                             __builtin_amdgcn_s_setprio(0);
+                            if (rc == kPlanBlockTooLong) { rc = 0; if (lane == 0) c.plan_too_long = 1; } // (not an error yet: see copy_wave)
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) {

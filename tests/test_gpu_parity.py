@@ -160,6 +160,37 @@ def test_every_single_byte_mutation_of_small_frames_matches_oracle(driver, monke
 
 
 @needs_zstd
+@pytest.mark.parametrize("driver", ["1", "2"])
+def test_multi_byte_mutations_match_oracle(driver, monkeypatch):
+    """One to three mutated bytes per frame, eight data classes x three levels (tools/fuzz_more.py runs the same generator
+    with more cases).  Several things are wrong at once in such frames, so the status depends on WHICH error is found
+    first: the oracle decodes a block's sequences and literals before it executes any sequence, then takes the sequences
+    in order (destination's end, 128 KiB block limit, offset).  The device pipeline reports in that order too -- e.g. a
+    highly repetitive frame ("repeats": 128 KiB from 128 bytes) whose first sequence got a bad offset AND whose output
+    would pass the destination is "corrupt", not "destination too small"."""
+    monkeypatch.setenv("MZD_DRIVER", driver)
+    rng = np.random.RandomState(8)
+    cases = []
+    for kind, seed, size in (("json", 41, 131072), ("text", 42, 100000), ("markup", 43, 60000), ("xray", 44, 131072), ("json", 45, 20000),
+                             ("dna", 46, 50000), ("repeats", 47, 131072), ("json", 48, 4096)):
+        for level in (1, 3, 19):
+            cp = corpus.build_corpus(kind, seed, [size], level=level)
+            good = cp.comp_file(0).tobytes()
+            for _ in range(60):
+                b = bytearray(good)
+                for _ in range(int(rng.randint(1, 4))):
+                    b[int(rng.randint(0, len(b)))] ^= int(rng.randint(1, 256))
+                cases.append((bytes(b), size))
+    res = mzd.decode_batch([c for c, _ in cases], [cap for _, cap in cases])
+    bad = []
+    for i, ((comp, cap), (st, out)) in enumerate(zip(cases, res)):
+        rc, want = oracle.decode(comp, cap=cap)
+        if st != rc or (st == 0 and out != want):
+            bad.append((i, st, rc))
+    assert not bad, (len(bad), bad[:10])
+
+
+@needs_zstd
 def test_random_mutations_of_128k_frames_match_oracle():
     """Single-block frames of the config-2 size (thousands of sequences: the state walk runs through many ring refills,
     the planner and the copier follow it through HBM queues), 400 random single-byte mutations each.  A corrupt
