@@ -105,7 +105,8 @@ struct Ctl {
     uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
     uint32_t next_stream, streams_done, streams_mask; // Huffman streams are handed out to whichever wavefront is free; mask: bit k = stream k decoded
     uint32_t tables_ready, plan_prog, copy_prog, plan_lit_used; // walker -> planner -> copier
-    uint32_t plan_too_long; // the plan ends where the block's output passes 128 KiB: the copier, which reports in stream order, gives the verdict
+    uint32_t plan_too_long; // 1: the plan ends with a chunk that cannot be executed (literals run out / output passes 128 KiB); 2: only the literals after
+                            // the last sequence pass 128 KiB.  No error yet: the copier, which reports in stream order, gives the verdict
     uint32_t seq_parsed;                           // the sequence header is parsed: nseq, seq_off, seq_len, modes are final
     uint32_t exec_done;                            // the copying wavefront has finished the block
     uint64_t exec_pos;                             // output bytes complete and visible (published by the executor)
@@ -1342,13 +1343,15 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint32_t tot = ll + ml;
         const uint32_t incl_t = wave_incl_scan(tot, lane), incl_l = wave_incl_scan(ll, lane);
         const uint32_t chunk_tot = __builtin_amdgcn_readlane(incl_t, 63), chunk_lit = __builtin_amdgcn_readlane(incl_l, 63);
-        if (chunk_lit > cx.nlit - lpos) return MZD_E_CORRUPT;
         const uint32_t ex_t = incl_t - tot; // this sequence's output offset inside the 64-chunk
         // the plan of this sequence: {ll, ml, offset, output offset inside the chunk} -> HBM (unbounded, so the
         // planner never waits for the copier, which may still be decoding literals); also what mzd_debug_last_block shows
         if (valid) seqs[i] = make_uint4(ll, ml, off, ex_t);
-        if (opos + chunk_tot > kBlockMax) { // the block's output passes 128 KiB inside this chunk: it is still published -- the copier
-            wg_fence();                    // finds the first offending sequence in stream order -- and it is the plan's last
+        if (chunk_lit > cx.nlit - lpos || opos + chunk_tot > kBlockMax) {
+            // the literals run out, or the block's output passes 128 KiB, inside this chunk: it is still published -- the copier
+            // finds the first offending sequence in stream order -- and it is the plan's last (the mark is set first)
+            if (lane == 0) S.c.plan_too_long = 1;
+            wg_fence();
             if (lane == 0) flag_store(&S.c.plan_prog, chunk + 1);
             return kPlanBlockTooLong;
         }
@@ -1359,9 +1362,11 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
     wg_fence();
     if (lane == 0) {
         S.c.rep_op[0] = R.s; S.c.rep_op[1] = (uint32_t)R.v0; S.c.rep_op[2] = (uint32_t)R.v1; S.c.rep_op[3] = (uint32_t)R.v2;
-        S.c.plan_lit_used = lpos; flag_store(&S.c.plan_prog, chunk);
+        S.c.plan_lit_used = lpos;
+        if (opos + rest > kBlockMax) S.c.plan_too_long = 2; // only the literals after the last sequence pass the limit: every chunk is published
+        flag_store(&S.c.plan_prog, chunk);
     }
-    return opos + rest > kBlockMax ? kPlanBlockTooLong : 0; // (only the literals after the last sequence pass the limit: every chunk is published)
+    return opos + rest > kBlockMax ? kPlanBlockTooLong : 0;
 }
 
 struct CopyCtx {
@@ -1452,19 +1457,21 @@ __device__ __noinline__ int exec_verdict(int rc, uint32_t nseq, uint32_t lit_str
 // ... and inside the chunk that cannot be executed (sequences base .. base+63 of the plan, read again here) the earliest
 // offending sequence decides.  room / blk_room: bytes left in the destination / under the block limit at the chunk's
 // start; hist: output of the frame + dictionary bytes before the chunk; rep: the block's starting repeat offsets.
-__device__ __noinline__ int chunk_verdict(const uint4* plan, uint32_t base, int lane, uint64_t room, uint32_t blk_room, uint64_t hist,
+__device__ __noinline__ int chunk_verdict(const uint4* plan, uint32_t base, int lane, uint64_t room, uint32_t blk_room, uint64_t hist, uint32_t lit_room,
                                           uint32_t rep0, uint32_t rep1, uint32_t rep2, uint32_t nseq, uint32_t lit_streams) {
     const bool valid = base + (uint32_t)lane < nseq;
     const uint4 pe = valid ? plan[base + (uint32_t)lane] : make_uint4(0, 0, 0, 0);
     uint32_t off = pe.z;
     if (off & kOffTag) off = (uint32_t)sel3((off >> 29) & 3, (int32_t)rep0, (int32_t)rep1, (int32_t)rep2) + (off & 0x1FFFFFFFu) - (uint32_t)kOffBias; // (as in copy_wave)
     const uint32_t ll = pe.x, ml = pe.y, ex_t = pe.w, incl_t = ex_t + ll + ml;
+    // per sequence the reference checks: literals left (lit_room: literals not yet used at the chunk's start), destination's
+    // end, block limit, offset -- "destination too small" only if nothing before it in that order is wrong
+    const uint64_t nolit = __ballot(valid && wave_incl_scan(ll, lane) > lit_room);
     const uint64_t over = __ballot(valid && incl_t > room);
     const uint64_t bad = __ballot(valid && (incl_t > blk_room || off == 0 || off > hist + ex_t + ll));
-    const int fo = over ? __builtin_ctzll(over) : 64, fb = bad ? __builtin_ctzll(bad) : 64;
-    // (a sequence that is both is "destination too small": checked first.  Neither: the plan ended here -- block too long --
-    //  without a sequence of this chunk being at fault, which cannot happen; reported as corrupt)
-    return exec_verdict(fo <= fb && fo < 64 ? MZD_E_DSTSIZE : MZD_E_CORRUPT, nseq, lit_streams);
+    const int fl = nolit ? __builtin_ctzll(nolit) : 64, fo = over ? __builtin_ctzll(over) : 64, fb = bad ? __builtin_ctzll(bad) : 64;
+    // (none of the three: the plan ended here without a sequence of this chunk being at fault, which cannot happen; corrupt)
+    return exec_verdict(fo < fl && fo <= fb ? MZD_E_DSTSIZE : MZD_E_CORRUPT, nseq, lit_streams);
 }
 
 __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint64_t* opos_io, int lane) {
@@ -1501,6 +1508,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     uint32_t lit_avail = lit_streams ? 0u : nlit_all;
     auto wait_lits = [&](uint32_t need) -> bool {
         if (need <= lit_avail) return true;
+        if (need > nlit_all) return false; // more literals than the block has (the caller tells the two failures apart)
         for (uint32_t it = 0; it < (1u << 24); it++) {
             const uint32_t m = flag_load(&S.c.streams_mask);
             const uint32_t k = (uint32_t)__builtin_ctz(~m); // first stream not decoded yet
@@ -1616,7 +1624,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 CSTAMP(0);
                 const uint32_t j = base + 64 + (uint32_t)lane;
                 pe_next = j < nseq ? plan[j] : make_uint4(0, 0, 0, 0);
-            } else if (__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED)) cut = true;
+            } else if (__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED) == 1) cut = true;
             else return MZD_E_CORRUPT;
         }
         const bool valid = (uint32_t)lane < cnt;
@@ -1638,7 +1646,12 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         const uint32_t incl_l = wave_incl_scan(ll, lane);
         const uint32_t my_lit = lpos + (incl_l - ll);
         lpos += __builtin_amdgcn_readlane(incl_l, 63);
-        if (!wait_lits(lpos)) return MZD_E_CORRUPT; // a literal stream failed (the error is posted)
+        if (__builtin_expect(!wait_lits(lpos), 0)) {
+            if (lpos <= nlit_all) return MZD_E_CORRUPT; // a literal stream failed (the error is posted)
+            lpos -= __builtin_amdgcn_readlane(incl_l, 63); // the literals run out inside this chunk (the plan's last: see plan_wave)
+            tbase = base;
+            break;
+        }
         const uint64_t mdst = opos + ex_t + ll; // absolute match destination
         // a match that starts before the frame reads the dictionary (config 5: most matches of a small record do).  When
         // its whole source lies there it is an ordinary old match with another base address; one that runs from the
@@ -1726,7 +1739,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         }
         opos += chunk_tot;
     }
-    if (tbase != 0xFFFFFFFFu) return chunk_verdict(plan, tbase, lane, cap - opos, blk_room, (opos - frame_start) + dict_len, cx.rep[0], cx.rep[1], cx.rep[2], nseq, lit_streams);
+    if (tbase != 0xFFFFFFFFu) return chunk_verdict(plan, tbase, lane, cap - opos, blk_room, (opos - frame_start) + dict_len, nlit_all - lpos, cx.rep[0], cx.rep[1], cx.rep[2], nseq, lit_streams);
     if (haveR) { finish_regs(R, RI); finish_rest(R, RI); }
     // the literals after the last sequence: the planner has validated them once it is finished
     if (nseq) {
@@ -1736,7 +1749,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
-        if (__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED)) // only the literals after the last sequence pass the block limit: the destination's end comes first
+        if (__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED) == 2) // only the literals after the last sequence pass the block limit: the destination's end comes first
             return exec_verdict(cap - *opos_io <= kBlockMax ? MZD_E_DSTSIZE : MZD_E_CORRUPT, nseq, lit_streams);
         if (lpos != __atomic_load_n(&S.c.plan_lit_used, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
         if (nlit_all - lpos > cap - opos) return MZD_E_DSTSIZE;
@@ -2315,7 +2328,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                                 __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
                                 rc = plan_wave(seqs, nseq, px, lane);
                                 __builtin_amdgcn_s_setprio(0);
-                                if (rc == kPlanBlockTooLong) { rc = 0; if (lane == 0) c.plan_too_long = 1; } // (not an error yet: see copy_wave)
+                                if (rc == kPlanBlockTooLong) rc = 0; // (not an error yet: Ctl::plan_too_long, copy_wave)
                             }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) {
@@ -2780,7 +2793,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                             __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
                             rc = plan_wave(seqs, nseq, px, lane);
                             __builtin_amdgcn_s_setprio(0);
-                            if (rc == kPlanBlockTooLong) { rc = 0; if (lane == 0) c.plan_too_long = 1; } // (not an error yet: see copy_wave)
+                            if (rc == kPlanBlockTooLong) rc = 0; // (not an error yet: Ctl::plan_too_long, copy_wave)
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) {

@@ -191,6 +191,45 @@ def test_multi_byte_mutations_match_oracle(driver, monkeypatch):
 
 
 @needs_zstd
+def test_mutated_dictionary_frames_and_multi_frame_files_match_oracle():
+    """Config-5-shaped records with mutated bytes, with the dictionary missing, truncated; files of frame + skippable frame +
+    frame with mutated bytes (tools/fuzz_dict.py runs the same generator with more cases)."""
+    rng = np.random.RandomState(3)
+    Z = oracle.LibZstd
+    assert Z.available()
+    sizes = [int(x) for x in np.random.RandomState(55).randint(300, 3001, size=200)]
+    d = corpus.train_dict("json", 5, sizes[:150], cap=40000)
+    h = mzd.load_dict(d)
+    cp = corpus.build_corpus("json", 5, sizes, dictionary=d)
+    cases = []
+    for i in range(0, 200, 2):
+        good = cp.comp_file(i).tobytes()
+        for _ in range(6):
+            b = bytearray(good)
+            for _ in range(int(rng.randint(1, 3))):
+                b[int(rng.randint(0, len(b)))] ^= int(rng.randint(1, 256))
+            cases.append((bytes(b), sizes[i], d, h))
+        cases.append((good, sizes[i], None, 0))
+        cases.append((good[:int(rng.randint(0, len(good)))], sizes[i], d, h))
+    for k in range(60):
+        a = Z.compress(corpus.gen("json", 60 + k, 1, 3000), 3, True)
+        b2 = Z.compress(corpus.gen("text", 61 + k, 1, 2000), 3, bool(k & 1))
+        skip = (0x184D2A50 + (k & 15)).to_bytes(4, "little") + (7).to_bytes(4, "little") + b"skipped"
+        f = bytearray(a + skip + b2)
+        if k % 3:
+            for _ in range(int(rng.randint(1, 3))):
+                f[int(rng.randint(0, len(f)))] ^= int(rng.randint(1, 256))
+        cases.append((bytes(f), 5000 if k % 5 else 4000, None, 0))
+    res = mzd.decode_batch([c[0] for c in cases], [c[1] for c in cases], [c[3] for c in cases])
+    bad = []
+    for i, ((comp, cap, dd, _), (st, out)) in enumerate(zip(cases, res)):
+        rc, want = oracle.decode(comp, cap=cap, dictionary=dd)
+        if st != rc or (st == 0 and out != want):
+            bad.append((i, st, rc))
+    assert not bad, (len(bad), bad[:10])
+
+
+@needs_zstd
 def test_random_mutations_of_128k_frames_match_oracle():
     """Single-block frames of the config-2 size (thousands of sequences: the state walk runs through many ring refills,
     the planner and the copier follow it through HBM queues), 400 random single-byte mutations each.  A corrupt
