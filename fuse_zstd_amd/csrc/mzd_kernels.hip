@@ -17,7 +17,7 @@
 //   K2  Huffman literals        64 lanes per stream by self-synchronising sub-stream decode (memoized entry
 //                               offsets) + DPP scan for the output offsets; streams handed out by a queue
 //   K3  FSE tables x3           one wavefront, ballot-rank symbol spread                                  (A.3)
-//   K4a FSE state walk          wavefront 0: the serial chain, tables + bitstream ring in LDS, 8-byte records (A.5)
+//   K4a FSE state walk          wavefront 0: the serial chain, tables + bitstream ring in LDS, 16-byte records (A.5)
 //   K4b plan                    wavefront 3: fields, symbolic repeat offsets (DPP scan), positions, validation
 //   K5  sequence execute        wavefront 1: runs of <= 64 sequences staged in LDS, prefetched HBM sources,
 //                               LDS->LDS matches in rounds, 16-byte coalesced flushes                     (A.5)
@@ -839,7 +839,7 @@ __device__ __noinline__ void build_seq_table_wave(uint64_t* tab, const int16_t* 
 //      single wavefront walks it.  On a lone wavefront every instruction costs ~4 cycles of issue,
 //      so the loop does only what the chain needs: three table reads + one 8-byte bitstream
 //      window (all LDS, issued together), the bit budget of the sequence, the three state updates.
-//      Per sequence it records {bit position, three states} (8 bytes) and nothing else.
+//      Per sequence it records {three state offsets, bit position} (16 bytes, its registers as they stand) and nothing else.
 //  (b) field conversion -- everything that is NOT a chain: extra bits, base values.  One lane per
 //      sequence, straight from the records of (a); done by the planning wavefront (plan_wave),
 //      64 sequences at a time, while the walker is already further down the stream.
