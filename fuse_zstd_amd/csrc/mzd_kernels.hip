@@ -836,7 +836,7 @@ __device__ __noinline__ void build_seq_table_wave(uint64_t* tab, const int16_t* 
 //
 //  (a) walk_sequences_wave -- the part that is serial by construction.  One bitstream carries three
 //      interleaved tANS states; state i+1 depends on the bits state i consumed, so a
-//      single wavefront walks it.  On a lone wavefront every instruction costs ~4 cycles of issue,
+//      single wavefront walks it.  On a lone wavefront every instruction costs 6-7.5 cycles of issue (tools/micro/asm_micro.hip),
 //      so the loop does only what the chain needs: three table reads + one 8-byte bitstream
 //      window (all LDS, issued together), the bit budget of the sequence, the three state updates.
 //      Per sequence it records {three state offsets, bit position} (16 bytes, its registers as they stand) and nothing else.
@@ -900,7 +900,7 @@ constexpr uint32_t kInRing = 0x80000000u;   // parse_seq_header: the staged head
 // The hot form of the chain, hand-scheduled: runs of kWalkGroup steps until n steps are done, or a group met a
 // sequence wider than its window (slack < 0: the group is void, the caller takes it again carefully from {sx, sy}, the
 // packed state at the group's start), or the read head comes within one group of the lowest resident ring chunk
-// (Gm < thresh: the caller refills).  A lone wavefront issues in order, ~5 cycles an instruction, and the four LDS reads
+// (Gm < thresh: the caller refills).  A lone wavefront issues in order, 6.25 (4-byte encodings) to 7.5 cycles (8-byte) an instruction, and the four LDS reads
 // return through a 64 B/clk path (32 clks): a step is the 12 chain instructions + the reads' round trip, ~137 cycles
 // (tools/micro/asm_micro.hip); whatever the chain does not need -- the record store, packing the next record, the
 // slack bookkeeping, publishing progress -- sits behind the reads, in the shadow of their latency.  Same arithmetic
