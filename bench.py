@@ -90,8 +90,14 @@ def cpu_baseline(cp, budget_s=10.0):
         # thread count: the fastest of {all hardware threads, half, a quarter} on a short probe (SMT rarely helps libzstd)
         probe = {}
         for nt in sorted({cores, max(cores // 2, 1), max(cores // 4, 1)}):
-            p = max(1, int(0.3 / max(b2(nt, 1), 1e-4)))
-            probe[nt] = total_out * p / b2(nt, p)
+            # (freshly created threads take a few hundred ms to spread over the cores: each probe lasts >= ~1 s)
+            p = max(1, -(-(256 << 20) // total_out))
+            while True:
+                tp = b2(nt, p)
+                if tp >= 1.0 or p >= 1 << 16:
+                    break
+                p = int(p * max(2.0, 1.2 / max(tp, 1e-3)))
+            probe[nt] = total_out * p / tp
         best_nt = max(probe, key=probe.get)
         reps = max(1, min(100000, int(budget_s * 0.6 * probe[best_nt] / total_out)))
         tt = b2(best_nt, reps)
