@@ -17,7 +17,8 @@ CONTENTSIZE_ERROR = 2**64 - 2
 EXPORTS = [
     "mzd_init", "mzd_shutdown", "mzd_device_count", "mzd_content_size", "mzd_decode", "mzd_decode_batch",
     "mzd_decode_batch_device", "mzd_batch_prepare", "mzd_batch_launch", "mzd_batch_collect", "mzd_batch_free",
-    "mzd_load_dict", "mzd_debug_last_block", "mzd_last_kernel_ms", "mzd_strerror", "mzd_version",
+    "mzd_load_dict", "mzd_unload_dict", "mzd_debug_last_block", "mzd_debug_set_driver", "mzd_debug_counters", "mzd_debug_stamps", "mzd_debug_tfin_all",
+    "mzd_host_alloc", "mzd_host_free", "mzd_last_kernel_ms", "mzd_strerror", "mzd_version",
     "mzd_fs_new", "mzd_fs_free", "mzd_fs_open", "mzd_fs_read", "mzd_fs_release", "mzd_fs_decode_count",
 ]
 
@@ -30,13 +31,13 @@ class MzdError(RuntimeError):
 
 class Job(C.Structure):  # mzd_job
     _fields_ = [("src", C.c_void_p), ("src_len", C.c_size_t), ("dst", C.c_void_p), ("dst_cap", C.c_size_t),
-                ("out_len", C.c_size_t), ("status", C.c_int32), ("dict_id", C.c_uint32)]
+                ("out_len", C.c_size_t), ("status", C.c_int32), ("dict_id", C.c_uint32), ("device", C.c_int32)]
 
 
 def build(force=False):
     """hipcc --offload-arch=gfx950 build of libmzd.so, in-tree (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("mzd_kernels.hip", "mzd_host.cpp", "mzd_device.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("mzd_kernels.hip", "mzd_small.hip", "mzd_host.cpp", "mzd_device.h", "mzd_tables.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mzd.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", src_dir, "-s"])
@@ -85,6 +86,12 @@ def lib():
         L.mzd_batch_free.argtypes = [C.c_void_p]
         L.mzd_batch_free.restype = None
         L.mzd_load_dict.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
+        L.mzd_unload_dict.argtypes = [C.c_uint32]
+        L.mzd_debug_set_driver.argtypes = [C.c_int]
+        L.mzd_host_alloc.restype = C.c_void_p
+        L.mzd_host_alloc.argtypes = [C.c_size_t]
+        L.mzd_host_free.restype = None
+        L.mzd_host_free.argtypes = [C.c_void_p]
         L.mzd_debug_last_block.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_size_t)]
         L.mzd_last_kernel_ms.argtypes = [C.c_int, C.POINTER(C.c_float)]
@@ -238,6 +245,45 @@ def load_dict(data):
     if rc != OK:
         raise MzdError(rc, "mzd_load_dict")
     return did.value
+
+
+def unload_dict(dict_id):
+    rc = lib().mzd_unload_dict(dict_id)
+    if rc != OK:
+        raise MzdError(rc, "mzd_unload_dict")
+
+
+def set_driver(driver):
+    """Diagnostics: 0 automatic, 1 / 2 that general driver only (no small-file kernel)."""
+    rc = lib().mzd_debug_set_driver(int(driver))
+    if rc != OK:
+        raise MzdError(rc, "mzd_debug_set_driver")
+
+
+def debug_counters(device=0):
+    out = (C.c_uint32 * 8)()
+    rc = lib().mzd_debug_counters(device, out)
+    if rc != OK:
+        raise MzdError(rc, "mzd_debug_counters")
+    return list(out)
+
+
+class HostBuffer:
+    """Pinned host memory from mzd_host_alloc, viewed as a numpy uint8 array (`.a`)."""
+
+    def __init__(self, n):
+        import numpy as np
+        self.n = int(n)
+        self.ptr = lib().mzd_host_alloc(max(self.n, 1))
+        if not self.ptr:
+            raise MzdError(E_DEVICE, "mzd_host_alloc")
+        self.a = np.ctypeslib.as_array((C.c_uint8 * max(self.n, 1)).from_address(self.ptr))[:self.n]
+
+    def free(self):
+        if self.ptr:
+            self.a = None
+            lib().mzd_host_free(self.ptr)
+            self.ptr = None
 
 
 def last_kernel_ms(device=0):

@@ -92,7 +92,9 @@ struct ContRecord { // one pushed task: where it starts and the frame it belongs
 };
 static_assert(sizeof(ContRecord) == 64, "ContRecord layout");
 
-// counter words (uint32): 0 ticket, 1 slot that ran the last task of job 0, 2 pushes, 3 files finished
+// counter words (uint32): 0 ticket, 1 slot that ran the last task of job 0, 2 pushes, 3 files finished,
+// 4 jobs the small-file kernel handed on (appended to job_list behind its fixed part), 5 the small-file kernel's group ticket
+constexpr uint32_t kCounterWords = 8;
 struct KernelArgs {
     DevJob* jobs;
     uint32_t njobs;
@@ -110,7 +112,33 @@ struct KernelArgs {
     uint32_t ring_cap;    // >= njobs + 1 (at most one unread continuation per file)
     uint32_t epoch;       // distinguishes this launch's ring records from stale ones
     uint32_t use_tasks;   // 1: driver 2 (block tasks), 0: driver 1 (a workgroup per file)
+    // Launches behind the small-file kernel decode a LIST of jobs: job_list[0 .. nlist_fixed) chosen by the host (files that
+    // are not small) followed by counter[4] entries appended on the device (small files that were not plain).  null: all jobs.
+    const uint32_t* job_list;
+    uint32_t nlist_fixed;
+    uint32_t wg0;         // first workgroup slot of this launch in the scratch arrays (several launches may be in flight)
 };
+
+// ---- the small-file kernel (mzd_small.hip): one lane per file, a group of G files per wavefront ------------------------
+constexpr uint32_t kSmallCap = 8192;                   // eligible: dst_cap <= kSmallCap ...
+constexpr uint32_t kSmallSrcMax = kSmallCap + 1024;    // ... and src_len <= kSmallSrcMax
+constexpr uint32_t kSmallGroupMax = 64;
+struct SmallArgs {
+    DevJob* jobs;
+    const uint32_t* small_list; // job indices, sorted by dictionary
+    uint32_t nsmall;
+    uint32_t* counter;          // the launch's counter block (words 4 and 5)
+    uint32_t* redo_list;        // = job_list + nlist_fixed
+    uint8_t* lit_scratch;       // gridDim.x * G * lit_stride bytes
+    uint32_t lit_stride;        // bytes per file: >= the largest capacity of the launch + 64
+    const DevDict* dicts;
+    uint32_t ndicts;
+    uint32_t with_dict;         // some job names a dictionary: LDS holds one dictionary's tables
+};
+
+void launch_small(const SmallArgs& a, uint32_t grid, int g, void* stream);
+uint32_t small_lds_bytes(int g, int with_dict);
+
 
 void launch_decode(const KernelArgs& a, uint32_t grid, void* stream);
 int kernel_lds_bytes();

@@ -1,17 +1,20 @@
-// mzd_host.cpp -- host runtime behind include/mzd.h: device/scratch management, job tables,
-// PCIe staging for the host-pointer entry points, round-robin sharding of files over GPUs,
-// and the C++ mirror of the reference's file-handle table (reference src/file.rs:10-135) with
-// open/read/release (reference src/main.rs:451-513, 595-599).
+// mzd_host.cpp -- host runtime behind include/mzd.h: device/scratch management, job tables, kernel dispatch
+// (small-file kernel, then the general drivers), the chunked PCIe pipeline of the host-pointer entry points,
+// round-robin sharding of files over GPUs, and the C++ mirror of the reference's file-handle table (reference
+// src/file.rs:10-135) with open/read/release (reference src/main.rs:451-513, 595-599).
 //
-// All decoding happens in mzd_kernels.hip; nothing here decodes (there is no CPU fallback:
+// All decoding happens in mzd_kernels.hip / mzd_small.hip; nothing here decodes (there is no CPU fallback:
 // without a usable GPU every decode entry point returns MZD_E_DEVICE).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -37,277 +40,585 @@ thread_local hipError_t last_hip_error = hipSuccess;
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+constexpr int kSlots = 4;                       // launches of the host path that may be in flight on one device
+constexpr size_t kSmallLitBytes = 256u << 20;   // literal scratch of the small-file kernel (shared by the slots)
+constexpr uint32_t kMaxDicts = 64;
+constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
+
+std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic
+
+// What one launch runs on: a stream, a counter block, a range of workgroup slots of the scratch arrays, a share of the
+// small-file kernel's literal scratch, the per-launch state of the block-task driver.  The host path keeps up to kSlots of
+// them in flight; the device-pointer entry points use all of the device at once (`whole`).
+struct Lane {
+    hipStream_t stream = nullptr;
+    uint32_t* counter = nullptr;  // kCounterWords
+    uint32_t wg0 = 0, nwg = 0;
+    uint8_t* small_lit = nullptr;
+    size_t small_lit_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    FileState* fstate = nullptr;   // per file of a launch: what a block task hands to its successor
+    TableArea* tables = nullptr;
+    ContRecord* ring = nullptr;
+    size_t task_cap = 0;
+    uint32_t epoch = 0;
+};
+
+struct Staging { // device (and pinned host) buffers of one host-path call
+    uint8_t *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+    size_t d_in_cap = 0, d_out_cap = 0, h_in_cap = 0, h_out_cap = 0;
+    DevJob* d_jobs = nullptr; DevJob* h_jobs = nullptr; // h_jobs pinned
+    uint32_t* d_lists = nullptr; uint32_t* h_lists = nullptr; // 2 entries per job: small list | job list
+    size_t jobs_cap = 0;
+    bool busy = false;
+};
+
 struct Device {
     int hip_id = 0;
-    hipStream_t stream = nullptr;
-    uint32_t max_wg = 0;
+    int index = 0;
+    uint32_t max_wg = 0, cus = 0;
     uint8_t* lit_scratch = nullptr;
     uint4* seq_scratch = nullptr;
     uint4* walk_scratch = nullptr;
+    uint8_t* small_lit = nullptr;
     DebugSlot* debug = nullptr;
-    uint32_t* counter = nullptr; // [0] tickets, [1] task << 12 | slot of the last compressed block of job 0, [2] pushes, [3] files finished
-    FileState* fstate = nullptr;  // per file of a launch: what a block task hands to its successor
-    TableArea* tables = nullptr;
-    ContRecord* ring = nullptr;   // pushed tasks
-    size_t task_cap = 0;          // files the three arrays above are sized for
-    uint32_t epoch = 0;
-    DevJob* d_jobs = nullptr;
-    size_t d_jobs_cap = 0;
-    DevJob* h_jobs = nullptr; // pinned
-    uint8_t *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
-    size_t in_cap = 0, out_cap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float last_ms = 0.f;
+    uint32_t* counters = nullptr; // (kSlots + 1) blocks of kCounterWords
+    Lane lane[kSlots];
+    Lane whole;                   // the whole device: stream = the library's own stream
+    Staging staging[2];
     DevDict* d_dicts = nullptr;
-    uint32_t ndicts = 0;
-    std::vector<void*> dict_bufs;
+    uint32_t ndicts = 0;          // highest handle in use
+    bool dict_used[kMaxDicts] = {};
+    void* dict_bufs[kMaxDicts] = {};
+    float last_ms = 0.f;
+    uint32_t* job0_counter = nullptr;      // counter block of the launch that decoded job 0 of the most recent call (mzd_debug_last_block)
+    std::atomic<bool> whole_used{false};   // a whole-device launch may still be running on a caller's stream: lanes wait for its end event
+    // resources: lanes and stagings are handed out under `mu`
     std::mutex mu;
+    std::condition_variable cv;
+    bool lane_busy[kSlots] = {};
+    bool whole_busy = false;
+    int whole_waiting = 0;
+    std::mutex dict_mu;
 };
 
-constexpr uint32_t kMaxDicts = 64;
 std::mutex g_mu;
-std::vector<std::unique_ptr<Device>> g_dev;
+std::vector<std::shared_ptr<Device>> g_dev;
+
+void free_lane(Lane& l, bool own_stream) {
+    hipFree(l.fstate); hipFree(l.tables); hipFree(l.ring);
+    if (l.ev0) hipEventDestroy(l.ev0);
+    if (l.ev1) hipEventDestroy(l.ev1);
+    if (own_stream && l.stream) hipStreamDestroy(l.stream);
+}
 
 void free_device(Device& d) {
     hipSetDevice(d.hip_id);
-    if (d.stream) hipStreamSynchronize(d.stream);
-    hipFree(d.lit_scratch); hipFree(d.seq_scratch); hipFree(d.walk_scratch); hipFree(d.debug); hipFree(d.counter); hipFree(d.d_jobs); hipFree(d.fstate); hipFree(d.tables); hipFree(d.ring);
-    hipFree(d.d_in); hipFree(d.d_out); hipFree(d.d_dicts);
+    hipDeviceSynchronize();
+    hipFree(d.lit_scratch); hipFree(d.seq_scratch); hipFree(d.walk_scratch); hipFree(d.small_lit); hipFree(d.debug); hipFree(d.counters); hipFree(d.d_dicts);
     for (void* p : d.dict_bufs) hipFree(p);
-    if (d.h_jobs) hipHostFree(d.h_jobs);
-    if (d.h_in) hipHostFree(d.h_in);
-    if (d.h_out) hipHostFree(d.h_out);
-    if (d.ev0) hipEventDestroy(d.ev0);
-    if (d.ev1) hipEventDestroy(d.ev1);
-    if (d.stream) hipStreamDestroy(d.stream);
+    for (auto& s : d.staging) {
+        hipFree(s.d_in); hipFree(s.d_out); hipFree(s.d_jobs); hipFree(s.d_lists);
+        if (s.h_in) hipHostFree(s.h_in);
+        if (s.h_out) hipHostFree(s.h_out);
+        if (s.h_jobs) hipHostFree(s.h_jobs);
+        if (s.h_lists) hipHostFree(s.h_lists);
+    }
+    for (auto& l : d.lane) free_lane(l, true);
+    free_lane(d.whole, true);
 }
 
-int init_device(Device& d, int hip_id) {
-    d.hip_id = hip_id;
+int init_device(Device& d, int hip_id, int index) {
+    d.hip_id = hip_id; d.index = index;
     HIPCHK(hipSetDevice(hip_id));
-    HIPCHK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
-    int cus = 0, per_cu = 0;
+    int cus = 0, per_cu = 0, per_cu2 = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_id));
-    int per_cu2 = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_kernel_ptr(0), kWG, 0));
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, (const void*)decode_kernel_ptr(1), kWG, 0));
     per_cu = std::min(per_cu, per_cu2); // the block-task driver needs its whole grid resident
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
+    d.cus = (uint32_t)cus;
     d.max_wg = (uint32_t)(cus * per_cu);
     HIPCHK(hipMalloc(&d.lit_scratch, (size_t)d.max_wg * kLitStride));
     HIPCHK(hipMalloc(&d.seq_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
     HIPCHK(hipMalloc(&d.walk_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
+    HIPCHK(hipMalloc(&d.small_lit, kSmallLitBytes));
     HIPCHK(hipMalloc(&d.debug, (size_t)d.max_wg * sizeof(DebugSlot)));
     HIPCHK(hipMemset(d.debug, 0, (size_t)d.max_wg * sizeof(DebugSlot)));
-    HIPCHK(hipMalloc(&d.counter, 64));
-    HIPCHK(hipMemset(d.counter, 0, 64));
+    HIPCHK(hipMalloc(&d.counters, (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
+    HIPCHK(hipMemset(d.counters, 0, (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&d.d_dicts, sizeof(DevDict) * kMaxDicts));
-    HIPCHK(hipEventCreate(&d.ev0));
-    HIPCHK(hipEventCreate(&d.ev1));
-    return MZD_OK;
-}
-
-int ensure_jobs(Device& d, size_t n) {
-    if (n <= d.d_jobs_cap) return MZD_OK;
-    size_t cap = std::max<size_t>(n, 1024);
-    hipFree(d.d_jobs);
-    if (d.h_jobs) hipHostFree(d.h_jobs);
-    d.d_jobs = nullptr; d.h_jobs = nullptr; d.d_jobs_cap = 0;
-    HIPCHK(hipMalloc(&d.d_jobs, cap * sizeof(DevJob)));
-    HIPCHK(hipHostMalloc(&d.h_jobs, cap * sizeof(DevJob), hipHostMallocDefault));
-    d.d_jobs_cap = cap;
-    return MZD_OK;
-}
-
-// per-file task state for launches of up to n files (grow-only)
-int ensure_task_state(Device& d, size_t n) {
-    if (n <= d.task_cap) return MZD_OK;
-    size_t cap = std::max<size_t>(n + n / 4, 1024);
-    hipFree(d.fstate); hipFree(d.tables); hipFree(d.ring);
-    d.fstate = nullptr; d.tables = nullptr; d.ring = nullptr; d.task_cap = 0;
-    HIPCHK(hipMalloc(&d.fstate, cap * sizeof(FileState)));
-    HIPCHK(hipMalloc(&d.tables, cap * sizeof(TableArea)));
-    HIPCHK(hipMalloc(&d.ring, (cap + 1) * sizeof(ContRecord)));
-    HIPCHK(hipMemset(d.ring, 0, (cap + 1) * sizeof(ContRecord)));
-    d.task_cap = cap;
-    return MZD_OK;
-}
-
-KernelArgs make_args(Device& d, DevJob* jobs, uint32_t njobs) {
-    KernelArgs a;
-    a.jobs = jobs; a.njobs = njobs; a.counter = d.counter;
-    a.lit_scratch = d.lit_scratch; a.seq_scratch = d.seq_scratch; a.walk_scratch = d.walk_scratch;
-    a.dicts = d.d_dicts; a.ndicts = d.ndicts; a.debug = d.debug; a.job_slot0 = d.counter + 1;
-    a.fstate = d.fstate; a.tables = d.tables; a.ring = d.ring; a.ring_cap = (uint32_t)d.task_cap + 1; a.epoch = d.epoch;
-    return a;
-}
-
-// enqueue: reset queue head, time the kernel with events on the launch stream
-// Workgroups worth launching: one per file, plus the block tasks big files will fork (a compressed 128 KiB block is
-// rarely below 2 KiB), capped by what is resident at once.  Idle workgroups leave as soon as every file is finished.
-// Returns 0 when no file of the launch can have more than one block (every capacity <= 128 KiB): then driver 1 runs,
-// one workgroup per file.
-uint32_t grid_for(const Device& d, const DevJob* h_jobs, size_t njobs) {
-    bool multi = false;
-    for (size_t i = 0; i < njobs && !multi; i++) multi = h_jobs[i].dst_cap > kBlockMax;
-    if (!multi) return 0;
-    uint64_t tasks = 0;
-    for (size_t i = 0; i < njobs && tasks < d.max_wg; i++) tasks += 1 + h_jobs[i].src_len / 2048;
-    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tasks, 1), d.max_wg);
-}
-
-int enqueue(Device& d, DevJob* d_jobs, uint32_t njobs, uint32_t grid, hipStream_t s) {
-    bool use_tasks = grid != 0;
-    if (const char* e = getenv("MZD_DRIVER")) use_tasks = atoi(e) == 2; // diagnostics: force driver 1 / 2
-    if (use_tasks) {
-        int trc = ensure_task_state(d, njobs);
-        if (trc) return trc;
-        d.epoch++; // ring records of earlier launches never match
-        grid = std::max<uint32_t>(grid, std::min<uint32_t>(njobs, d.max_wg));
-        HIPCHK(hipMemsetAsync(d.counter, 0, 16, s));
-        HIPCHK(hipMemsetAsync(d.fstate, 0, (size_t)njobs * sizeof(FileState), s));
-    } else {
-        grid = std::min<uint32_t>(njobs, d.max_wg);
-        HIPCHK(hipMemsetAsync(d.counter, 0, 16, s));
+    HIPCHK(hipMemset(d.d_dicts, 0, sizeof(DevDict) * kMaxDicts));
+    const uint32_t share = d.max_wg / kSlots;
+    for (int k = 0; k < kSlots; k++) {
+        Lane& l = d.lane[k];
+        HIPCHK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        l.counter = d.counters + (size_t)k * kCounterWords;
+        l.wg0 = (uint32_t)k * share; l.nwg = share;
+        l.small_lit = d.small_lit + (size_t)k * (kSmallLitBytes / kSlots); l.small_lit_bytes = kSmallLitBytes / kSlots;
+        HIPCHK(hipEventCreate(&l.ev0));
+        HIPCHK(hipEventCreate(&l.ev1));
     }
-    HIPCHK(hipEventRecord(d.ev0, s));
-    KernelArgs ka = make_args(d, d_jobs, njobs);
+    Lane& w = d.whole;
+    HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    w.counter = d.counters + (size_t)kSlots * kCounterWords;
+    w.wg0 = 0; w.nwg = d.max_wg; w.small_lit = d.small_lit; w.small_lit_bytes = kSmallLitBytes;
+    HIPCHK(hipEventCreate(&w.ev0));
+    HIPCHK(hipEventCreate(&w.ev1));
+    return MZD_OK;
+}
+
+// ---- lanes and stagings are handed out under Device::mu ----------------------------------------------------------
+int take_lane(Device& d, bool wait) { // a free lane, or -1 (wait == false: do not block)
+    std::unique_lock<std::mutex> lk(d.mu);
+    for (;;) {
+        if (!d.whole_busy && !d.whole_waiting)
+            for (int k = 0; k < kSlots; k++)
+                if (!d.lane_busy[k]) { d.lane_busy[k] = true; return k; }
+        if (!wait) return -1;
+        d.cv.wait(lk);
+    }
+}
+void give_lane(Device& d, int k) {
+    { std::lock_guard<std::mutex> lk(d.mu); d.lane_busy[k] = false; }
+    d.cv.notify_all();
+}
+void take_whole(Device& d) {
+    std::unique_lock<std::mutex> lk(d.mu);
+    d.whole_waiting++;
+    d.cv.wait(lk, [&] { if (d.whole_busy) return false; for (bool b : d.lane_busy) if (b) return false; return true; });
+    d.whole_waiting--;
+    d.whole_busy = true;
+}
+void give_whole(Device& d) {
+    { std::lock_guard<std::mutex> lk(d.mu); d.whole_busy = false; }
+    d.cv.notify_all();
+}
+struct WholeGuard {
+    Device& d;
+    explicit WholeGuard(Device& dd) : d(dd) { take_whole(d); }
+    ~WholeGuard() { give_whole(d); }
+};
+Staging* take_staging(Device& d) {
+    std::unique_lock<std::mutex> lk(d.mu);
+    for (;;) {
+        for (auto& s : d.staging) if (!s.busy) { s.busy = true; return &s; }
+        d.cv.wait(lk);
+    }
+}
+void give_staging(Device& d, Staging* s) {
+    { std::lock_guard<std::mutex> lk(d.mu); s->busy = false; }
+    d.cv.notify_all();
+}
+
+// per-file task state of a lane for launches of up to n files (grow-only)
+int ensure_task_state(Lane& l, size_t n) {
+    if (n <= l.task_cap) return MZD_OK;
+    size_t cap = std::max<size_t>(n + n / 4, 1024);
+    hipFree(l.fstate); hipFree(l.tables); hipFree(l.ring);
+    l.fstate = nullptr; l.tables = nullptr; l.ring = nullptr; l.task_cap = 0;
+    HIPCHK(hipMalloc(&l.fstate, cap * sizeof(FileState)));
+    HIPCHK(hipMalloc(&l.tables, cap * sizeof(TableArea)));
+    HIPCHK(hipMalloc(&l.ring, (cap + 1) * sizeof(ContRecord)));
+    HIPCHK(hipMemset(l.ring, 0, (cap + 1) * sizeof(ContRecord)));
+    l.task_cap = cap;
+    return MZD_OK;
+}
+
+// ---- what a launch decodes with which kernel --------------------------------------------------------------------
+// Small files (one frame of one block in the plain case; capacity <= kSmallCap) go to the small-file kernel, one lane per
+// file; the others -- and whatever that kernel hands on -- to a general driver: block tasks when some file can have more
+// than one block, else a workgroup per file.
+struct Plan {
+    uint32_t njobs = 0, nsmall = 0, nbig = 0;
+    int small_g = 16;
+    bool with_dict = false, multi = false;
+    uint32_t lit_stride = 0;   // literal scratch per small file: largest capacity + 64
+    uint32_t big_tasks = 0;    // workgroups worth launching for the files that are not small
+};
+// lists: [0, njobs) small list (job indices sorted by dictionary), [njobs, 2 njobs) job list of the general driver
+Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_wg) {
+    Plan p;
+    p.njobs = (uint32_t)njobs;
+    const int force = g_force_driver.load(std::memory_order_relaxed);
+    uint32_t* small = lists;
+    uint32_t* big = lists + njobs;
+    bool all_dict = true;
+    uint64_t tasks = 0;
+    size_t maxcap = 0;
+    for (size_t i = 0; i < njobs; i++) {
+        const DevJob& j = jobs[i];
+        const bool is_small = (force == 0 || force == 3) && j.dst_cap <= kSmallCap && j.src_len <= kSmallSrcMax;
+        if (is_small) {
+            small[p.nsmall++] = (uint32_t)i;
+            if (j.dict) p.with_dict = true; else all_dict = false;
+            maxcap = std::max<size_t>(maxcap, j.dst_cap);
+        } else {
+            big[p.nbig++] = (uint32_t)i;
+            if (j.dst_cap > kBlockMax) p.multi = true;
+            if (tasks < max_wg) tasks += 1 + j.src_len / 2048;
+        }
+    }
+    if (p.nsmall) {
+        p.small_g = (p.with_dict && all_dict) ? 64 : 16;
+        p.lit_stride = (uint32_t)align_up(maxcap + 64, 64);
+        if (p.with_dict) // groups share one dictionary's tables: sort by dictionary (stable)
+            std::stable_sort(small, small + p.nsmall, [&](uint32_t x, uint32_t y) { return jobs[x].dict < jobs[y].dict; });
+    }
+    if (force == 1) p.multi = false;
+    if (force == 2) p.multi = true;
+    p.big_tasks = (uint32_t)std::min<uint64_t>(tasks, max_wg);
+    return p;
+}
+
+// enqueue one launch on lane `l`: [small-file kernel] + general driver, timed by the lane's events
+int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, const uint32_t* d_lists) {
+    const uint32_t njobs = p.njobs;
+    KernelArgs ka;
+    ka.jobs = d_jobs; ka.njobs = njobs; ka.counter = l.counter;
+    ka.lit_scratch = d.lit_scratch; ka.seq_scratch = d.seq_scratch; ka.walk_scratch = d.walk_scratch;
+    ka.dicts = d.d_dicts; ka.ndicts = d.ndicts; ka.debug = d.debug; ka.job_slot0 = l.counter + 1;
+    ka.job_list = nullptr; ka.nlist_fixed = 0; ka.wg0 = l.wg0;
+    const bool use_tasks = p.multi;
+    if (use_tasks) {
+        int trc = ensure_task_state(l, njobs);
+        if (trc) return trc;
+        l.epoch++; // ring records of earlier launches never match
+        HIPCHK(hipMemsetAsync(l.fstate, 0, (size_t)njobs * sizeof(FileState), s));
+    }
+    ka.fstate = l.fstate; ka.tables = l.tables; ka.ring = l.ring; ka.ring_cap = (uint32_t)l.task_cap + 1; ka.epoch = l.epoch;
     ka.use_tasks = use_tasks ? 1u : 0u;
+    HIPCHK(hipMemsetAsync(l.counter, 0, kCounterWords * sizeof(uint32_t), s));
+    HIPCHK(hipEventRecord(l.ev0, s));
+    uint32_t grid;
+    if (p.nsmall) {
+        SmallArgs sa;
+        sa.jobs = d_jobs; sa.small_list = d_lists; sa.nsmall = p.nsmall; sa.counter = l.counter;
+        sa.redo_list = const_cast<uint32_t*>(d_lists) + njobs + p.nbig;
+        sa.lit_scratch = l.small_lit; sa.lit_stride = p.lit_stride;
+        sa.dicts = d.d_dicts; sa.ndicts = d.ndicts; sa.with_dict = p.with_dict ? 1u : 0u;
+        const uint32_t ngroups = (p.nsmall + (uint32_t)p.small_g - 1) / (uint32_t)p.small_g;
+        const uint32_t lds = small_lds_bytes(p.small_g, p.with_dict);
+        uint32_t resident = d.cus * std::min<uint32_t>(8u, (160u * 1024u) / lds); // one wavefront per workgroup
+        resident = std::max<uint32_t>(1u, resident * l.nwg / d.max_wg);
+        const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / ((size_t)p.small_g * p.lit_stride));
+        launch_small(sa, std::min(ngroups, std::min(resident, by_scratch)), p.small_g, s);
+        HIPCHK(hipGetLastError());
+        ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig;
+        // what is left for the general driver: the files that are not small, and whatever the small-file kernel hands on
+        // (normally nothing; a corpus of malformed small files: all of them)
+        grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
+    } else {
+        grid = use_tasks ? std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(njobs, l.nwg)) : njobs;
+    }
+    grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, l.nwg));
     launch_decode(ka, grid, s);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(d.ev1, s));
+    HIPCHK(hipEventRecord(l.ev1, s));
     return MZD_OK;
 }
 
-// jobs carry DEVICE pointers.  Caller holds d.mu.
+void fill_devjob(DevJob& j, const void* src, size_t src_len, void* dst, size_t cap, uint32_t dict, const Device& d) {
+    j.src = (const uint8_t*)src; j.src_len = src_len; j.dst = (uint8_t*)dst; j.dst_cap = cap;
+    j.out_len = 0; j.status = MZD_E_DEVICE;
+    j.dict = (dict >= 1 && dict <= kMaxDicts && d.dict_used[dict - 1]) ? dict : (dict ? 0xFFFFFFFFu : 0u); // an unloaded handle: MZD_E_DICT
+}
+
+int ensure_staging_jobs(Staging& st, size_t n) {
+    if (n <= st.jobs_cap) return MZD_OK;
+    size_t cap = std::max<size_t>(n + n / 4, 1024);
+    hipFree(st.d_jobs); hipFree(st.d_lists);
+    if (st.h_jobs) hipHostFree(st.h_jobs);
+    if (st.h_lists) hipHostFree(st.h_lists);
+    st.d_jobs = nullptr; st.h_jobs = nullptr; st.d_lists = nullptr; st.h_lists = nullptr; st.jobs_cap = 0;
+    HIPCHK(hipMalloc(&st.d_jobs, cap * sizeof(DevJob)));
+    HIPCHK(hipHostMalloc(&st.h_jobs, cap * sizeof(DevJob), hipHostMallocDefault));
+    HIPCHK(hipMalloc(&st.d_lists, cap * 2 * sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc(&st.h_lists, cap * 2 * sizeof(uint32_t), hipHostMallocDefault));
+    st.jobs_cap = cap;
+    return MZD_OK;
+}
+
+// jobs carry DEVICE pointers; the whole device, one launch
 int run_device_jobs(Device& d, mzd_job* jobs, size_t njobs, hipStream_t s) {
     HIPCHK(hipSetDevice(d.hip_id));
     if (njobs == 0) return MZD_OK;
-    if (njobs > 0xFFFFFFF0u) return MZD_E_PARAM;
-    int rc = ensure_jobs(d, njobs);
+    if (njobs > 0x7FFFFFF0u) return MZD_E_PARAM;
+    Staging* st = take_staging(d); // (same order as the host path: staging first, then execution resources)
+    struct Give { Device& d; Staging* s; ~Give() { give_staging(d, s); } } give{d, st};
+    WholeGuard g(d);
+    int rc = ensure_staging_jobs(*st, njobs);
     if (rc) return rc;
-    for (size_t i = 0; i < njobs; i++) {
-        DevJob& j = d.h_jobs[i];
-        j.src = jobs[i].src; j.src_len = jobs[i].src_len; j.dst = jobs[i].dst; j.dst_cap = jobs[i].dst_cap;
-        j.out_len = 0; j.status = MZD_E_DEVICE; j.dict = jobs[i].dict_id;
-    }
-    HIPCHK(hipMemcpyAsync(d.d_jobs, d.h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice, s));
-    rc = enqueue(d, d.d_jobs, (uint32_t)njobs, grid_for(d, d.h_jobs, njobs), s);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(d.h_jobs, d.d_jobs, njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
+    for (size_t i = 0; i < njobs; i++) fill_devjob(st->h_jobs[i], jobs[i].src, jobs[i].src_len, jobs[i].dst, jobs[i].dst_cap, jobs[i].dict_id, d);
+    const Plan p = make_plan(st->h_jobs, njobs, st->h_lists, d.max_wg);
+    if (!s) s = d.whole.stream;
+    HIPCHK(hipMemcpyAsync(st->d_jobs, st->h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice, s));
+    if (p.nsmall) HIPCHK(hipMemcpyAsync(st->d_lists, st->h_lists, njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    d.job0_counter = d.whole.counter;
+    rc = enqueue(d, d.whole, s, st->d_jobs, p, st->d_lists);
+    if (rc) { hipStreamSynchronize(s); return rc; }
+    HIPCHK(hipMemcpyAsync(st->h_jobs, st->d_jobs, njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipEventElapsedTime(&d.last_ms, d.ev0, d.ev1));
-    for (size_t i = 0; i < njobs; i++) { jobs[i].out_len = (size_t)d.h_jobs[i].out_len; jobs[i].status = d.h_jobs[i].status; }
+    HIPCHK(hipEventElapsedTime(&d.last_ms, d.whole.ev0, d.whole.ev1));
+    for (size_t i = 0; i < njobs; i++) { jobs[i].out_len = (size_t)st->h_jobs[i].out_len; jobs[i].status = st->h_jobs[i].status; jobs[i].device = d.index; }
     return MZD_OK;
 }
 
-int ensure_staging(Device& d, size_t in_bytes, size_t out_bytes) {
-    if (in_bytes > d.in_cap) {
-        size_t cap = align_up(in_bytes + in_bytes / 4, 1 << 20);
-        hipFree(d.d_in); if (d.h_in) hipHostFree(d.h_in);
-        d.d_in = nullptr; d.h_in = nullptr; d.in_cap = 0;
-        HIPCHK(hipMalloc(&d.d_in, cap));
-        HIPCHK(hipHostMalloc(&d.h_in, cap, hipHostMallocDefault));
-        d.in_cap = cap;
-    }
-    if (out_bytes > d.out_cap) {
-        size_t cap = align_up(out_bytes + out_bytes / 4, 1 << 20);
-        hipFree(d.d_out); if (d.h_out) hipHostFree(d.h_out);
-        d.d_out = nullptr; d.h_out = nullptr; d.out_cap = 0;
-        HIPCHK(hipMalloc(&d.d_out, cap));
-        HIPCHK(hipHostMalloc(&d.h_out, cap, hipHostMallocDefault));
-        d.out_cap = cap;
-    }
-    return MZD_OK;
-}
-
-// The staging copies (user buffers <-> pinned memory) of a big batch are memory-bound host work: split over a few
-// threads (one thread moves ~10 GB/s; the PCIe link ~50).  fn(k) handles job k of [0, n).
+// ---- the host path ------------------------------------------------------------------------------------------------
+// The staging copies (user buffers <-> pinned memory) are memory-bound host work: split over a few threads (one thread
+// moves ~10 GB/s; the PCIe link ~50).  fn(k) handles piece k of [0, n).
 template <class F>
-void parallel_jobs(size_t n, size_t total_bytes, F fn) {
-    unsigned want = total_bytes < (8u << 20) ? 1u : std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+void parallel_for(size_t n, size_t total_bytes, F fn) {
+    unsigned want = total_bytes < (4u << 20) ? 1u : std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
     if (want <= 1 || n < 2 * want) { for (size_t k = 0; k < n; k++) fn(k); return; }
     std::vector<std::thread> th;
     for (unsigned t = 0; t < want; t++)
         th.emplace_back([=]() { for (size_t k = n * t / want; k < n * (t + 1) / want; k++) fn(k); });
     for (auto& x : th) x.join();
 }
-
-// HOST-pointer jobs `idx` on one device: pinned staging -> H2D -> kernel -> D2H -> user buffers.
-int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
-    std::lock_guard<std::mutex> lk(d.mu);
-    HIPCHK(hipSetDevice(d.hip_id));
-    if (idx.empty()) return MZD_OK;
-    size_t in_total = 0, out_total = 0;
-    std::vector<size_t> in_off(idx.size()), out_off(idx.size());
-    for (size_t k = 0; k < idx.size(); k++) {
-        const mzd_job& j = jobs[idx[k]];
-        in_off[k] = in_total; in_total += align_up(j.src_len + MZD_SRC_PADDING, kAlign);
-        out_off[k] = out_total; out_total += align_up(j.dst_cap + 16, kAlign);
-    }
-    int rc = ensure_staging(d, in_total, out_total);
-    if (rc) return rc;
-    rc = ensure_jobs(d, idx.size());
-    if (rc) return rc;
-    parallel_jobs(idx.size(), in_total, [&](size_t k) {
-        const mzd_job& j = jobs[idx[k]];
-        if (j.src_len) memcpy(d.h_in + in_off[k], j.src, j.src_len);
-        memset(d.h_in + in_off[k] + j.src_len, 0, MZD_SRC_PADDING);
-        DevJob& dj = d.h_jobs[k];
-        dj.src = d.d_in + in_off[k]; dj.src_len = j.src_len; dj.dst = d.d_out + out_off[k]; dj.dst_cap = j.dst_cap;
-        dj.out_len = 0; dj.status = MZD_E_DEVICE; dj.dict = j.dict_id;
-    });
-    hipStream_t s = d.stream;
-    HIPCHK(hipMemcpyAsync(d.d_in, d.h_in, in_total, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d.d_jobs, d.h_jobs, idx.size() * sizeof(DevJob), hipMemcpyHostToDevice, s));
-    rc = enqueue(d, d.d_jobs, (uint32_t)idx.size(), grid_for(d, d.h_jobs, idx.size()), s);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(d.h_jobs, d.d_jobs, idx.size() * sizeof(DevJob), hipMemcpyDeviceToHost, s));
-    // The output comes back in slices of jobs; while slice i+1 crosses the link, slice i is copied out to the callers' buffers.
-    const size_t kSlice = 24u << 20;
-    std::vector<size_t> cut{0};
-    for (size_t k = 0, acc = 0; k < idx.size(); k++) {
-        acc += (k + 1 < idx.size() ? out_off[k + 1] : out_total) - out_off[k];
-        if (acc >= kSlice || k + 1 == idx.size()) { cut.push_back(k + 1); acc = 0; }
-    }
-    std::vector<hipEvent_t> evs(cut.size() - 1, nullptr);
-    for (size_t i = 0; i + 1 < cut.size(); i++) {
-        const size_t b0 = out_off[cut[i]], b1 = cut[i + 1] < idx.size() ? out_off[cut[i + 1]] : out_total;
-        hipError_t e = hipMemcpyAsync(d.h_out + b0, d.d_out + b0, b1 - b0, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&evs[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(evs[i], s);
-        if (e != hipSuccess) { hipStreamSynchronize(s); for (auto ev : evs) if (ev) hipEventDestroy(ev); return MZD_E_DEVICE; }
-    }
-    int result = MZD_OK;
-    for (size_t i = 0; i + 1 < cut.size(); i++) {
-        if (hipEventSynchronize(evs[i]) != hipSuccess) result = MZD_E_DEVICE; // the job table was copied before the first slice
-        if (result == MZD_OK)
-            parallel_jobs(cut[i + 1] - cut[i], (cut[i + 1] < idx.size() ? out_off[cut[i + 1]] : out_total) - out_off[cut[i]], [&](size_t r) {
-                const size_t k = cut[i] + r;
-                mzd_job& j = jobs[idx[k]];
-                j.status = d.h_jobs[k].status;
-                j.out_len = (size_t)d.h_jobs[k].out_len;
-                size_t ncopy = std::min<size_t>(j.out_len, j.dst_cap);
-                if (ncopy && j.dst) memcpy(j.dst, d.h_out + out_off[k], ncopy);
-            });
-    }
-    hipStreamSynchronize(s);
-    for (auto ev : evs) if (ev) hipEventDestroy(ev);
-    if (result != MZD_OK) return result;
-    HIPCHK(hipEventElapsedTime(&d.last_ms, d.ev0, d.ev1));
-    return MZD_OK;
+// one big copy, split by bytes
+void parallel_memcpy(uint8_t* d, const uint8_t* s, size_t n) {
+    if (n < (4u << 20)) { memcpy(d, s, n); return; }
+    const size_t piece = 2u << 20, np = (n + piece - 1) / piece;
+    parallel_for(np, n, [=](size_t k) { const size_t o = k * piece; memcpy(d + o, s + o, std::min(piece, n - o)); });
 }
 
-Device* get_device(int i) {
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+// A RUN = consecutive jobs whose buffers lie one behind the other in the caller's memory (inputs: ascending with gaps below
+// a page, so that the bytes between them are readable; outputs: exactly adjacent, so that nothing but output bytes is
+// ever written).  A run is mirrored 1:1 in the device staging buffer and crosses the link as ONE copy -- straight from /
+// into the caller's memory when that is pinned (mzd_host_alloc), else through the pinned staging image.
+struct Layout {
+    std::vector<size_t> off;       // device offset of job k's buffer
+    std::vector<uint32_t> run_of;  // run of job k
+    std::vector<size_t> run_dev, run_len; // device offset and byte length of each run
+    std::vector<const uint8_t*> run_host;
+    size_t total = 0;
+};
+Layout make_layout(const mzd_job* jobs, const std::vector<size_t>& idx, bool input, size_t tail) {
+    Layout L;
+    const size_t n = idx.size();
+    L.off.resize(n); L.run_of.resize(n);
+    const uint8_t* run_host = nullptr; size_t run_dev = 0, run_len = 0;
+    bool open = false;
+    auto close = [&]() {
+        L.run_dev.push_back(run_dev); L.run_len.push_back(run_len); L.run_host.push_back(run_host);
+        L.total = align_up(run_dev + run_len + tail, kAlign);
+    };
+    for (size_t k = 0; k < n; k++) {
+        const mzd_job& j = jobs[idx[k]];
+        const uint8_t* p = input ? j.src : j.dst;
+        const size_t len = input ? j.src_len : j.dst_cap;
+        bool joins = false;
+        if (open && p && run_host && p >= run_host + run_len) {
+            const size_t gap = (size_t)(p - (run_host + run_len));
+            joins = input ? gap < 4096 : gap == 0;
+        }
+        if (!joins) {
+            if (open) close();
+            run_host = p; run_dev = L.total + (p ? ((uintptr_t)p & 15) : 0); run_len = 0; open = true;
+        }
+        const size_t rel = p && run_host ? (size_t)(p - run_host) : 0;
+        L.off[k] = run_dev + rel;
+        L.run_of[k] = (uint32_t)L.run_dev.size();
+        run_len = rel + len;
+    }
+    if (open) close();
+    return L;
+}
+
+// HOST-pointer jobs `idx` on one device, as a pipeline of chunks: while chunk k decodes, chunk k+1 crosses the link one way
+// and chunk k-1 the other (kSlots launches in flight, each on its own stream and its own share of the scratch).
+int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
+    HIPCHK(hipSetDevice(d.hip_id));
+    const size_t n = idx.size();
+    if (n == 0) return MZD_OK;
+    if (n > 0x7FFFFFF0u) return MZD_E_PARAM;
+    Staging* st = take_staging(d);
+    struct Give { Device& d; Staging* s; ~Give() { give_staging(d, s); } } give{d, st};
+    const Layout Lin = make_layout(jobs, idx, true, MZD_SRC_PADDING), Lout = make_layout(jobs, idx, false, 16);
+    // straight from / into the caller's memory?  Only when it is pinned and the runs are few (a copy call costs microseconds)
+    auto direct_ok = [&](const Layout& L) {
+        if (L.run_dev.size() > std::max<size_t>(8, n / 64)) return false;
+        for (size_t r = 0; r < L.run_dev.size(); r++)
+            if (L.run_len[r] && !(L.run_host[r] && is_pinned_host(L.run_host[r]) && is_pinned_host(L.run_host[r] + L.run_len[r] - 1))) return false;
+        return true;
+    };
+    const bool in_direct = direct_ok(Lin), out_direct = direct_ok(Lout);
+    auto grow_dev = [&](uint8_t*& p, size_t& cap, size_t want) -> int {
+        if (want <= cap) return MZD_OK;
+        hipFree(p); p = nullptr; cap = 0;
+        const size_t c = align_up(want + want / 4, 1 << 20);
+        HIPCHK(hipMalloc(&p, c));
+        cap = c;
+        return MZD_OK;
+    };
+    auto grow_host = [&](uint8_t*& p, size_t& cap, size_t want) -> int {
+        if (want <= cap) return MZD_OK;
+        if (p) hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t c = align_up(want + want / 4, 1 << 20);
+        HIPCHK(hipHostMalloc(&p, c, hipHostMallocDefault));
+        cap = c;
+        return MZD_OK;
+    };
+    int rc;
+    if ((rc = grow_dev(st->d_in, st->d_in_cap, Lin.total))) return rc;
+    if ((rc = grow_dev(st->d_out, st->d_out_cap, Lout.total))) return rc;
+    if (!in_direct && (rc = grow_host(st->h_in, st->h_in_cap, Lin.total))) return rc;
+    if (!out_direct && (rc = grow_host(st->h_out, st->h_out_cap, Lout.total))) return rc;
+    if ((rc = ensure_staging_jobs(*st, n))) return rc;
+    for (size_t k = 0; k < n; k++) {
+        const mzd_job& j = jobs[idx[k]];
+        fill_devjob(st->h_jobs[k], st->d_in + Lin.off[k], j.src_len, st->d_out + Lout.off[k], j.dst_cap, j.dict_id, d);
+    }
+    // chunks: at least kSlots when the batch is worth splitting, ~kChunkBytes each, cut at job boundaries
+    size_t bytes_total = 0;
+    for (size_t k = 0; k < n; k++) bytes_total += jobs[idx[k]].src_len + jobs[idx[k]].dst_cap;
+    size_t nchunks = bytes_total < (8u << 20) ? 1 : std::max<size_t>(kSlots, (bytes_total + kChunkBytes - 1) / kChunkBytes);
+    nchunks = std::min(nchunks, n);
+    std::vector<size_t> cut{0};
+    {
+        size_t acc = 0, target = (bytes_total + nchunks - 1) / nchunks;
+        for (size_t k = 0; k < n; k++) {
+            acc += jobs[idx[k]].src_len + jobs[idx[k]].dst_cap;
+            if ((acc >= target && cut.size() < nchunks) || k + 1 == n) { cut.push_back(k + 1); acc = 0; }
+        }
+    }
+    nchunks = cut.size() - 1;
+    struct InFlight { size_t c; int lane; hipEvent_t done; };
+    std::deque<InFlight> fly;
+    int result = MZD_OK;
+    float ms_sum = 0.f;
+    // the copies of a job range: one per run piece
+    auto for_run_pieces = [&](const Layout& L, size_t c0, size_t c1, bool input, const std::function<void(size_t dev_off, const uint8_t* host, size_t len)>& fn) {
+        size_t k = c0;
+        while (k < c1) {
+            const uint32_t r = L.run_of[k];
+            size_t e = k;
+            while (e + 1 < c1 && L.run_of[e + 1] == r) e++;
+            const mzd_job& jl = jobs[idx[e]];
+            const size_t lo = L.off[k], hi = L.off[e] + (input ? jl.src_len : jl.dst_cap);
+            const mzd_job& jf = jobs[idx[k]];
+            fn(lo, input ? jf.src : jf.dst, hi - lo);
+            k = e + 1;
+        }
+    };
+    auto retire = [&](const InFlight& f) { // wait for a chunk, hand its bytes and results to the caller
+        if (hipEventSynchronize(f.done) != hipSuccess) result = MZD_E_DEVICE;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, d.lane[f.lane].ev0, d.lane[f.lane].ev1) == hipSuccess) ms_sum += ms;
+        hipEventDestroy(f.done);
+        give_lane(d, f.lane);
+        const size_t c0 = cut[f.c], c1 = cut[f.c + 1];
+        if (result != MZD_OK) return;
+        size_t bytes = 0;
+        for (size_t k = c0; k < c1; k++) bytes += std::min<size_t>(st->h_jobs[k].out_len, jobs[idx[k]].dst_cap);
+        parallel_for(c1 - c0, out_direct ? 0 : bytes, [&](size_t r) {
+            const size_t k = c0 + r;
+            mzd_job& j = jobs[idx[k]];
+            j.status = st->h_jobs[k].status;
+            j.out_len = (size_t)st->h_jobs[k].out_len;
+            j.device = d.index;
+            const size_t ncopy = std::min<size_t>(j.out_len, j.dst_cap);
+            if (!out_direct && ncopy && j.dst) memcpy(j.dst, st->h_out + Lout.off[k], ncopy);
+        });
+    };
+    for (size_t c = 0; c < nchunks && result == MZD_OK; c++) {
+        const size_t c0 = cut[c], c1 = cut[c + 1];
+        // a lane: a free one, else the oldest chunk of this call is retired first (its lane is ours to reuse)
+        int ln = take_lane(d, fly.empty());
+        while (ln < 0) {
+            retire(fly.front()); fly.pop_front();
+            ln = take_lane(d, fly.empty());
+        }
+        Lane& l = d.lane[ln];
+        hipStream_t s = l.stream;
+        hipError_t e = hipSuccess;
+        if (c == 0) d.job0_counter = l.counter;
+        if (d.whole_used.load(std::memory_order_relaxed)) e = hipStreamWaitEvent(s, d.whole.ev1, 0); // a device-path launch still in flight on a caller's stream
+        // inputs
+        if (!in_direct) {
+            size_t bytes = 0;
+            for (size_t k = c0; k < c1; k++) bytes += jobs[idx[k]].src_len;
+            if (Lin.run_dev.size() <= std::max<size_t>(8, n / 64)) { // few long runs: big copies split by bytes
+                for_run_pieces(Lin, c0, c1, true, [&](size_t dev_off, const uint8_t* host, size_t len) { if (len && host) parallel_memcpy(st->h_in + dev_off, host, len); });
+            } else {
+                parallel_for(c1 - c0, bytes, [&](size_t r) {
+                    const mzd_job& j = jobs[idx[c0 + r]];
+                    if (j.src_len && j.src) memcpy(st->h_in + Lin.off[c0 + r], j.src, j.src_len);
+                });
+            }
+            const size_t lo = Lin.off[c0], hi = Lin.off[c1 - 1] + jobs[idx[c1 - 1]].src_len;
+            if (hi > lo) e = hipMemcpyAsync(st->d_in + lo, st->h_in + lo, hi - lo, hipMemcpyHostToDevice, s);
+        } else {
+            for_run_pieces(Lin, c0, c1, true, [&](size_t dev_off, const uint8_t* host, size_t len) {
+                if (len && e == hipSuccess) e = hipMemcpyAsync(st->d_in + dev_off, host, len, hipMemcpyHostToDevice, s);
+            });
+        }
+        // job table (+ lists) of the chunk, the kernels
+        Plan p;
+        if (e == hipSuccess) {
+            p = make_plan(st->h_jobs + c0, c1 - c0, st->h_lists + 2 * c0, l.nwg);
+            e = hipMemcpyAsync(st->d_jobs + c0, st->h_jobs + c0, (c1 - c0) * sizeof(DevJob), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess && p.nsmall) e = hipMemcpyAsync(st->d_lists + 2 * c0, st->h_lists + 2 * c0, (c1 - c0) * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+        }
+        int erc = MZD_OK;
+        if (e == hipSuccess) erc = enqueue(d, l, s, st->d_jobs + c0, p, st->d_lists + 2 * c0);
+        // results and outputs
+        if (e == hipSuccess && erc == MZD_OK) e = hipMemcpyAsync(st->h_jobs + c0, st->d_jobs + c0, (c1 - c0) * sizeof(DevJob), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && erc == MZD_OK) {
+            if (!out_direct) {
+                const size_t lo = Lout.off[c0], hi = Lout.off[c1 - 1] + jobs[idx[c1 - 1]].dst_cap;
+                if (hi > lo) e = hipMemcpyAsync(st->h_out + lo, st->d_out + lo, hi - lo, hipMemcpyDeviceToHost, s);
+            } else {
+                for_run_pieces(Lout, c0, c1, false, [&](size_t dev_off, const uint8_t* host, size_t len) {
+                    if (len && e == hipSuccess) e = hipMemcpyAsync(const_cast<uint8_t*>(host), st->d_out + dev_off, len, hipMemcpyDeviceToHost, s);
+                });
+            }
+        }
+        hipEvent_t done = nullptr;
+        if (e == hipSuccess && erc == MZD_OK) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (e == hipSuccess && erc == MZD_OK) e = hipEventRecord(done, s);
+        if (e != hipSuccess || erc != MZD_OK) {
+            hipStreamSynchronize(s);
+            if (done) hipEventDestroy(done);
+            give_lane(d, ln);
+            result = erc != MZD_OK ? erc : MZD_E_DEVICE;
+            break;
+        }
+        fly.push_back(InFlight{c, ln, done});
+    }
+    while (!fly.empty()) { retire(fly.front()); fly.pop_front(); }
+    if (result == MZD_OK) d.last_ms = ms_sum;
+    return result;
+}
+
+std::shared_ptr<Device> get_device(int i) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (i < 0 || (size_t)i >= g_dev.size()) return nullptr;
-    return g_dev[(size_t)i].get();
+    return g_dev[(size_t)i];
 }
 
 inline uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 inline uint32_t rd32(const uint8_t* p) { return rd16(p) | (rd16(p + 2) << 16); }
 inline uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
+
+void drop_devices(std::vector<std::shared_ptr<Device>>& devs) { // waits until nobody uses a device, then frees it
+    for (auto& d : devs) {
+        take_whole(*d);
+        { std::unique_lock<std::mutex> lk(d->mu); d->cv.wait(lk, [&] { for (auto& s : d->staging) if (s.busy) return false; return true; }); }
+        free_device(*d);
+    }
+    devs.clear();
+}
 
 } // namespace
 
@@ -315,40 +626,54 @@ struct mzd_batch {
     int device;
     DevJob* d_jobs;
     DevJob* h_jobs;
+    uint32_t* d_lists;
     size_t njobs;
+    Plan plan;
+    std::shared_ptr<Device> dev;
 };
 
 extern "C" {
 
 int mzd_init(const int* device_ids, int n) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& d : g_dev) free_device(*d);
-    g_dev.clear();
+    std::vector<std::shared_ptr<Device>> old;
+    { std::lock_guard<std::mutex> lk(g_mu); old.swap(g_dev); }
+    drop_devices(old); // (calls in flight on the old devices finish first)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MZD_E_DEVICE;
     std::vector<int> ids;
     if (!device_ids || n <= 0) ids.push_back(0);
     else ids.assign(device_ids, device_ids + n);
+    std::vector<std::shared_ptr<Device>> fresh;
     for (int id : ids) {
-        if (id < 0 || id >= count) { for (auto& d : g_dev) free_device(*d); g_dev.clear(); return MZD_E_PARAM; }
-        auto d = std::make_unique<Device>();
-        int rc = init_device(*d, id);
-        if (rc) { free_device(*d); for (auto& e : g_dev) free_device(*e); g_dev.clear(); return rc; }
-        g_dev.push_back(std::move(d));
+        if (id < 0 || id >= count) { for (auto& d : fresh) free_device(*d); return MZD_E_PARAM; }
+        auto d = std::make_shared<Device>();
+        int rc = init_device(*d, id, (int)fresh.size());
+        if (rc) { free_device(*d); for (auto& e : fresh) free_device(*e); return rc; }
+        fresh.push_back(std::move(d));
     }
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_dev = std::move(fresh);
     return MZD_OK;
 }
 
 void mzd_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& d : g_dev) free_device(*d);
-    g_dev.clear();
+    std::vector<std::shared_ptr<Device>> old;
+    { std::lock_guard<std::mutex> lk(g_mu); old.swap(g_dev); }
+    drop_devices(old);
 }
 
 int mzd_device_count(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     return (int)g_dev.size();
 }
+
+// Pinned host memory every initialised device can copy from / into directly (no staging copy on the host path).
+void* mzd_host_alloc(size_t n) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n ? n : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void mzd_host_free(void* p) { if (p) hipHostFree(p); }
 
 // Frame header walk (RFC 8878 3.1.1): no entropy decoding, so it stays on the host.
 uint64_t mzd_content_size(const uint8_t* src, size_t n) {
@@ -395,20 +720,21 @@ uint64_t mzd_content_size(const uint8_t* src, size_t n) {
 }
 
 int mzd_decode_batch(mzd_job* jobs, size_t njobs) {
-    size_t ndev;
-    { std::lock_guard<std::mutex> lk(g_mu); ndev = g_dev.size(); }
+    std::vector<std::shared_ptr<Device>> devs;
+    { std::lock_guard<std::mutex> lk(g_mu); devs = g_dev; }
+    const size_t ndev = devs.size();
     if (ndev == 0) return MZD_E_DEVICE;
     if (!jobs && njobs) return MZD_E_PARAM;
-    for (size_t i = 0; i < njobs; i++) { jobs[i].status = MZD_E_DEVICE; jobs[i].out_len = 0; }
+    for (size_t i = 0; i < njobs; i++) { jobs[i].status = MZD_E_DEVICE; jobs[i].out_len = 0; jobs[i].device = -1; }
     std::vector<std::vector<size_t>> shard(ndev);
     for (size_t i = 0; i < njobs; i++) shard[i % ndev].push_back(i); // file i -> GPU i mod N
     std::vector<int> rcs(ndev, MZD_OK);
     if (ndev == 1) {
-        rcs[0] = run_host_jobs(*get_device(0), jobs, shard[0]);
+        rcs[0] = run_host_jobs(*devs[0], jobs, shard[0]);
     } else {
         std::vector<std::thread> th;
         for (size_t d = 0; d < ndev; d++)
-            th.emplace_back([&, d] { rcs[d] = run_host_jobs(*get_device((int)d), jobs, shard[d]); });
+            th.emplace_back([&, d] { rcs[d] = run_host_jobs(*devs[d], jobs, shard[d]); });
         for (auto& t : th) t.join();
     }
     for (int rc : rcs) if (rc) return rc;
@@ -425,106 +751,154 @@ int mzd_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* o
 }
 
 int mzd_decode_batch_device(int device, mzd_job* jobs, size_t njobs, void* stream) {
-    Device* d = get_device(device);
+    auto d = get_device(device);
     if (!d) return MZD_E_DEVICE;
     if (!jobs && njobs) return MZD_E_PARAM;
-    std::lock_guard<std::mutex> lk(d->mu);
-    return run_device_jobs(*d, jobs, njobs, stream ? (hipStream_t)stream : d->stream);
+    return run_device_jobs(*d, jobs, njobs, (hipStream_t)stream);
 }
 
 int mzd_batch_prepare(int device, const mzd_job* jobs, size_t njobs, mzd_batch** out) {
-    Device* d = get_device(device);
+    auto d = get_device(device);
     if (!d) return MZD_E_DEVICE;
-    if (!jobs || !out || njobs == 0 || njobs > 0xFFFFFFF0u) return MZD_E_PARAM;
-    std::lock_guard<std::mutex> lk(d->mu);
+    if (!jobs || !out || njobs == 0 || njobs > 0x7FFFFFF0u) return MZD_E_PARAM;
     HIPCHK(hipSetDevice(d->hip_id));
-    auto* b = new mzd_batch{device, nullptr, nullptr, njobs};
-    if (hipMalloc(&b->d_jobs, njobs * sizeof(DevJob)) != hipSuccess || hipHostMalloc(&b->h_jobs, njobs * sizeof(DevJob), hipHostMallocDefault) != hipSuccess) {
-        hipFree(b->d_jobs); delete b; return MZD_E_DEVICE;
+    auto* b = new mzd_batch{device, nullptr, nullptr, nullptr, njobs, Plan{}, d};
+    std::vector<uint32_t> lists(njobs * 2);
+    if (hipMalloc(&b->d_jobs, njobs * sizeof(DevJob)) != hipSuccess || hipMalloc(&b->d_lists, njobs * 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc(&b->h_jobs, njobs * sizeof(DevJob), hipHostMallocDefault) != hipSuccess) {
+        hipFree(b->d_jobs); hipFree(b->d_lists); delete b; return MZD_E_DEVICE;
     }
-    for (size_t i = 0; i < njobs; i++) {
-        DevJob& j = b->h_jobs[i];
-        j.src = jobs[i].src; j.src_len = jobs[i].src_len; j.dst = jobs[i].dst; j.dst_cap = jobs[i].dst_cap;
-        j.out_len = 0; j.status = MZD_E_DEVICE; j.dict = jobs[i].dict_id;
+    for (size_t i = 0; i < njobs; i++) fill_devjob(b->h_jobs[i], jobs[i].src, jobs[i].src_len, jobs[i].dst, jobs[i].dst_cap, jobs[i].dict_id, *d);
+    b->plan = make_plan(b->h_jobs, njobs, lists.data(), d->max_wg);
+    if (hipMemcpy(b->d_jobs, b->h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b->d_lists, lists.data(), njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(b->d_jobs); hipFree(b->d_lists); hipHostFree(b->h_jobs); delete b; return MZD_E_DEVICE;
     }
-    if (hipMemcpy(b->d_jobs, b->h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice) != hipSuccess) { hipFree(b->d_jobs); hipHostFree(b->h_jobs); delete b; return MZD_E_DEVICE; }
     *out = b;
     return MZD_OK;
 }
 
 int mzd_batch_launch(mzd_batch* b, void* stream) {
     if (!b) return MZD_E_PARAM;
-    Device* d = get_device(b->device);
-    if (!d) return MZD_E_DEVICE;
-    std::lock_guard<std::mutex> lk(d->mu);
-    HIPCHK(hipSetDevice(d->hip_id));
-    return enqueue(*d, b->d_jobs, (uint32_t)b->njobs, grid_for(*d, b->h_jobs, b->njobs), stream ? (hipStream_t)stream : d->stream);
+    Device& d = *b->dev;
+    HIPCHK(hipSetDevice(d.hip_id));
+    WholeGuard g(d); // (launches of one batch follow each other on `stream`; host-path launches wait for their end event)
+    d.job0_counter = d.whole.counter;
+    d.whole_used.store(true, std::memory_order_relaxed);
+    return enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists);
 }
 
 int mzd_batch_collect(mzd_batch* b, mzd_job* jobs, void* stream) {
     if (!b) return MZD_E_PARAM;
-    Device* d = get_device(b->device);
-    if (!d) return MZD_E_DEVICE;
-    std::lock_guard<std::mutex> lk(d->mu);
-    HIPCHK(hipSetDevice(d->hip_id));
-    hipStream_t s = stream ? (hipStream_t)stream : d->stream;
+    Device& d = *b->dev;
+    HIPCHK(hipSetDevice(d.hip_id));
+    hipStream_t s = stream ? (hipStream_t)stream : d.whole.stream;
     HIPCHK(hipMemcpyAsync(b->h_jobs, b->d_jobs, b->njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipEventElapsedTime(&d->last_ms, d->ev0, d->ev1));
+    HIPCHK(hipEventElapsedTime(&d.last_ms, d.whole.ev0, d.whole.ev1));
     if (jobs)
-        for (size_t i = 0; i < b->njobs; i++) { jobs[i].out_len = (size_t)b->h_jobs[i].out_len; jobs[i].status = b->h_jobs[i].status; }
+        for (size_t i = 0; i < b->njobs; i++) { jobs[i].out_len = (size_t)b->h_jobs[i].out_len; jobs[i].status = b->h_jobs[i].status; jobs[i].device = d.index; }
     return MZD_OK;
 }
 
 void mzd_batch_free(mzd_batch* b) {
     if (!b) return;
-    Device* d = get_device(b->device);
-    if (d) hipSetDevice(d->hip_id);
+    hipSetDevice(b->dev->hip_id);
     hipFree(b->d_jobs);
+    hipFree(b->d_lists);
     hipHostFree(b->h_jobs);
     delete b;
 }
 
 int mzd_load_dict(const uint8_t* dict, size_t n, uint32_t* dict_id) {
-    size_t ndev;
-    { std::lock_guard<std::mutex> lk(g_mu); ndev = g_dev.size(); }
-    if (ndev == 0) return MZD_E_DEVICE;
+    std::vector<std::shared_ptr<Device>> devs;
+    { std::lock_guard<std::mutex> lk(g_mu); devs = g_dev; }
+    if (devs.empty()) return MZD_E_DEVICE;
     if (!dict || n == 0 || n > 0x7FFFFFFFu || !dict_id) return MZD_E_PARAM;
-    uint32_t handle = 0;
-    for (size_t k = 0; k < ndev; k++) {
-        Device& d = *get_device((int)k);
-        std::lock_guard<std::mutex> lk(d.mu);
+    // the same handle on every device: the lowest one free everywhere
+    uint32_t slot = kMaxDicts;
+    for (uint32_t k = 0; k < kMaxDicts && slot == kMaxDicts; k++) {
+        bool free_all = true;
+        for (auto& d : devs) { std::lock_guard<std::mutex> lk(d->dict_mu); if (d->dict_used[k]) free_all = false; }
+        if (free_all) slot = k;
+    }
+    if (slot == kMaxDicts) return MZD_E_PARAM;
+    for (auto& dp : devs) {
+        Device& d = *dp;
+        WholeGuard g(d);
+        std::lock_guard<std::mutex> lk(d.dict_mu);
         HIPCHK(hipSetDevice(d.hip_id));
-        if (d.ndicts >= kMaxDicts) return MZD_E_PARAM;
         uint8_t* buf = nullptr;
         int32_t* st = nullptr;
         HIPCHK(hipMalloc(&buf, align_up(n + MZD_SRC_PADDING, kAlign)));
-        d.dict_bufs.push_back(buf);
+        hipFree(d.dict_bufs[slot]);
+        d.dict_bufs[slot] = buf;
         HIPCHK(hipMemset(buf, 0, align_up(n + MZD_SRC_PADDING, kAlign)));
         HIPCHK(hipMemcpy(buf, dict, n, hipMemcpyHostToDevice));
         HIPCHK(hipMalloc(&st, 64));
         HIPCHK(hipMemset(st, 0xFF, 64));
-        launch_dict_kernel(buf, (uint32_t)n, d.d_dicts + d.ndicts, st, d.stream);
+        launch_dict_kernel(buf, (uint32_t)n, d.d_dicts + slot, st, d.whole.stream);
         HIPCHK(hipGetLastError());
         int32_t status = MZD_E_DEVICE;
-        HIPCHK(hipMemcpyAsync(&status, st, 4, hipMemcpyDeviceToHost, d.stream));
-        HIPCHK(hipStreamSynchronize(d.stream));
+        HIPCHK(hipMemcpyAsync(&status, st, 4, hipMemcpyDeviceToHost, d.whole.stream));
+        HIPCHK(hipStreamSynchronize(d.whole.stream));
         hipFree(st);
         if (status != MZD_OK) return status;
-        d.ndicts++;
-        handle = d.ndicts;
+        d.dict_used[slot] = true;
+        d.ndicts = std::max(d.ndicts, slot + 1);
     }
-    *dict_id = handle;
+    *dict_id = slot + 1;
+    return MZD_OK;
+}
+
+int mzd_unload_dict(uint32_t dict_id) {
+    std::vector<std::shared_ptr<Device>> devs;
+    { std::lock_guard<std::mutex> lk(g_mu); devs = g_dev; }
+    if (devs.empty()) return MZD_E_DEVICE;
+    if (dict_id < 1 || dict_id > kMaxDicts) return MZD_E_PARAM;
+    int rc = MZD_E_PARAM;
+    for (auto& dp : devs) {
+        Device& d = *dp;
+        WholeGuard g(d); // no launch in flight reads the dictionary
+        std::lock_guard<std::mutex> lk(d.dict_mu);
+        if (!d.dict_used[dict_id - 1]) continue;
+        hipSetDevice(d.hip_id);
+        d.dict_used[dict_id - 1] = false;
+        hipFree(d.dict_bufs[dict_id - 1]);
+        d.dict_bufs[dict_id - 1] = nullptr;
+        rc = MZD_OK;
+    }
+    return rc;
+}
+
+int mzd_debug_set_driver(int driver) {
+    if (driver < 0 || driver > 3) return MZD_E_PARAM;
+    g_force_driver.store(driver, std::memory_order_relaxed);
+    return MZD_OK;
+}
+
+// Diagnostic: the counter block of the launch that decoded job 0 of the most recent call (mzd_device.h: tickets, pushes,
+// files finished, jobs the small-file kernel handed on, its group tickets).
+int mzd_debug_counters(int device, uint32_t* out8) {
+    auto dp = get_device(device);
+    if (!dp || !out8) return MZD_E_PARAM;
+    Device* d = dp.get();
+    WholeGuard g(*d);
+    HIPCHK(hipSetDevice(d->hip_id));
+    if (!d->job0_counter) return MZD_E_PARAM;
+    HIPCHK(hipMemcpy(out8, d->job0_counter, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return MZD_OK;
 }
 
 int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit, uint32_t* seq4, size_t seq_cap, size_t* n_seq) {
-    Device* d = get_device(device);
-    if (!d) return MZD_E_DEVICE;
-    std::lock_guard<std::mutex> lk(d->mu);
+    auto dp = get_device(device);
+    if (!dp) return MZD_E_DEVICE;
+    Device* d = dp.get();
+    WholeGuard g(*d);
     HIPCHK(hipSetDevice(d->hip_id));
     uint32_t slot = 0;
-    HIPCHK(hipMemcpy(&slot, d->counter + 1, 4, hipMemcpyDeviceToHost));
+    if (!d->job0_counter) return MZD_E_PARAM;
+    HIPCHK(hipMemcpy(&slot, d->job0_counter + 1, 4, hipMemcpyDeviceToHost));
     slot &= 0xFFFu; // task << 12 | slot
     if (slot >= d->max_wg) return MZD_E_PARAM;
     DebugSlot ds;
@@ -542,12 +916,14 @@ int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit
 
 // Diagnostic (libmzd_diag.so, built with -DMZD_STAMPS): per-phase cycle sums of the workgroup that ran job 0.
 int mzd_debug_stamps(int device, uint64_t* out8) {
-    Device* d = get_device(device);
-    if (!d || !out8) return MZD_E_PARAM;
-    std::lock_guard<std::mutex> lk(d->mu);
+    auto dp = get_device(device);
+    if (!dp || !out8) return MZD_E_PARAM;
+    Device* d = dp.get();
+    WholeGuard g(*d);
     HIPCHK(hipSetDevice(d->hip_id));
     uint32_t slot = 0;
-    HIPCHK(hipMemcpy(&slot, d->counter + 1, 4, hipMemcpyDeviceToHost));
+    if (!d->job0_counter) return MZD_E_PARAM;
+    HIPCHK(hipMemcpy(&slot, d->job0_counter + 1, 4, hipMemcpyDeviceToHost));
     slot &= 0xFFFu; // task << 12 | slot
     if (slot >= d->max_wg) return MZD_E_PARAM;
     DebugSlot ds;
@@ -560,9 +936,10 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
 
 // Diagnostic: tfin[12] of every workgroup slot (n_slots * 12 values); returns the slot count.
 int mzd_debug_tfin_all(int device, uint64_t* out, int max_slots) {
-    Device* d = get_device(device);
-    if (!d || !out) return MZD_E_PARAM;
-    std::lock_guard<std::mutex> lk(d->mu);
+    auto dp = get_device(device);
+    if (!dp || !out) return MZD_E_PARAM;
+    Device* d = dp.get();
+    WholeGuard g(*d);
     HIPCHK(hipSetDevice(d->hip_id));
     int n = std::min<int>((int)d->max_wg, max_slots);
     std::vector<DebugSlot> all((size_t)n);
@@ -572,7 +949,7 @@ int mzd_debug_tfin_all(int device, uint64_t* out, int max_slots) {
 }
 
 int mzd_last_kernel_ms(int device, float* ms) {
-    Device* d = get_device(device);
+    auto d = get_device(device);
     if (!d || !ms) return MZD_E_PARAM;
     *ms = d->last_ms;
     return MZD_OK;
@@ -594,7 +971,7 @@ const char* mzd_strerror(int code) {
     }
 }
 
-const char* mzd_version(void) { return "mzd 0.1 (gfx950)"; }
+const char* mzd_version(void) { return "mzd 0.2 (gfx950)"; }
 
 } // extern "C"
 

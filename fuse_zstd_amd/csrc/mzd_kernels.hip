@@ -34,6 +34,7 @@
 
 #include "../../include/mzd.h"
 #include "mzd_device.h"
+#include "mzd_tables.h"
 
 #ifndef MZD_PRIO_WALK
 #define MZD_PRIO_WALK 3
@@ -53,7 +54,7 @@ namespace mzd {
 #define TTASK() do { if (tid == 0) S.ttask = __builtin_readcyclecounter(); } while (0)
 #define TTASK_END() do { if (tid == 0) S.tfin[11] = __builtin_readcyclecounter() - S.ttask; } while (0)
 #define TCOUNT(k, v) do { if (lane == 0) atomicAdd((unsigned long long*)&S.tfin[k], (unsigned long long)(v)); } while (0)
-#define TFIN_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 12; k_++) a.debug[blockIdx.x].tfin[k_] = S.tfin[k_]; } } while (0)
+#define TFIN_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 12; k_++) a.debug[a.wg0 + blockIdx.x].tfin[k_] = S.tfin[k_]; } } while (0)
 #else
 #define TFIN(k)
 #define TCOUNT(k, v)
@@ -67,7 +68,7 @@ namespace mzd {
 #ifdef MZD_STAMPS
 #define STAMP_DECL uint64_t st_prev = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
-#define STAMP_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 8; k_++) { a.debug[blockIdx.x].stamp[k_] = st_acc[k_]; a.debug[blockIdx.x].cstamp[k_] = S.cdiag[k_]; } a.debug[blockIdx.x].stamp[2] = S.c.diag_slow; } } while (0)
+#define STAMP_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 8; k_++) { a.debug[a.wg0 + blockIdx.x].stamp[k_] = st_acc[k_]; a.debug[a.wg0 + blockIdx.x].cstamp[k_] = S.cdiag[k_]; } a.debug[a.wg0 + blockIdx.x].stamp[2] = S.c.diag_slow; } } while (0)
 #define CSTAMP_DECL uint64_t cs_prev = __builtin_readcyclecounter()
 #define CSTAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); if (lane == 0) S.cdiag[k] += t_ - cs_prev; cs_prev = t_; } while (0)
 #if 0
@@ -196,14 +197,6 @@ __device__ __noinline__ uint32_t bits_at(const uint8_t* p, uint32_t nbytes, int3
     return (uint32_t)(v & ((1ull << n) - 1));
 }
 
-__device__ const uint32_t LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
-__device__ const uint8_t LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-__device__ const uint32_t ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
-__device__ const uint8_t ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-__device__ const int16_t LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
-__device__ const int16_t ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
-__device__ const int16_t OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
-
 // Intra-workgroup flags in LDS (the block pipeline): relaxed atomics + workgroup fences.  Every spin
 // also ends when an error is posted, and is bounded.
 __device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
@@ -212,12 +205,15 @@ __device__ __forceinline__ void flag_store(uint32_t* p, uint32_t v) { __atomic_s
 __device__ __forceinline__ void post_err(int32_t* err, int rc) {
     if (rc) { int32_t expected = 0; __atomic_compare_exchange_n(err, &expected, rc, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); }
 }
-__device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want, const int32_t* err) {
+// (a wait that runs out is a failure of the launch -- a co-tenant starved the workgroup, a role died -- not of the input:
+//  it posts MZD_E_DEVICE, and whatever the waiting role reports afterwards loses to it)
+__device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want, int32_t* err) {
     for (uint32_t it = 0; it < (1u << 24); it++) {
         if (flag_load(p) >= want) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
         if (__atomic_load_n(err, __ATOMIC_RELAXED)) return false;
         __builtin_amdgcn_s_sleep(2);
     }
+    post_err(err, MZD_E_DEVICE);
     return false;
 }
 
@@ -891,6 +887,7 @@ __device__ __forceinline__ uint64_t ring_read64(uint32_t e) {
 
 constexpr uint32_t kWalkFin = 0x80000000u;
 constexpr uint32_t kNoJob = 0xFFFFFFFFu;
+constexpr uint32_t kDoneJob = 0xFFFFFFFEu; // the queue is empty
 #ifndef MZD_PRE_PRIO
 #define MZD_PRE_PRIO 2
 #endif
@@ -1252,12 +1249,13 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
     const uint8_t* const gbase = cx.seq_sp - bias;
     auto wait_walker = [&](uint32_t need) -> bool { // true when sequences [0, need) are recorded
         if (need > nseq) need = nseq;
-        uint32_t pg = 0;
-        for (uint32_t it = 0; it < (1u << 24); it++) {
+        uint32_t pg = 0, it = 0;
+        for (; it < (1u << 24); it++) {
             pg = flag_load(cx.prog);
             if ((pg & ~kWalkFin) >= need || (pg & kWalkFin)) break;
             __builtin_amdgcn_s_sleep(4);
         }
+        if (it == (1u << 24)) post_err(&S.c.err, MZD_E_DEVICE); // (a wait that ran out: see spin_ge)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return (pg & ~kWalkFin) >= need;
     };
@@ -1446,12 +1444,14 @@ struct RunInfo { // wave-uniform
 // A verdict of the copying wavefront waits until the walker and the literal decoders have theirs (a corrupt bitstream
 // wins: it is posted first) ...
 __device__ __noinline__ int exec_verdict(int rc, uint32_t nseq, uint32_t lit_streams) {
-    for (uint32_t it = 0; it < (1u << 24); it++) {
+    uint32_t it = 0;
+    for (; it < (1u << 24); it++) {
         const bool walked = !nseq || (flag_load(&S.c.walk_prog) & kWalkFin) != 0;
         const bool lits = !lit_streams || __atomic_load_n(&S.c.streams_done, __ATOMIC_RELAXED) >= lit_streams;
         if ((walked && lits) || __atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) break;
         __builtin_amdgcn_s_sleep(4);
     }
+    if (it == (1u << 24)) post_err(&S.c.err, MZD_E_DEVICE);
     return rc;
 }
 // ... and inside the chunk that cannot be executed (sequences base .. base+63 of the plan, read again here) the earliest
@@ -1495,12 +1495,13 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     uint32_t lpos = 0;
     CSTAMP_DECL;
     auto wait_plan = [&](uint32_t nchunks_needed) -> bool { // true when that many chunks are planned
-        uint32_t pg = 0;
-        for (uint32_t it = 0; it < (1u << 24); it++) {
+        uint32_t pg = 0, it = 0;
+        for (; it < (1u << 24); it++) {
             pg = flag_load(&S.c.plan_prog);
             if ((pg & ~kPlanFin) >= nchunks_needed || (pg & kPlanFin)) break;
             __builtin_amdgcn_s_sleep(4);
         }
+        if (it == (1u << 24)) post_err(&S.c.err, MZD_E_DEVICE);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return (pg & ~kPlanFin) >= nchunks_needed;
     };
@@ -1517,6 +1518,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return false;
             __builtin_amdgcn_s_sleep(4);
         }
+        post_err(&S.c.err, MZD_E_DEVICE);
         return false;
     };
     constexpr uint32_t kBufStride = kStage + 16;
@@ -1743,10 +1745,12 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     if (haveR) { finish_regs(R, RI); finish_rest(R, RI); }
     // the literals after the last sequence: the planner has validated them once it is finished
     if (nseq) {
-        for (uint32_t it = 0; it < (1u << 24); it++) {
+        uint32_t it = 0;
+        for (; it < (1u << 24); it++) {
             if (flag_load(&S.c.plan_prog) & kPlanFin) break;
             __builtin_amdgcn_s_sleep(4);
         }
+        if (it == (1u << 24)) post_err(&S.c.err, MZD_E_DEVICE);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
         if (__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED) == 2) // only the literals after the last sequence pass the block limit: the destination's end comes first
@@ -1768,8 +1772,6 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
 }
 
 // ------------------------------------------------------------------------------------ K7
-constexpr uint64_t XP1 = 0x9E3779B185EBCA87ull, XP2 = 0xC2B2AE3D27D4EB4Full, XP3 = 0x165667B19E3779F9ull,
-                   XP4 = 0x85EBCA77C2B2AE63ull, XP5 = 0x27D4EB2F165667C5ull;
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 __device__ __forceinline__ uint64_t xround(uint64_t acc, uint64_t in) { acc += in * XP2; acc = rotl64(acc, 31); return acc * XP1; }
 __device__ __forceinline__ uint64_t xmerge(uint64_t h, uint64_t v) { v = xround(0, v); h ^= v; return h * XP1 + XP4; }
@@ -2068,6 +2070,15 @@ __device__ __noinline__ void build_tables_wave(int lane) {
 #define WG_SNAPSHOT(...) do { __syncthreads(); __VA_ARGS__; __syncthreads(); } while (0)
 
 
+// The launch's queue: tickets are job indices, or -- behind the small-file kernel -- indices into the launch's job list
+// (the host's part, then what that kernel handed on: KernelArgs::job_list).
+__device__ __forceinline__ uint32_t queue_len(const KernelArgs& a) { return a.job_list ? a.nlist_fixed + __atomic_load_n(&a.counter[4], __ATOMIC_RELAXED) : a.njobs; }
+__device__ __forceinline__ uint32_t queue_job(const KernelArgs& a, uint32_t ticket) { return a.job_list ? a.job_list[ticket] : ticket; }
+__device__ __forceinline__ uint32_t take_job(const KernelArgs& a) { // one lane
+    const uint32_t t = atomicAdd(&a.counter[0], 1u);
+    return t < queue_len(a) ? queue_job(a, t) : kDoneJob;
+}
+
 // Driver 1, by the walking wavefront once its own work on a file's last block is done: take the next file and parse
 // the headers of its first block (frame header, block header, literals header, sequence header with its three
 // normalized-count descriptions: ~60 K cycles of serial parsing) into S.c2, so that the workgroup finds them ready
@@ -2076,7 +2087,7 @@ __device__ __noinline__ void build_tables_wave(int lane) {
 __device__ __noinline__ void pre_parse_next(const KernelArgs& a, int lane) {
     Ctl& c2 = S.c2;
     uint32_t j2 = 0;
-    if (lane == 0) { j2 = atomicAdd(&a.counter[0], 1u); S.pre_job = j2; S.pre_valid = 0; }
+    if (lane == 0) { j2 = take_job(a); S.pre_job = j2; S.pre_valid = 0; }
     j2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j2);
     if (j2 >= a.njobs) return;
     const uint8_t* const src = a.jobs[j2].src;
@@ -2117,9 +2128,10 @@ __device__ __noinline__ void pre_parse_next(const KernelArgs& a, int lane) {
 // stays in registers and LDS.
 __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint8_t* const lit_buf = a.lit_scratch + (size_t)blockIdx.x * kLitStride;
-    uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
-    uint4* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
+    const uint32_t slot = a.wg0 + blockIdx.x; // this workgroup's place in the scratch arrays
+    uint8_t* const lit_buf = a.lit_scratch + (size_t)slot * kLitStride;
+    uint4* const seqs = a.seq_scratch + (size_t)slot * kSeqStride;
+    uint4* const walk = a.walk_scratch + (size_t)slot * kSeqStride;
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
@@ -2129,7 +2141,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
         TTASK();
         if (tid == 0) { // the file the walking wavefront took ahead (pre_parse_next), or the next one of the queue
             if (S.pre_job != kNoJob) { c.job = S.pre_job; c.t_valid = S.pre_valid | 2u; S.pre_job = kNoJob; S.pre_valid = 0; } // (bit 1: S.pj holds the job's table entry)
-            else { c.job = atomicAdd(&a.counter[0], 1u); c.t_valid = 0; }
+            else { c.job = take_job(a); c.t_valid = 0; }
         }
         uint32_t j, tv, lf = 0, lh = 0;
         WG_SNAPSHOT(j = c.job; tv = c.t_valid; lf = c.lds_dict_fse; lh = c.lds_dict_huf);
@@ -2153,7 +2165,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
 #ifdef MZD_STAMPS
             for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = 0;
 #endif
-            if (j == 0) a.counter[1] = blockIdx.x;
+            if (j == 0) a.counter[1] = a.wg0 + blockIdx.x;
             if (job_dict > a.ndicts) c.err = MZD_E_DICT;
         }
         int err = 0;
@@ -2391,7 +2403,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                                 flag_store(&c.exec_done, 1);
                                 c.out = opos; c.pos = pos0 + bsize;
                                 if (a.debug) {
-                                    DebugSlot& ds = a.debug[blockIdx.x];
+                                    DebugSlot& ds = a.debug[a.wg0 + blockIdx.x];
                                     ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0 || lit_in_place(); ds.lit_raw_ptr = (uint64_t)(uintptr_t)(lit_in_place() ? dst + out0 : lit);
                                 }
                             }
@@ -2501,9 +2513,10 @@ __device__ __noinline__ bool load_pred(const FileState* fs, uint32_t t) {
 
 __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint8_t* const lit_buf = a.lit_scratch + (size_t)blockIdx.x * kLitStride;
-    uint4* const seqs = a.seq_scratch + (size_t)blockIdx.x * kSeqStride;
-    uint4* const walk = a.walk_scratch + (size_t)blockIdx.x * kSeqStride;
+    const uint32_t slot = a.wg0 + blockIdx.x; // this workgroup's place in the scratch arrays
+    uint8_t* const lit_buf = a.lit_scratch + (size_t)slot * kLitStride;
+    uint4* const seqs = a.seq_scratch + (size_t)slot * kSeqStride;
+    uint4* const walk = a.walk_scratch + (size_t)slot * kSeqStride;
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
@@ -2514,14 +2527,15 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         if (tid == 0) {
             c.t_valid = 0;
             const uint32_t ticket = atomicAdd(&a.counter[0], 1u);
-            if (ticket < a.njobs) { c.job = ticket; c.task = 0; c.pos = 0; c.in_frame = 0; c.with_dict = 0; c.t_valid = 1; }
+            const uint32_t nq = queue_len(a);
+            if (ticket < nq) { c.job = queue_job(a, ticket); c.task = 0; c.pos = 0; c.in_frame = 0; c.with_dict = 0; c.t_valid = 1; }
             else {
-                const uint32_t m = ticket - a.njobs;
+                const uint32_t m = ticket - nq;
                 const ContRecord* r = &a.ring[m % a.ring_cap];
                 const uint64_t want = ((uint64_t)a.epoch << 32) | (uint64_t)(m + 1);
                 for (uint32_t it = 0; it < (1u << 23); it++) {
                     bool got = __hip_atomic_load(&r->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
-                    if (!got && g_load(&a.counter[3]) >= a.njobs) { // every file is finished: nothing is pushed any more
+                    if (!got && g_load(&a.counter[3]) >= nq) { // every file is finished: nothing is pushed any more
                         got = __hip_atomic_load(&r->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
                         if (!got) break;
                     }
@@ -2876,9 +2890,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                             c.out = opos; c.pos = pos0 + bsize;
                             flag_store(&c.exec_done, 1);
                             if (a.debug) {
-                                DebugSlot& ds = a.debug[blockIdx.x];
+                                DebugSlot& ds = a.debug[a.wg0 + blockIdx.x];
                                 ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0 || lit_in_place(); ds.lit_raw_ptr = (uint64_t)(uintptr_t)(lit_in_place() ? dst : lit);
-                                if (j == 0) atomicMax(&a.counter[1], (t << 12) | blockIdx.x); // the slot that ran the last compressed block of job 0
+                                if (j == 0) atomicMax(&a.counter[1], (t << 12) | (a.wg0 + blockIdx.x)); // the slot that ran the last compressed block of job 0
                             }
                         }
                         STAMP(6);

@@ -60,6 +60,7 @@ typedef struct mzd_job {
     size_t out_len;     /* OUT: decoded length (what open_wrapper stores in user.real_size, :473-482) */
     int32_t status;     /* OUT: MZD_OK or MZD_E_* */
     uint32_t dict_id;   /* 0 = none, else a handle from mzd_load_dict */
+    int32_t device;     /* OUT: index (into mzd_init's list) of the GPU that decoded the job; -1 if none did */
 } mzd_job;
 
 /* Initialise `n` devices (HIP ordinals); ids == NULL / n == 0 -> device 0 only.
@@ -68,6 +69,12 @@ typedef struct mzd_job {
 int mzd_init(const int* device_ids, int n);
 void mzd_shutdown(void);
 int mzd_device_count(void); /* devices initialised by mzd_init (0 before) */
+
+/* Pinned host memory that every initialised GPU copies from / into directly.  Optional: mzd_decode_batch takes any host
+ * pointers; buffers from this allocator skip the staging copy on the host (the caller of reference src/main.rs:463 would
+ * read the .zst into / decode into such buffers instead of a tempfile).  NULL when the allocation fails. */
+void* mzd_host_alloc(size_t n);
+void mzd_host_free(void* p);
 
 /* Sum of Frame_Content_Size over all frames of a file (host-side header walk, no GPU):
  * the analogue of ZSTD_getFrameContentSize the caller uses to size `dst`.
@@ -82,8 +89,10 @@ int mzd_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* o
 
 /* Many files per call, HOST pointers.  Jobs are dealt round-robin over the initialised
  * devices (job i -> device i mod N; no collective: files are independent).  Per-job
- * status/out_len are filled in.  Returns MZD_OK if the batch ran (inspect job status),
- * MZD_E_DEVICE / MZD_E_PARAM otherwise. */
+ * status/out_len/device are filled in.  Returns MZD_OK if the batch ran (inspect job status),
+ * MZD_E_DEVICE / MZD_E_PARAM otherwise.  On each device the batch crosses PCIe as a pipeline of
+ * chunks (copy in | decode | copy out on separate streams); several threads may call at once.
+ * Bytes of dst between out_len and dst_cap are unspecified afterwards (never anything past dst_cap). */
 int mzd_decode_batch(mzd_job* jobs, size_t njobs);
 
 /* Many files per call, DEVICE pointers on `device` (index into mzd_init's list): src/dst
@@ -104,12 +113,27 @@ void mzd_batch_free(mzd_batch* b);
  * content).  Uploaded once to every initialised device.  The reference itself cannot open
  * dictionary frames (copy_decode has none); this serves BASELINE config 5. */
 int mzd_load_dict(const uint8_t* dict, size_t n, uint32_t* dict_id);
+/* Frees a dictionary on every device (a long-lived daemon cycles through more than the 64 that fit at once).  Jobs that
+ * still name the handle fail with MZD_E_DICT.  MZD_E_PARAM for a handle that is not loaded. */
+int mzd_unload_dict(uint32_t dict_id);
 
 /* Test hook: literal buffer and sequence triples {ll, ml, off, 0} (u32 x 4) of the LAST
  * compressed block decoded by the workgroup that ran job 0 of the previous call on
  * `device`, for phase-by-phase comparison with the oracle's trace. */
 int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit,
                          uint32_t* seq4, size_t seq_cap, size_t* n_seq);
+
+/* Diagnostics (tests, tools/): which kernel a launch takes.  0 / 3 automatic (small files: the lane-per-file kernel; then a
+ * workgroup per file, or block tasks when a file can have several blocks), 1 / 2: that general driver only. */
+int mzd_debug_set_driver(int driver);
+/* The 8 counter words of the launch that decoded job 0 of the most recent call: [0] queue tickets, [2] block tasks pushed,
+ * [3] files finished by the block-task driver, [4] small files the lane-per-file kernel handed on to the general driver,
+ * [5] groups it took. */
+int mzd_debug_counters(int device, uint32_t* out8);
+/* Diagnostic builds only (make diag / tfin): per-phase cycle sums of the workgroup that ran job 0; role finish times of
+ * every workgroup slot.  In the product build they return zeros. */
+int mzd_debug_stamps(int device, uint64_t* out22);
+int mzd_debug_tfin_all(int device, uint64_t* out, int max_slots);
 
 /* Milliseconds the decode kernel of the last launch on `device` took (hipEvents on the
  * launch stream).  Valid after the launch has been collected. */

@@ -1,0 +1,242 @@
+"""GPU tests at BASELINE.json's FULL configuration sizes (run with -m gpu on an MI355X), the lane-per-file kernel's
+hand-over to the general drivers, the pipelined host path (pinned / pageable buffers, calls in flight from several
+threads), dictionary unloading, and -- where the box has two GPUs -- the multi-GPU product path.
+
+Every case goes through the C ABI (include/mzd.h); expected bytes come from the seeded generator (what was
+compressed), and a sample of every corpus is decoded by the oracle as well."""
+import threading
+
+import numpy as np
+import pytest
+
+import corpus
+import fuse_zstd_amd as mzd
+import oracle
+from tests import golden_util
+
+pytestmark = pytest.mark.gpu
+VECS = golden_util.load_manifest()
+needs_zstd = pytest.mark.skipif(not corpus.have_zstd(), reason="no libzstd shared object to compress a corpus with")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def gpu():
+    mzd.build()
+    mzd.init()
+    yield
+    mzd.shutdown()
+
+
+def _device_resident(cp, dict_id=0):
+    """Decode a corpus HBM -> HBM (mzd_decode_batch_device); returns (results, output bytes as numpy)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    comp = torch.from_numpy(cp.comp).to(dev)  # (corpus images end with >= 64 zero bytes: MZD_SRC_PADDING)
+    end = int(cp.raw_offs[-1] + cp.raw_sizes[-1])
+    out = torch.zeros(end + 64, dtype=torch.uint8, device=dev)
+    jobs = mzd.api.make_jobs([comp.data_ptr() + int(o) for o in cp.comp_offs], cp.comp_sizes,
+                             [out.data_ptr() + int(o) for o in cp.raw_offs], cp.raw_sizes, [dict_id] * cp.nfiles if dict_id else None)
+    torch.cuda.synchronize()
+    res = mzd.decode_batch_device(0, jobs)
+    return res, out.cpu().numpy(), end
+
+
+def _check_corpus(cp, res, got, end, dictionary=None, sample=100):
+    bad = [(i, st, n) for i, (st, n) in enumerate(res) if st != 0 or n != int(cp.raw_sizes[i])]
+    assert not bad, bad[:5]
+    assert bool((got[:end] == cp.raw[:end]).all())  # (gaps between files are zero on both sides)
+    step = max(1, cp.nfiles // sample)
+    for i in range(0, cp.nfiles, step):  # ~1 % against the oracle
+        rc, ref = oracle.decode(cp.comp_file(i).tobytes(), cap=int(cp.raw_sizes[i]), dictionary=dictionary)
+        assert rc == 0 and ref == cp.raw_file(i).tobytes(), i
+
+
+@needs_zstd
+def test_config2_full_size():
+    """BASELINE configs[1]: 1 000 x 128 KiB single-block JSON frames, one launch (a workgroup per file)."""
+    cp = corpus.build_corpus("json", 2, [131072] * 1000)
+    res, got, end = _device_resident(cp)
+    _check_corpus(cp, res, got, end, sample=10)
+
+
+@needs_zstd
+def test_config3_full_size():
+    """BASELINE configs[2] (Silesia-proxy: 7 data classes, every literal / table mode), 1 000 x 128 KiB frames."""
+    cp = corpus.build_corpus("text", 3, [131072] * 1000, kind_mod=7)
+    res, got, end = _device_resident(cp)
+    _check_corpus(cp, res, got, end, sample=14)
+
+
+@needs_zstd
+def test_config4_full_size_takes_the_small_file_kernel():
+    """BASELINE configs[3] / the north_star's corpus: 10 000 x 4 KiB JSON files (parallel-files.fio shape) in one launch:
+    the lane-per-file kernel decodes all of them (nothing is handed on: counter word 4)."""
+    cp = corpus.build_corpus("json", 4, [4096] * 10000)
+    res, got, end = _device_resident(cp)
+    _check_corpus(cp, res, got, end, sample=100)
+    c = mzd.debug_counters(0)
+    assert c[4] == 0 and c[5] >= (10000 + 15) // 16, c
+
+
+@needs_zstd
+def test_config4_log_uniform_mix_of_small_and_multi_block_files():
+    """The log-uniform variant in small (4 KiB .. 1 MiB, 600 files): small files take the lane-per-file kernel, the others
+    block tasks, in ONE launch behind each other."""
+    rng = np.random.RandomState(1234)
+    sizes = [int(x) for x in np.exp(rng.uniform(np.log(1000), np.log(1 << 20), size=600)).astype(np.int64)]
+    cp = corpus.build_corpus("json", 4, sizes)
+    res, got, end = _device_resident(cp)
+    _check_corpus(cp, res, got, end, sample=60)
+
+
+@needs_zstd
+def test_config5_full_size_shared_dictionary():
+    """BASELINE configs[4]: 50 000 records of 300..3000 B, the 112 640-byte trained dictionary (tables shared in LDS by the
+    64 files of a wavefront; most matches read the dictionary content)."""
+    sizes = [int(x) for x in np.random.RandomState(55).randint(300, 3001, size=50000)]
+    d = corpus.train_dict("json", 5, sizes[:4000], cap=112640)
+    assert len(d) > 100000
+    h = mzd.load_dict(d)
+    cp = corpus.build_corpus("json", 5, sizes, dictionary=d)
+    res, got, end = _device_resident(cp, h)
+    _check_corpus(cp, res, got, end, dictionary=d, sample=200)
+    c = mzd.debug_counters(0)
+    assert c[4] < 500, c  # (a few records carry their own tables: those go to the general driver)
+    mzd.unload_dict(h)
+
+
+@needs_zstd
+@pytest.mark.parametrize("kind", ["json", "text", "markup", "int32", "dna", "xray", "random", "repeats"])
+def test_small_files_of_every_class_and_size(kind):
+    """Files of 0 .. 8 KiB (the lane-per-file kernel's range) and a little beyond, levels 1 / 3 / 19: every literal mode
+    (raw, RLE, Huffman 1 and 4 streams), predefined / RLE / FSE tables, raw and RLE blocks, long overlapping matches."""
+    sizes = [0, 1, 2, 7, 15, 16, 17, 31, 32, 33, 63, 64, 100, 255, 256, 300, 511, 700, 1000, 1023, 1024, 2000, 3000, 4095, 4096, 4097,
+             5000, 6000, 8191, 8192, 8193, 9000, 12000]
+    for level in (1, 3, 19):
+        cp = corpus.build_corpus(kind, 77, sizes * 3, level=level)
+        srcs = [cp.comp_file(i).tobytes() for i in range(cp.nfiles)]
+        res = mzd.decode_batch(srcs, [int(s) for s in cp.raw_sizes])
+        for i, (st, out) in enumerate(res):
+            assert st == 0 and out == cp.raw_file(i).tobytes(), (kind, level, int(cp.raw_sizes[i]), st)
+        rc, ref = oracle.decode(srcs[7], cap=int(cp.raw_sizes[7]))
+        assert rc == 0 and ref == cp.raw_file(7).tobytes()
+
+
+def test_small_kernel_hands_on_what_is_not_plain():
+    """In one launch: the reference's own test payloads (raw-block frames of a few bytes), an empty file, small multi-frame
+    files, skippable frames, truncated and corrupted frames, too-small outputs.  The lane-per-file kernel decodes the plain
+    ones and hands the others to the general driver, whose verdict must be the oracle's."""
+    vs = [v for v in VECS if v.dict is None and len(v.comp) <= 8192 and (not v.ok or v.out_len <= 8192)]
+    assert len(vs) > 40
+    srcs = [v.comp for v in vs] + [b""]
+    caps = [v.out_len if v.ok else 8192 for v in vs] + [16]
+    # the same again into buffers that are too small (and a few bytes too large)
+    srcs += [v.comp for v in vs if v.ok and v.out_len > 2]
+    caps += [v.out_len - 1 for v in vs if v.ok and v.out_len > 2]
+    srcs += [v.comp for v in vs if v.ok]
+    caps += [v.out_len + 5 for v in vs if v.ok]
+    res = mzd.decode_batch(srcs, caps)
+    for i, (st, out) in enumerate(res):
+        rc, want = oracle.decode(srcs[i], cap=caps[i])
+        assert st == rc, (i, st, rc)
+        assert st != 0 or out == want, i
+    c = mzd.debug_counters(0)
+    assert c[4] > 0 and c[5] > 0, c  # both kernels had work
+
+
+@needs_zstd
+def test_host_path_pinned_pageable_and_concurrent_calls():
+    """mzd_decode_batch is a pipeline of chunks per device; buffers from mzd_host_alloc cross the link without a staging copy.
+    Same bytes either way, also with several calls in flight from different threads (each on its own files)."""
+    cp = corpus.build_corpus("json", 2, [131072] * 300)  # ~ 48 MB: several chunks
+    end = int(cp.raw_offs[-1] + cp.raw_sizes[-1])
+    L = mzd.api.lib()
+    pin_in = mzd.HostBuffer(len(cp.comp)); pin_in.a[:] = cp.comp
+    pins = [mzd.HostBuffer(end + 64) for _ in range(3)]
+    try:
+        def run(src_arr, dst_arr):
+            jobs = mzd.api.make_jobs([src_arr.ctypes.data + int(o) for o in cp.comp_offs], cp.comp_sizes,
+                                     [dst_arr.ctypes.data + int(o) for o in cp.raw_offs], cp.raw_sizes)
+            rc = L.mzd_decode_batch(jobs, cp.nfiles)
+            assert rc == 0 and all(j.status == 0 and j.device == 0 for j in jobs)
+            assert bool((dst_arr[:end] == cp.raw[:end]).all())
+        run(pin_in.a, pins[0].a)                                    # pinned -> pinned
+        run(cp.comp, np.zeros(end + 64, dtype=np.uint8))            # pageable -> pageable
+        run(pin_in.a, np.zeros(end + 64, dtype=np.uint8))           # mixed
+        errs = []
+
+        def worker(k):
+            try:
+                for _ in range(3):
+                    pins[k].a[:end] = 0
+                    run(pin_in.a, pins[k].a)
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs[:1]
+    finally:
+        pin_in.free()
+        for p in pins:
+            p.free()
+
+
+@needs_zstd
+def test_unload_dict_frees_the_handle():
+    sizes = [int(x) for x in np.random.RandomState(5).randint(300, 3001, size=300)]
+    d = corpus.train_dict("json", 5, sizes[:200], cap=30000)
+    cp = corpus.build_corpus("json", 5, sizes[:20], dictionary=d)
+    srcs = [cp.comp_file(i).tobytes() for i in range(20)]
+    h = mzd.load_dict(d)
+    assert all(st == 0 for st, _ in mzd.decode_batch(srcs, sizes[:20], [h] * 20))
+    mzd.unload_dict(h)
+    assert all(st == mzd.E_DICT for st, _ in mzd.decode_batch(srcs, sizes[:20], [h] * 20))  # the handle no longer names a dictionary
+    with pytest.raises(mzd.MzdError):
+        mzd.unload_dict(h)
+    h2 = mzd.load_dict(d)  # the slot is reused
+    assert h2 == h
+    assert all(st == 0 and out == cp.raw_file(i).tobytes() for i, (st, out) in enumerate(mzd.decode_batch(srcs, sizes[:20], [h2] * 20)))
+    mzd.unload_dict(h2)
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+@needs_zstd
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs")
+def test_multi_gpu_product_path_round_robin():
+    """mzd_init([0, 1]) -> file i is decoded by device i mod 2 (mzd_job.device), dictionaries are loaded on
+    both devices, every file byte-exact."""
+    mzd.shutdown()
+    mzd.init([0, 1])
+    try:
+        assert mzd.device_count() == 2
+        sizes = [int(x) for x in np.random.RandomState(55).randint(300, 3001, size=2000)]
+        d = corpus.train_dict("json", 5, sizes[:1000], cap=60000)
+        h = mzd.load_dict(d)
+        cp = corpus.build_corpus("json", 5, sizes, dictionary=d)
+        L = mzd.api.lib()
+        out = np.zeros(int(cp.raw_offs[-1] + cp.raw_sizes[-1]) + 64, dtype=np.uint8)
+        jobs = mzd.api.make_jobs([cp.comp.ctypes.data + int(o) for o in cp.comp_offs], cp.comp_sizes,
+                                 [out.ctypes.data + int(o) for o in cp.raw_offs], cp.raw_sizes, [h] * cp.nfiles)
+        assert L.mzd_decode_batch(jobs, cp.nfiles) == 0
+        for i, j in enumerate(jobs):
+            assert j.status == 0 and j.out_len == sizes[i] and j.device == i % 2, (i, j.status, j.device)
+            o = int(cp.raw_offs[i])
+            assert out[o:o + sizes[i]].tobytes() == cp.raw_file(i).tobytes(), i
+        # big files too (block tasks on both devices)
+        cp2 = corpus.build_corpus("json", 7, [300000, 131072, 1 << 20, 4096, 700000, 70000])
+        res = mzd.decode_batch([cp2.comp_file(i).tobytes() for i in range(cp2.nfiles)], [int(s) for s in cp2.raw_sizes])
+        for i, (st, o) in enumerate(res):
+            assert st == 0 and o == cp2.raw_file(i).tobytes(), i
+    finally:
+        mzd.shutdown()
+        mzd.init()

@@ -20,6 +20,18 @@ def gpu():
     mzd.shutdown()
 
 
+DRIVERS = ["auto", "1", "2"]  # auto: small files take the lane-per-file kernel, the rest (and what it hands on) a general driver
+
+
+@pytest.fixture
+def force_driver():
+    """mzd_debug_set_driver for one test: 'auto' or the general driver '1' / '2' alone."""
+    def set_(driver):
+        mzd.set_driver(0 if driver == "auto" else int(driver))
+    yield set_
+    mzd.set_driver(0)
+
+
 def test_golden_positive_batch():
     """Every positive vector without a dictionary, in ONE batch (one workgroup per file)."""
     vs = [v for v in VECS if v.ok and v.dict is None]
@@ -46,10 +58,12 @@ def test_golden_negative(v):
 
 @pytest.mark.parametrize("name", ["json_4k", "json_128k", "proxy_text_128k", "proxy_dna_300k", "hand_rle_lits_rle_tables",
                                   "hand_long_nbseq", "hand_direct_weights_4s", "json_1m"])
-def test_phase_intermediates_match_cpu_twin(name):
-    """Literal buffer (K2) and sequence triples (K4) of the last compressed block, as the GPU
-    left them in its scratch, against the oracle's dump of the same block."""
+def test_phase_intermediates_match_cpu_twin(name, force_driver):
+    """Literal buffer (K2) and sequence triples (K4) of the last compressed block, as the block pipeline
+    left them in its scratch, against the oracle's dump of the same block.  (The lane-per-file kernel keeps no
+    sequence records -- it executes a sequence the moment it is decoded -- so the general drivers are forced.)"""
     v = next(x for x in VECS if x.name == name)
+    force_driver("2" if v.out_len > 131072 else "1")
     rc, out, blocks, dump = oracle.decode(v.comp, cap=v.out_len, want_trace=True, dump=True)
     assert rc == 0
     st, got = mzd.decode(v.comp, v.out_len)
@@ -98,14 +112,14 @@ def test_dictionary_frames():
 needs_zstd = pytest.mark.skipif(not corpus.have_zstd(), reason="no libzstd shared object to compress a corpus with")
 
 
-@pytest.mark.parametrize("driver", ["1", "2"])
-def test_both_drivers_decode_every_vector(driver, monkeypatch):
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_both_drivers_decode_every_vector(driver, force_driver):
     """The library has two kernel drivers: one workgroup per file (launches whose capacities are all <= 128 KiB) and
     block tasks (the blocks of a frame on different workgroups: tables, repeat offsets, output position and checksum
-    state handed from task to task).  Forced through MZD_DRIVER, each must decode every positive vector (single- and
+    state handed from task to task).  Forced through mzd_debug_set_driver (and left to the library: 'auto', where small files take the lane-per-file kernel first), each must decode every positive vector (single- and
     multi-block, multi-frame, skippable, windows > 128 KiB) byte-exactly, in one batch and one by one, and report the
     oracle's error class on every negative vector."""
-    monkeypatch.setenv("MZD_DRIVER", driver)
+    force_driver(driver)
     vs = [v for v in VECS if v.ok and v.dict is None]
     res = mzd.decode_batch([v.comp for v in vs], [v.out_len for v in vs])
     bad = [(v.name, st) for v, (st, out) in zip(vs, res) if st != 0 or out != v.expected()]
@@ -125,13 +139,13 @@ def test_both_drivers_decode_every_vector(driver, monkeypatch):
 
 
 @needs_zstd
-@pytest.mark.parametrize("driver", ["1", "2"])
-def test_every_single_byte_mutation_of_small_frames_matches_oracle(driver, monkeypatch):
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_every_single_byte_mutation_of_small_frames_matches_oracle(driver, force_driver):
     """The fuzz corpus of SURVEY.md row N3 on the device: EVERY byte of several small frames (Huffman + FSE blocks, a
     raw-literal block, an RLE-heavy one, levels 3 and 19) flipped three ways, every truncation, and every output capacity of one frame: ~14 000 cases in one launch.  For each
     mutant the status must be the oracle's and, where both accept, the bytes too -- a mutant must never hang, fault or
     write outside its output buffer (every job gets its own buffer: a stray write shows up as a neighbour's mismatch)."""
-    monkeypatch.setenv("MZD_DRIVER", driver)
+    force_driver(driver)
     Z = oracle.LibZstd
     frames = []
     for kind, seed, size, level in (("json", 12, 700, 3), ("json", 13, 2500, 19), ("text", 14, 2000, 3), ("repeats", 15, 3000, 3),
@@ -160,15 +174,15 @@ def test_every_single_byte_mutation_of_small_frames_matches_oracle(driver, monke
 
 
 @needs_zstd
-@pytest.mark.parametrize("driver", ["1", "2"])
-def test_multi_byte_mutations_match_oracle(driver, monkeypatch):
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_multi_byte_mutations_match_oracle(driver, force_driver):
     """One to three mutated bytes per frame, eight data classes x three levels (tools/fuzz_more.py runs the same generator
     with more cases).  Several things are wrong at once in such frames, so the status depends on WHICH error is found
     first: the oracle decodes a block's sequences and literals before it executes any sequence, then takes the sequences
     in order (destination's end, 128 KiB block limit, offset).  The device pipeline reports in that order too -- e.g. a
     highly repetitive frame ("repeats": 128 KiB from 128 bytes) whose first sequence got a bad offset AND whose output
     would pass the destination is "corrupt", not "destination too small"."""
-    monkeypatch.setenv("MZD_DRIVER", driver)
+    force_driver(driver)
     rng = np.random.RandomState(8)
     cases = []
     for kind, seed, size in (("json", 41, 131072), ("text", 42, 100000), ("markup", 43, 60000), ("xray", 44, 131072), ("json", 45, 20000),
@@ -254,12 +268,12 @@ def test_random_mutations_of_128k_frames_match_oracle():
 
 
 @needs_zstd
-@pytest.mark.parametrize("driver", ["1", "2"])
-def test_corrupted_multi_block_files_report_the_oracles_error(driver, monkeypatch):
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_corrupted_multi_block_files_report_the_oracles_error(driver, force_driver):
     """Single-byte mutations in every block of multi-block frames (and truncations, and too-small outputs): the status
     must be the oracle's class -- with block tasks an error has to travel from the task that finds it to the task that
     closes the file, in stream order -- and a decode that still succeeds must produce the oracle's bytes."""
-    monkeypatch.setenv("MZD_DRIVER", driver)
+    force_driver(driver)
     rng = np.random.RandomState(77)
     cases = []
     for kind, size in (("json", 600000), ("text", 400000), ("xray", 300000), ("repeats", 500000)):
@@ -282,10 +296,10 @@ def test_corrupted_multi_block_files_report_the_oracles_error(driver, monkeypatc
 
 
 @needs_zstd
-@pytest.mark.parametrize("driver", ["1", "2"])
-def test_multi_block_corpus_both_drivers(driver, monkeypatch):
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_multi_block_corpus_both_drivers(driver, force_driver):
     """Seeded files of 4 KiB .. 1 MiB (up to 8 blocks, treeless literals and repeat tables between them) in one batch."""
-    monkeypatch.setenv("MZD_DRIVER", driver)
+    force_driver(driver)
     sizes = [4096, 200000, 1 << 20, 131073, 70000, 1 << 20, 300000, 4096, 655360, 131072, 262144, 99999] * 3
     for kind in ("json", "text", "xray", "repeats"):
         cp = corpus.build_corpus(kind, 7, sizes)
@@ -313,12 +327,12 @@ def test_seeded_corpus_vs_oracle(kind, level):
 
 
 @needs_zstd
-@pytest.mark.parametrize("driver", ["1", "2"])
-def test_multi_block_frames_with_a_dictionary(driver, monkeypatch):
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_multi_block_frames_with_a_dictionary(driver, force_driver):
     """Frames of several blocks compressed WITH a dictionary: the first block starts from the dictionary's tables and
     repeat offsets, later blocks inherit tables from their predecessors (block tasks: through the file's table area)
     and matches may reach through earlier blocks into the dictionary content."""
-    monkeypatch.setenv("MZD_DRIVER", driver)
+    force_driver(driver)
     sizes = [150000, 400000, 131073, 3000, 262144, 700000]
     d = corpus.train_dict("json", 12, [2500] * 2000)
     cp = corpus.build_corpus("json", 12, sizes, dictionary=d, first_index=5000)

@@ -101,3 +101,63 @@ def test_oracle_accept_reject_agrees_with_libzstd_on_mutations():
         assert len(stricter) <= 8, stricter[:10]
     else:
         assert not stricter, stricter[:10]
+
+
+_CHECK_157 = r"""
+import ctypes as C, glob, os, sys, sysconfig
+sys.path.insert(0, os.environ["MZD_ROOT"])
+from tests import golden_util
+L = None
+roots = {sysconfig.get_paths().get("purelib", ""), sysconfig.get_paths().get("platlib", ""), "/usr/local/lib/python3.10/dist-packages"}
+for r in roots:
+    for p in sorted(glob.glob(r + "/pillow.libs/libzstd*.so*")):
+        try:
+            cand = C.CDLL(p)
+            cand.ZSTD_versionString.restype = C.c_char_p
+            if cand.ZSTD_versionString().decode().startswith("1.5."):
+                L = cand
+        except OSError:
+            pass
+if L is None:
+    print("SKIP"); sys.exit(0)
+for f in (L.ZSTD_decompressDCtx, L.ZSTD_decompress_usingDict):
+    f.restype = C.c_size_t
+L.ZSTD_isError.argtypes = [C.c_size_t]
+L.ZSTD_createDCtx.restype = C.c_void_p
+L.ZSTD_decompressDCtx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+L.ZSTD_decompress_usingDict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+L.ZSTD_freeDCtx.argtypes = [C.c_void_p]
+dctx = L.ZSTD_createDCtx()
+n = 0
+for v in golden_util.load_manifest():
+    cap = (v.out_len if v.ok else 1 << 22) + 1
+    buf = C.create_string_buffer(cap)
+    if v.dict is not None:
+        r = L.ZSTD_decompress_usingDict(dctx, buf, cap, v.comp, len(v.comp), v.dict, len(v.dict))
+    else:
+        r = L.ZSTD_decompressDCtx(dctx, buf, cap, v.comp, len(v.comp))  # (all concatenated frames, skippable ones skipped)
+    if v.ok:
+        assert not L.ZSTD_isError(r), v.name
+        assert buf.raw[:r] == v.expected(), v.name
+    elif v.name != "window_too_large":  # (a one-shot decode has no window limit; copy_decode streams)
+        assert L.ZSTD_isError(r), v.name
+    n += 1
+L.ZSTD_freeDCtx(dctx)
+print("OK", n, L.ZSTD_versionString().decode())
+"""
+
+
+def test_golden_accept_reject_against_libzstd_1_5_when_loadable():
+    """Every golden vector through a libzstd of the reference's own minor version (the reference pins 1.5.6: reference
+    Cargo.lock:2371-2396; pillow's wheel ships a 1.5.x): positives decode to the committed bytes, negatives are refused.
+    tests/golden was made with 1.4.8; decode output is format-determined, this pins it.  In a process of its own: two
+    libzstd versions in one address space interpose each other's symbols."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CHECK_157], env=dict(os.environ, MZD_ROOT=root), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    if r.stdout.strip() == "SKIP":
+        pytest.skip("no libzstd 1.5.x on this machine")
+    assert r.stdout.startswith("OK"), r.stdout

@@ -1,5 +1,7 @@
 """CPU suite: the N > 1 path of bench.py -- files dealt round-robin over ranks (file i -> rank i mod N),
-no data-path collective, aggregation with all_reduce/all_gather -- on 2 gloo ranks."""
+no data-path collective, aggregation with all_reduce/all_gather -- on 2 gloo ranks.  Each rank also drives the product
+library on its own shard as far as a machine without a GPU allows: the host-side frame walk (mzd_content_size) sizes every
+output, and the decode entry points refuse loudly (MZD_E_DEVICE) instead of falling back to a CPU decoder."""
 import os
 import subprocess
 import sys
@@ -14,6 +16,8 @@ sys.path.insert(0, os.environ["MZD_ROOT"])
 import numpy as np
 import torch, torch.distributed as dist
 import bench, corpus, oracle
+import fuse_zstd_amd as mzd
+mzd.build()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 nfiles = 6
@@ -27,6 +31,15 @@ for workload in ("cfg2", "cfg4lu"):
         assert cp.raw_file(i).tobytes() == corpus.gen(kind, cfg_id, g, sizes[i]), (workload, rank, i)
         rc, out = oracle.decode(cp.comp_file(i).tobytes(), cap=sizes[i])
         assert rc == 0 and out == cp.raw_file(i).tobytes()
+        assert mzd.content_size(cp.comp_file(i).tobytes()) == sizes[i]   # product: what the caller sizes dst with
+    if torch.cuda.device_count() == 0:                                   # product: no GPU -> every rank's batch is refused, loudly
+        try:
+            mzd.init([0])
+            raise SystemExit("mzd.init succeeded without a GPU")
+        except mzd.MzdError as e:
+            assert e.code == mzd.E_DEVICE
+        jobs = mzd.api.make_jobs([cp.comp.ctypes.data + int(o) for o in cp.comp_offs], cp.comp_sizes, [0] * nfiles, [0] * nfiles)
+        assert mzd.api.lib().mzd_decode_batch(jobs, nfiles) == mzd.E_DEVICE
     mine = torch.tensor([rank + i * world for i in range(nfiles)], dtype=torch.int64)
     allidx = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allidx, mine)

@@ -1,4 +1,4 @@
-"""Diagnostic: kernel time of n files of one size under both drivers (MZD_DRIVER=1: a workgroup per file, 2: block tasks)."""
+"""Diagnostic: kernel time of n files of one size under both drivers (mzd_debug_set_driver 1: a workgroup per file, 2: block tasks)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fuse_zstd_amd as mzd, corpus
@@ -9,7 +9,7 @@ for size, n in ((1 << 20, 1), (1 << 20, 8), (1 << 20, 64), (1 << 18, 64), (1 << 
     srcs = [cp.comp_file(i).tobytes() for i in range(n)]
     line = "%s %4d x %7d B:" % (kind, n, size)
     for drv in ("1", "2"):
-        os.environ["MZD_DRIVER"] = drv
+        mzd.set_driver(int(drv))
         for rep in range(3):
             res = mzd.decode_batch(srcs, [size] * n)
         ok = all(st == 0 and out == cp.raw_file(i).tobytes() for i, (st, out) in enumerate(res))

@@ -3,8 +3,8 @@ Races between tasks (hand-over of tables / repeat offsets / positions / checksum
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fuse_zstd_amd as mzd, corpus
-os.environ.setdefault("MZD_DRIVER", "2")
 mzd.init()
+mzd.set_driver(int(os.environ.get("MZD_DRIVER", "2")))
 rng = random.Random(12345)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 total = 0
