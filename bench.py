@@ -37,6 +37,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP starts: the host path overlaps 4 kernel streams and 2 copy streams (mzd_host.cpp)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

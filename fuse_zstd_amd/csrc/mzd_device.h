@@ -134,9 +134,10 @@ struct SmallArgs {
     const DevDict* dicts;
     uint32_t ndicts;
     uint32_t with_dict;         // some job names a dictionary: LDS holds one dictionary's tables
+    uint64_t* stamps;           // diagnostic build (-DMZD_SMALL_STAMPS): 9 cycle stamps of workgroup 0's first group, else unused
 };
 
-void launch_small(const SmallArgs& a, uint32_t grid, int g, void* stream);
+void launch_small(const SmallArgs& a, uint32_t grid, int g, uint32_t lds_at_least, void* stream);
 uint32_t small_lds_bytes(int g, int with_dict);
 
 

@@ -12,6 +12,7 @@
 #include <cerrno>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -41,7 +42,7 @@ constexpr size_t kAlign = 256;
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr int kSlots = 4;                       // launches of the host path that may be in flight on one device
-constexpr size_t kSmallLitBytes = 256u << 20;   // literal scratch of the small-file kernel (shared by the slots)
+constexpr size_t kSmallLitBytes = 512u << 20;   // literal scratch of the small-file kernel: every resident file's literals (shared by the slots)
 constexpr uint32_t kMaxDicts = 64;
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
@@ -62,6 +63,7 @@ struct Lane {
     ContRecord* ring = nullptr;
     size_t task_cap = 0;
     uint32_t epoch = 0;
+    std::mutex submit_mu;          // a launch is a sequence of stream operations: one thread at a time per lane
 };
 
 struct Staging { // device (and pinned host) buffers of one host-path call
@@ -84,7 +86,8 @@ struct Device {
     DebugSlot* debug = nullptr;
     uint32_t* counters = nullptr; // (kSlots + 1) blocks of kCounterWords
     Lane lane[kSlots];
-    Lane whole;                   // the whole device: stream = the library's own stream
+    Lane whole;                   // the whole device (its stream is lane 0's: a whole-device launch runs when no lane is busy)
+    hipStream_t copy_in = nullptr, copy_out = nullptr; // the host path's transfers: one stream per direction, shared by all calls
     Staging staging[2];
     DevDict* d_dicts = nullptr;
     uint32_t ndicts = 0;          // highest handle in use
@@ -96,7 +99,8 @@ struct Device {
     // resources: lanes and stagings are handed out under `mu`
     std::mutex mu;
     std::condition_variable cv;
-    bool lane_busy[kSlots] = {};
+    int lane_inflight[kSlots] = {}; // chunks submitted and not yet retired, per lane
+    unsigned next_lane = 0;
     bool whole_busy = false;
     int whole_waiting = 0;
     std::mutex dict_mu;
@@ -125,7 +129,9 @@ void free_device(Device& d) {
         if (s.h_lists) hipHostFree(s.h_lists);
     }
     for (auto& l : d.lane) free_lane(l, true);
-    free_lane(d.whole, true);
+    free_lane(d.whole, false);
+    if (d.copy_in) hipStreamDestroy(d.copy_in);
+    if (d.copy_out) hipStreamDestroy(d.copy_out);
 }
 
 int init_device(Device& d, int hip_id, int index) {
@@ -160,8 +166,10 @@ int init_device(Device& d, int hip_id, int index) {
         HIPCHK(hipEventCreate(&l.ev0));
         HIPCHK(hipEventCreate(&l.ev1));
     }
+    HIPCHK(hipStreamCreateWithFlags(&d.copy_in, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&d.copy_out, hipStreamNonBlocking));
     Lane& w = d.whole;
-    HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    w.stream = d.lane[0].stream;
     w.counter = d.counters + (size_t)kSlots * kCounterWords;
     w.wg0 = 0; w.nwg = d.max_wg; w.small_lit = d.small_lit; w.small_lit_bytes = kSmallLitBytes;
     HIPCHK(hipEventCreate(&w.ev0));
@@ -170,24 +178,24 @@ int init_device(Device& d, int hip_id, int index) {
 }
 
 // ---- lanes and stagings are handed out under Device::mu ----------------------------------------------------------
-int take_lane(Device& d, bool wait) { // a free lane, or -1 (wait == false: do not block)
+// A lane is a stream plus its share of the scratch: launches queued on it run one after the other, so any number of chunks --
+// of any number of calls -- may be in flight on it.  What is counted is only whether the device is idle (take_whole).
+// holding: the caller has chunks in flight already; it must not wait behind a whole-device request that waits for them.
+int lane_begin(Device& d, bool holding) {
     std::unique_lock<std::mutex> lk(d.mu);
-    for (;;) {
-        if (!d.whole_busy && !d.whole_waiting)
-            for (int k = 0; k < kSlots; k++)
-                if (!d.lane_busy[k]) { d.lane_busy[k] = true; return k; }
-        if (!wait) return -1;
-        d.cv.wait(lk);
-    }
+    d.cv.wait(lk, [&] { return !d.whole_busy && (holding || !d.whole_waiting); });
+    const int k = (int)(d.next_lane++ % kSlots);
+    d.lane_inflight[k]++;
+    return k;
 }
-void give_lane(Device& d, int k) {
-    { std::lock_guard<std::mutex> lk(d.mu); d.lane_busy[k] = false; }
+void lane_end(Device& d, int k) {
+    { std::lock_guard<std::mutex> lk(d.mu); d.lane_inflight[k]--; }
     d.cv.notify_all();
 }
 void take_whole(Device& d) {
     std::unique_lock<std::mutex> lk(d.mu);
     d.whole_waiting++;
-    d.cv.wait(lk, [&] { if (d.whole_busy) return false; for (bool b : d.lane_busy) if (b) return false; return true; });
+    d.cv.wait(lk, [&] { if (d.whole_busy) return false; for (int c : d.lane_inflight) if (c) return false; return true; });
     d.whole_waiting--;
     d.whole_busy = true;
 }
@@ -273,7 +281,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
 }
 
 // enqueue one launch on lane `l`: [small-file kernel] + general driver, timed by the lane's events
-int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, const uint32_t* d_lists) {
+int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, const uint32_t* d_lists, hipEvent_t ev0, hipEvent_t ev1) {
     const uint32_t njobs = p.njobs;
     KernelArgs ka;
     ka.jobs = d_jobs; ka.njobs = njobs; ka.counter = l.counter;
@@ -290,20 +298,23 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     ka.fstate = l.fstate; ka.tables = l.tables; ka.ring = l.ring; ka.ring_cap = (uint32_t)l.task_cap + 1; ka.epoch = l.epoch;
     ka.use_tasks = use_tasks ? 1u : 0u;
     HIPCHK(hipMemsetAsync(l.counter, 0, kCounterWords * sizeof(uint32_t), s));
-    HIPCHK(hipEventRecord(l.ev0, s));
+    HIPCHK(hipEventRecord(ev0, s));
     uint32_t grid;
     if (p.nsmall) {
         SmallArgs sa;
         sa.jobs = d_jobs; sa.small_list = d_lists; sa.nsmall = p.nsmall; sa.counter = l.counter;
         sa.redo_list = const_cast<uint32_t*>(d_lists) + njobs + p.nbig;
-        sa.lit_scratch = l.small_lit; sa.lit_stride = p.lit_stride;
-        sa.dicts = d.d_dicts; sa.ndicts = d.ndicts; sa.with_dict = p.with_dict ? 1u : 0u;
         const uint32_t ngroups = (p.nsmall + (uint32_t)p.small_g - 1) / (uint32_t)p.small_g;
         const uint32_t lds = small_lds_bytes(p.small_g, p.with_dict);
         uint32_t resident = d.cus * std::min<uint32_t>(8u, (160u * 1024u) / lds); // one wavefront per workgroup
         resident = std::max<uint32_t>(1u, resident * l.nwg / d.max_wg);
-        const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / ((size_t)p.small_g * p.lit_stride));
-        launch_small(sa, std::min(ngroups, std::min(resident, by_scratch)), p.small_g, s);
+        const size_t per_wave = (size_t)p.small_g * p.lit_stride;
+        const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / per_wave);
+        const uint32_t sgrid = std::min(ngroups, std::min(resident, by_scratch));
+        sa.lit_scratch = l.small_lit; sa.lit_stride = p.lit_stride;
+        sa.dicts = d.d_dicts; sa.ndicts = d.ndicts; sa.with_dict = p.with_dict ? 1u : 0u;
+        sa.stamps = reinterpret_cast<uint64_t*>(d.debug); // (diagnostic builds: the first debug slot's first bytes; unused otherwise)
+        launch_small(sa, sgrid, p.small_g, 0, s);
         HIPCHK(hipGetLastError());
         ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig;
         // what is left for the general driver: the files that are not small, and whatever the small-file kernel hands on
@@ -315,7 +326,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, l.nwg));
     launch_decode(ka, grid, s);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(l.ev1, s));
+    HIPCHK(hipEventRecord(ev1, s));
     return MZD_OK;
 }
 
@@ -356,7 +367,7 @@ int run_device_jobs(Device& d, mzd_job* jobs, size_t njobs, hipStream_t s) {
     HIPCHK(hipMemcpyAsync(st->d_jobs, st->h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice, s));
     if (p.nsmall) HIPCHK(hipMemcpyAsync(st->d_lists, st->h_lists, njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     d.job0_counter = d.whole.counter;
-    rc = enqueue(d, d.whole, s, st->d_jobs, p, st->d_lists);
+    rc = enqueue(d, d.whole, s, st->d_jobs, p, st->d_lists, d.whole.ev0, d.whole.ev1);
     if (rc) { hipStreamSynchronize(s); return rc; }
     HIPCHK(hipMemcpyAsync(st->h_jobs, st->d_jobs, njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -493,10 +504,6 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         }
     }
     nchunks = cut.size() - 1;
-    struct InFlight { size_t c; int lane; hipEvent_t done; };
-    std::deque<InFlight> fly;
-    int result = MZD_OK;
-    float ms_sum = 0.f;
     // the copies of a job range: one per run piece
     auto for_run_pieces = [&](const Layout& L, size_t c0, size_t c1, bool input, const std::function<void(size_t dev_off, const uint8_t* host, size_t len)>& fn) {
         size_t k = c0;
@@ -511,43 +518,23 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
             k = e + 1;
         }
     };
-    auto retire = [&](const InFlight& f) { // wait for a chunk, hand its bytes and results to the caller
-        if (hipEventSynchronize(f.done) != hipSuccess) result = MZD_E_DEVICE;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, d.lane[f.lane].ev0, d.lane[f.lane].ev1) == hipSuccess) ms_sum += ms;
-        hipEventDestroy(f.done);
-        give_lane(d, f.lane);
-        const size_t c0 = cut[f.c], c1 = cut[f.c + 1];
-        if (result != MZD_OK) return;
-        size_t bytes = 0;
-        for (size_t k = c0; k < c1; k++) bytes += std::min<size_t>(st->h_jobs[k].out_len, jobs[idx[k]].dst_cap);
-        parallel_for(c1 - c0, out_direct ? 0 : bytes, [&](size_t r) {
-            const size_t k = c0 + r;
-            mzd_job& j = jobs[idx[k]];
-            j.status = st->h_jobs[k].status;
-            j.out_len = (size_t)st->h_jobs[k].out_len;
-            j.device = d.index;
-            const size_t ncopy = std::min<size_t>(j.out_len, j.dst_cap);
-            if (!out_direct && ncopy && j.dst) memcpy(j.dst, st->h_out + Lout.off[k], ncopy);
-        });
-    };
+    // Per chunk: its inputs on the copy-in stream, its kernels on a lane (round-robin), its outputs on the copy-out stream,
+    // tied together by events.  Everything is submitted without waiting; then the chunks are retired in order.
+    struct Chunk { int lane = -1; hipEvent_t in = nullptr, k0 = nullptr, k1 = nullptr, done = nullptr; };
+    std::vector<Chunk> ch(nchunks);
+    int result = MZD_OK;
+    size_t submitted = 0;
     for (size_t c = 0; c < nchunks && result == MZD_OK; c++) {
         const size_t c0 = cut[c], c1 = cut[c + 1];
-        // a lane: a free one, else the oldest chunk of this call is retired first (its lane is ours to reuse)
-        int ln = take_lane(d, fly.empty());
-        while (ln < 0) {
-            retire(fly.front()); fly.pop_front();
-            ln = take_lane(d, fly.empty());
-        }
-        Lane& l = d.lane[ln];
-        hipStream_t s = l.stream;
-        hipError_t e = hipSuccess;
-        if (c == 0) d.job0_counter = l.counter;
-        if (d.whole_used.load(std::memory_order_relaxed)) e = hipStreamWaitEvent(s, d.whole.ev1, 0); // a device-path launch still in flight on a caller's stream
+        Chunk& k = ch[c];
+        hipError_t e = hipEventCreateWithFlags(&k.in, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreate(&k.k0);
+        if (e == hipSuccess) e = hipEventCreate(&k.k1);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&k.done, hipEventDisableTiming);
         // inputs
-        if (!in_direct) {
+        if (e == hipSuccess && !in_direct) {
             size_t bytes = 0;
-            for (size_t k = c0; k < c1; k++) bytes += jobs[idx[k]].src_len;
+            for (size_t q = c0; q < c1; q++) bytes += jobs[idx[q]].src_len;
             if (Lin.run_dev.size() <= std::max<size_t>(8, n / 64)) { // few long runs: big copies split by bytes
                 for_run_pieces(Lin, c0, c1, true, [&](size_t dev_off, const uint8_t* host, size_t len) { if (len && host) parallel_memcpy(st->h_in + dev_off, host, len); });
             } else {
@@ -557,46 +544,79 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
                 });
             }
             const size_t lo = Lin.off[c0], hi = Lin.off[c1 - 1] + jobs[idx[c1 - 1]].src_len;
-            if (hi > lo) e = hipMemcpyAsync(st->d_in + lo, st->h_in + lo, hi - lo, hipMemcpyHostToDevice, s);
-        } else {
+            if (hi > lo) e = hipMemcpyAsync(st->d_in + lo, st->h_in + lo, hi - lo, hipMemcpyHostToDevice, d.copy_in);
+        } else if (e == hipSuccess) {
             for_run_pieces(Lin, c0, c1, true, [&](size_t dev_off, const uint8_t* host, size_t len) {
-                if (len && e == hipSuccess) e = hipMemcpyAsync(st->d_in + dev_off, host, len, hipMemcpyHostToDevice, s);
+                if (len && e == hipSuccess) e = hipMemcpyAsync(st->d_in + dev_off, host, len, hipMemcpyHostToDevice, d.copy_in);
             });
         }
-        // job table (+ lists) of the chunk, the kernels
-        Plan p;
-        if (e == hipSuccess) {
-            p = make_plan(st->h_jobs + c0, c1 - c0, st->h_lists + 2 * c0, l.nwg);
-            e = hipMemcpyAsync(st->d_jobs + c0, st->h_jobs + c0, (c1 - c0) * sizeof(DevJob), hipMemcpyHostToDevice, s);
-            if (e == hipSuccess && p.nsmall) e = hipMemcpyAsync(st->d_lists + 2 * c0, st->h_lists + 2 * c0, (c1 - c0) * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s);
-        }
+        if (e != hipSuccess) { result = MZD_E_DEVICE; break; }
+        const int ln = lane_begin(d, submitted != 0);
+        k.lane = ln;
+        submitted = c + 1;
+        Lane& l = d.lane[ln];
+        // job table (+ lists) of the chunk behind its inputs
+        const Plan p = make_plan(st->h_jobs + c0, c1 - c0, st->h_lists + 2 * c0, l.nwg);
+        e = hipMemcpyAsync(st->d_jobs + c0, st->h_jobs + c0, (c1 - c0) * sizeof(DevJob), hipMemcpyHostToDevice, d.copy_in);
+        if (e == hipSuccess && p.nsmall) e = hipMemcpyAsync(st->d_lists + 2 * c0, st->h_lists + 2 * c0, (c1 - c0) * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, d.copy_in);
+        if (e == hipSuccess) e = hipEventRecord(k.in, d.copy_in);
+        // the kernels
         int erc = MZD_OK;
-        if (e == hipSuccess) erc = enqueue(d, l, s, st->d_jobs + c0, p, st->d_lists + 2 * c0);
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> sub(l.submit_mu);
+            if (c == 0) d.job0_counter = l.counter;
+            e = hipStreamWaitEvent(l.stream, k.in, 0);
+            if (e == hipSuccess && d.whole_used.load(std::memory_order_relaxed)) e = hipStreamWaitEvent(l.stream, d.whole.ev1, 0); // a device-path launch may still run on a caller's stream
+            if (e == hipSuccess) erc = enqueue(d, l, l.stream, st->d_jobs + c0, p, st->d_lists + 2 * c0, k.k0, k.k1);
+        }
         // results and outputs
-        if (e == hipSuccess && erc == MZD_OK) e = hipMemcpyAsync(st->h_jobs + c0, st->d_jobs + c0, (c1 - c0) * sizeof(DevJob), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && erc == MZD_OK) e = hipStreamWaitEvent(d.copy_out, k.k1, 0);
+        if (e == hipSuccess && erc == MZD_OK) e = hipMemcpyAsync(st->h_jobs + c0, st->d_jobs + c0, (c1 - c0) * sizeof(DevJob), hipMemcpyDeviceToHost, d.copy_out);
         if (e == hipSuccess && erc == MZD_OK) {
             if (!out_direct) {
                 const size_t lo = Lout.off[c0], hi = Lout.off[c1 - 1] + jobs[idx[c1 - 1]].dst_cap;
-                if (hi > lo) e = hipMemcpyAsync(st->h_out + lo, st->d_out + lo, hi - lo, hipMemcpyDeviceToHost, s);
+                if (hi > lo) e = hipMemcpyAsync(st->h_out + lo, st->d_out + lo, hi - lo, hipMemcpyDeviceToHost, d.copy_out);
             } else {
                 for_run_pieces(Lout, c0, c1, false, [&](size_t dev_off, const uint8_t* host, size_t len) {
-                    if (len && e == hipSuccess) e = hipMemcpyAsync(const_cast<uint8_t*>(host), st->d_out + dev_off, len, hipMemcpyDeviceToHost, s);
+                    if (len && e == hipSuccess) e = hipMemcpyAsync(const_cast<uint8_t*>(host), st->d_out + dev_off, len, hipMemcpyDeviceToHost, d.copy_out);
                 });
             }
         }
-        hipEvent_t done = nullptr;
-        if (e == hipSuccess && erc == MZD_OK) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
-        if (e == hipSuccess && erc == MZD_OK) e = hipEventRecord(done, s);
-        if (e != hipSuccess || erc != MZD_OK) {
-            hipStreamSynchronize(s);
-            if (done) hipEventDestroy(done);
-            give_lane(d, ln);
-            result = erc != MZD_OK ? erc : MZD_E_DEVICE;
-            break;
-        }
-        fly.push_back(InFlight{c, ln, done});
+        if (e == hipSuccess && erc == MZD_OK) e = hipEventRecord(k.done, d.copy_out);
+        if (e != hipSuccess || erc != MZD_OK) result = erc != MZD_OK ? erc : MZD_E_DEVICE;
     }
-    while (!fly.empty()) { retire(fly.front()); fly.pop_front(); }
+    if (result != MZD_OK) { // something could not be submitted: let what is in flight finish, report the failure
+        hipStreamSynchronize(d.copy_in);
+        for (size_t c = 0; c < submitted; c++) hipStreamSynchronize(d.lane[ch[c].lane].stream);
+        hipStreamSynchronize(d.copy_out);
+    }
+    float ms_sum = 0.f;
+    for (size_t c = 0; c < nchunks; c++) { // retire in order: wait, hand bytes and results to the caller
+        Chunk& k = ch[c];
+        if (c < submitted && result == MZD_OK) {
+            if (hipEventSynchronize(k.done) != hipSuccess) result = MZD_E_DEVICE;
+            float ms = 0.f;
+            if (result == MZD_OK && hipEventElapsedTime(&ms, k.k0, k.k1) == hipSuccess) ms_sum += ms;
+        }
+        if (k.lane >= 0) lane_end(d, k.lane);
+        if (k.in) hipEventDestroy(k.in);
+        if (k.k0) hipEventDestroy(k.k0);
+        if (k.k1) hipEventDestroy(k.k1);
+        if (k.done) hipEventDestroy(k.done);
+        if (c >= submitted || result != MZD_OK) continue;
+        const size_t c0 = cut[c], c1 = cut[c + 1];
+        size_t bytes = 0;
+        for (size_t q = c0; q < c1; q++) bytes += std::min<size_t>(st->h_jobs[q].out_len, jobs[idx[q]].dst_cap);
+        parallel_for(c1 - c0, out_direct ? 0 : bytes, [&](size_t r) {
+            const size_t q = c0 + r;
+            mzd_job& j = jobs[idx[q]];
+            j.status = st->h_jobs[q].status;
+            j.out_len = (size_t)st->h_jobs[q].out_len;
+            j.device = d.index;
+            const size_t ncopy = std::min<size_t>(j.out_len, j.dst_cap);
+            if (!out_direct && ncopy && j.dst) memcpy(j.dst, st->h_out + Lout.off[q], ncopy);
+        });
+    }
     if (result == MZD_OK) d.last_ms = ms_sum;
     return result;
 }
@@ -635,6 +655,10 @@ struct mzd_batch {
 extern "C" {
 
 int mzd_init(const int* device_ids, int n) {
+    // The host path keeps kSlots kernel streams and two copy streams busy at once: ask the HIP runtime for enough hardware
+    // queues (its default, 4, makes streams share queues, i.e. serialises them).  Only effective before the runtime starts;
+    // a process that has used HIP already sets GPU_MAX_HW_QUEUES itself (bench.py does).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     std::vector<std::shared_ptr<Device>> old;
     { std::lock_guard<std::mutex> lk(g_mu); old.swap(g_dev); }
     drop_devices(old); // (calls in flight on the old devices finish first)
@@ -785,7 +809,7 @@ int mzd_batch_launch(mzd_batch* b, void* stream) {
     WholeGuard g(d); // (launches of one batch follow each other on `stream`; host-path launches wait for their end event)
     d.job0_counter = d.whole.counter;
     d.whole_used.store(true, std::memory_order_relaxed);
-    return enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists);
+    return enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists, d.whole.ev0, d.whole.ev1);
 }
 
 int mzd_batch_collect(mzd_batch* b, mzd_job* jobs, void* stream) {
@@ -931,6 +955,16 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
     for (int i = 0; i < 8; i++) out8[i] = ds.stamp[i];
     for (int i = 0; i < 8; i++) out8[8 + i] = ds.cstamp[i];
     for (int i = 0; i < 6; i++) out8[16 + i] = ds.tfin[i];
+    return MZD_OK;
+}
+
+// Diagnostic (a build with -DMZD_SMALL_STAMPS): the 8 phase stamps of the small-file kernel's workgroup 0.
+int mzd_debug_small_stamps(int device, uint64_t* out8) { // (9 values)
+    auto dp = get_device(device);
+    if (!dp || !out8) return MZD_E_PARAM;
+    WholeGuard g(*dp);
+    HIPCHK(hipSetDevice(dp->hip_id));
+    HIPCHK(hipMemcpy(out8, dp->debug, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MZD_OK;
 }
 

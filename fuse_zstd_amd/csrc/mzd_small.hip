@@ -13,8 +13,12 @@
 //     D  Huffman streams                                  lane = (file, stream) -> literal scratch (HBM, L2-resident)
 //     E  sequence header, normalized counts               lane = file
 //     F  FSE decode tables                                lane = (file, table)  -> the file's LDS slot (Huffman table is dead)
-//     G  state walk + repeat offsets + execute            lane = file: the classic serial loop, 16-64 files abreast
+//     G  state walk + repeat offsets + execute            lane = file, four sequences per step: HBM requests, then the walk of
+//                                                         the next four (LDS only), then the stores
 //     H  XXH64                                            lane = (file, accumulator)
+// Header bytes, Huffman streams and sequence bitstreams are staged in LDS before the loops that read them: a loop that
+// loads from HBM waits a round trip per load (s_waitcnt vmcnt(0) also waits for every store in flight), and a scattered
+// vector-memory instruction costs a wavefront ~200 cycles of issue -- measured, tools/small_stamps.py.
 // Only the plain case is decoded here: ONE frame holding ONE block, no error of any kind.  Anything else -- several
 // frames or blocks, skippable frames, tables that do not fit the slot, every malformed input -- is handed, untouched,
 // to the general drivers (the job index is appended to the launch's job list; mzd_host.cpp runs them right behind
@@ -23,6 +27,7 @@
 #include <stdint.h>
 
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/mzd.h"
 #include "mzd_device.h"
@@ -42,6 +47,9 @@ DI void gs64(uint8_t* p, uint64_t v) { __builtin_memcpy((gp)p, &v, 8); }
 DI void gs32(uint8_t* p, uint32_t v) { __builtin_memcpy((gp)p, &v, 4); }
 DI void gs8(uint8_t* p, uint32_t v) { *(gp)p = (uint8_t)v; }
 DI int hibit32(uint32_t v) { return 31 - __builtin_clz(v); }
+struct V16 { uint64_t a, b; }; // 16 bytes, any alignment (global_load / global_store_dwordx4)
+DI V16 gv16(const uint8_t* p) { V16 v; __builtin_memcpy(&v, (gcp)p, 16); return v; }
+DI void gsv16(uint8_t* p, const V16& v) { __builtin_memcpy((gp)p, &v, 16); }
 
 // ------------------------------------------------------------------------------------ LDS image (dynamic)
 extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -56,11 +64,14 @@ constexpr uint32_t kOffFiles = 1024;   // per-file areas
 constexpr uint32_t kAux = 256;         // per file: Huffman weights, then the normalized counts of the three sequence tables
 constexpr uint32_t kCtxBytes = 160;    // per file: FileLds (<= 128 bytes) + 32 bytes of scratch (rank counters)
 constexpr uint32_t kCtxScratch = 128;
+constexpr uint32_t kTreeStage = 1280;  // G = 16: the Huffman tree description is staged at main + kTreeStage (192 bytes), behind the weights' FSE table and counts
+constexpr uint32_t kSeqStage = 192;    // staged bytes of a sequences section header
 constexpr uint32_t kDictBytes = (512 + 512 + 256) * 4 + 2048 * 2;
 
 struct FileLds { // what lanes other than the file's own need to know
     uint64_t src, dst;
     uint32_t live, streams, huf_off, huf_log; // huf_off: byte offset of the Huffman table in LDS
+    uint32_t hs_lds;                          // LDS byte offset of the staged Huffman streams, or 0
     uint32_t s_off[4], s_len[4];
     uint32_t nlit, out_len, has_ck, n, nseq;
     uint8_t mode[4], al[4], nsym[4], rle[4];  // per sequence table (LL, OF, ML)
@@ -72,6 +83,7 @@ template <int G> struct Lay {
     static constexpr uint32_t kMain = G == 16 ? 2048u : 16u; // Huffman table (<= 2^10 entries), later the FSE tables (<= 512 entries)
     static constexpr uint32_t kAuxB = G == 16 ? kAux : 0u;
     static constexpr uint32_t kStride = kMain + kAuxB + kCtxBytes;
+    static constexpr uint32_t kSeqStageB = G == 16 ? kSeqStage : 256u; // staged bytes of a sequences section header (G = 16: inside the slot); G = 64: the file's stage, later its sequence bitstream
     static constexpr uint32_t kDict = kOffFiles + G * kStride;
     DI static uint32_t main_off(uint32_t f) { return kOffFiles + f * kStride; }
     DI static uint32_t aux_off(uint32_t f) { return main_off(f) + kMain; }
@@ -90,101 +102,80 @@ DI void wave_sync() { // LDS + global writes of this wavefront visible to its ot
 }
 
 // ------------------------------------------------------------------------------------ bit readers (per lane, HBM/L2)
-// Backward bitstream (A: "read from the end"): p[0..len), `h` = number of unread bits.  `cur` holds the unread bits
-// MSB-aligned (bit 63 = stream bit h-1); bits below stream bit 0 read as zero and drive h negative (= over-read).
-struct BackBits {
-    const uint8_t* p;
+// Bit readers over header bytes staged in LDS (`base` byte offset, `n` bytes staged, >= 8 readable bytes behind them).
+DI uint64_t lds_u64(uint32_t off) { uint64_t v; __builtin_memcpy(&v, lds + off, 8); return v; }
+struct LBack { // backward (the Huffman weights' stream: <= 128 bytes), zero below the start
+    uint32_t base;
     int32_t h;
     uint64_t cur;
     int32_t avail;
-    DI bool init(const uint8_t* sp, uint32_t sl) {
-        p = sp; cur = 0; avail = 0; h = 0;
+    DI bool init(uint32_t off, uint32_t sl) {
+        base = off; cur = 0; avail = 0; h = 0;
         if (sl == 0) return false;
-        const uint32_t last = gu8(sp + sl - 1);
+        const uint32_t last = lds[off + sl - 1];
         if (last == 0) return false;
         h = (int32_t)((sl - 1) * 8) + hibit32(last);
         return true;
     }
-    DI void refill() { // >= 57 valid bits (or zeros past the start)
+    DI void refill() {
         if (h <= 0) { cur = 0; avail = 64; return; }
-        const int32_t b = (h - 1) >> 3;             // byte holding stream bit h-1
-        const uint64_t W = gu64(p + b - 7);         // stream bytes [b-7, b]: every stream is preceded by >= 12 header bytes of its file
-        const int32_t sh = 8 * (b + 1) - h;         // bits of W above the read head: 0..7
+        const int32_t b = (h - 1) >> 3;
+        uint64_t W = b >= 7 ? lds_u64(base + (uint32_t)(b - 7)) : lds_u64(base) << (8 * (7 - b)); // (the staged bytes before the stream are not its own)
+        const int32_t sh = 8 * (b + 1) - h;
         cur = W << sh;
         avail = 64 - sh;
-        if (h < avail) cur &= ~0ull << (64 - h);    // bits below stream bit 0 are zero
+        if (h < avail) cur &= ~0ull << (64 - h);
     }
-    DI uint32_t peek(uint32_t n) const { return n ? (uint32_t)(cur >> (64 - n)) : 0u; } // n <= 32 <= avail
-    DI void skip(uint32_t n) { cur <<= n; avail -= (int32_t)n; h -= (int32_t)n; }
     DI uint32_t read(uint32_t n) { // n <= 32
         if ((int32_t)n > avail) refill();
-        const uint32_t v = peek(n);
-        skip(n);
+        const uint32_t v = n ? (uint32_t)(cur >> (64 - n)) : 0u;
+        cur <<= n; avail -= (int32_t)n; h -= (int32_t)n;
         return v;
     }
 };
 
-// Forward bitstream of a normalized-count header (A.3); zero past its end.
-struct FwdBits {
-    const uint8_t* p;
-    uint32_t n;
-    uint64_t win;
-    int32_t wbase, wtop;
-    DI uint32_t take(int32_t bit, int nb) { // bits [bit, bit + nb), nb <= 16
-        if (bit < wbase || bit + nb > wtop) {
-            const uint32_t byte = (uint32_t)bit >> 3;
-            wbase = (int32_t)(byte * 8); wtop = wbase + 64;
-            win = 0;
-            if (byte < n) {
-                win = gu64(p + byte); // (may over-read <= 7 bytes: input padding)
-                const uint32_t av = n - byte;
-                if (av < 8) win &= (1ull << (av * 8)) - 1;
-            }
-        }
-        return (uint32_t)(win >> (bit - wbase)) & ((1u << nb) - 1);
-    }
-};
-
-// Normalized counts (A.3) -> int16 norm[] in LDS at byte offset `norm_off`.  Returns bytes used or 0 (give up).
-// sym_cap: symbols the caller has room for (<= max_sym + 1).
-DI uint32_t read_ncount_lane(const uint8_t* p, uint32_t n, int max_log, int max_sym, int sym_cap, uint32_t norm_off, uint32_t& nsym_out, uint32_t& log_out) {
+// Normalized counts (A.3) from header bytes staged in LDS (>= 8 readable bytes behind them) -> int16 norm[] in LDS at byte
+// offset `norm_off`.  Returns bytes used or 0 (give up).  sym_cap: symbols the caller has room for (<= max_sym + 1).
+// Every field (<= 10 bits) is one unaligned 4-byte LDS read at its bit position: no window to maintain.  Bits past the
+// description's end need no masking: a read that touches them either leaves `bit` past the limit (rejected), or it is the
+// short form of a value whose dropped bit was the only one outside, which does not enter the value.
+DI uint32_t read_ncount_lane(uint32_t src_off, uint32_t n, int max_log, int max_sym, int sym_cap, uint32_t norm_off, uint32_t& nsym_out, uint32_t& log_out) {
     if (n < 1) return 0;
     const int32_t limit = (int32_t)(n > 4096 ? 4096 : n) * 8;
-    FwdBits fb{p, n, 0, 0, 0};
-    int32_t bit = 0;
-    const int al = 5 + (int)fb.take(bit, 4);
-    bit += 4;
+    auto bits = [&](int32_t bit) -> uint32_t { uint32_t v; __builtin_memcpy(&v, lds + src_off + ((uint32_t)bit >> 3), 4); return v >> (bit & 7); }; // >= 25 bits
+    int32_t bit = 4;
+    const int al = 5 + (int)(bits(0) & 15);
     if (al > max_log) return 0;
     int remaining = 1 << al, sym = 0;
-    while (remaining > 0 && sym <= max_sym) {
+    bool bad = false;
+    while (remaining > 0 && sym <= max_sym && !bad) {
         const int nb = hibit32((uint32_t)(remaining + 1)) + 1;
-        if (bit >= limit) return 0;
-        int val = (int)fb.take(bit, nb);
-        bit += nb;
+        bad |= bit >= limit;
+        const int val = (int)(bits(bit) & ((1u << nb) - 1));
         const int lower = (1 << (nb - 1)) - 1;
         const int thr = (1 << nb) - 1 - (remaining + 1);
-        if ((val & lower) < thr) { bit -= 1; val &= lower; }
-        else if (val > lower) val -= thr;
-        const int pr = val - 1;
+        const bool small = (val & lower) < thr;
+        const int v2 = small ? (val & lower) : (val > lower ? val - thr : val);
+        bit += small ? nb - 1 : nb;
+        const int pr = v2 - 1;
         remaining -= (pr < 0) ? 1 : pr;
-        if (remaining < 0 || sym >= sym_cap) return 0;
+        bad |= (remaining < 0) | (sym >= sym_cap);
+        if (bad) break;
         L16s(norm_off + 2 * (uint32_t)sym) = (int16_t)pr;
         sym++;
-        if (pr == 0) {
+        if (pr == 0) { // runs of zero-probability symbols: 2 bits each, 3 = "and more"
             for (;;) {
-                if (bit >= limit) return 0;
-                const int r = (int)fb.take(bit, 2);
+                if (bit >= limit) { bad = true; break; }
+                const int r = (int)(bits(bit) & 3);
                 bit += 2;
-                for (int i = 0; i < r; i++) {
-                    if (sym > max_sym || sym >= sym_cap) return 0;
-                    L16s(norm_off + 2 * (uint32_t)sym) = 0;
-                    sym++;
-                }
+                if (sym + r > max_sym + 1 || sym + r > sym_cap) { bad = true; break; }
+                for (int i = 0; i < r; i++) L16s(norm_off + 2 * (uint32_t)(sym + i)) = 0;
+                sym += r;
                 if (r != 3) break;
             }
         }
     }
-    if (remaining != 0 || sym > max_sym + 1 || bit > limit) return 0;
+    if (bad || remaining != 0 || sym > max_sym + 1 || bit > limit) return 0;
     nsym_out = (uint32_t)sym;
     log_out = (uint32_t)al;
     return (uint32_t)((bit + 7) >> 3);
@@ -232,7 +223,14 @@ DI void copy_lane(uint8_t* d, const uint8_t* s, uint32_t n, const uint8_t* dlim)
 }
 // a match: n bytes from d - off, overlap allowed (A.5 "byte-sequentially")
 DI void match_lane(uint8_t* d, uint32_t off, uint32_t n, const uint8_t* dlim) {
-    if (d + n + 8 <= dlim) {
+    if (off >= 32 && d + n + 32 <= dlim) { // (two 16-byte pieces in flight)
+        const uint8_t* s = d - off;
+        for (uint32_t k = 0; k < n; k += 32) {
+            const V16 a = gv16(s + k), b = gv16(s + k + 16);
+            gsv16(d + k, a);
+            if (k + 16 < n) gsv16(d + k + 16, b);
+        }
+    } else if (d + n + 8 <= dlim) {
         if (off >= 8) {
             const uint8_t* s = d - off;
             if (off >= 16) { // two chunks in flight
@@ -269,6 +267,13 @@ DI uint64_t xxh_tail(uint64_t hh, const uint8_t* q, const uint8_t* end) {
     return hh;
 }
 
+// Diagnostic build only (-DMZD_SMALL_STAMPS): cycle counter of workgroup 0 at every phase boundary of its first group.
+#ifdef MZD_SMALL_STAMPS
+#define SSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) a.stamps[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SSTAMP(k)
+#endif
+
 // ------------------------------------------------------------------------------------ the kernel
 struct DictInfo { // the dictionary whose tables sit in LDS (wave-uniform)
     uint32_t handle, formatted, dict_id, content_len, huf_log;
@@ -291,6 +296,8 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
     constexpr int LPF = 64 / G; // lanes per file in the (file, part) phases: 4 or 1
     const int lane = threadIdx.x;
     const uint32_t dict_off = LY::kDict;
+    const uint32_t stage64_off = dict_off + (a.with_dict ? kDictBytes : 0u); // G = 64: the staged sequence headers, behind the dictionary's tables
+    (void)stage64_off;
 
     // ---- once per wavefront: code tables, predefined tables
     if (lane < 36) L32(kOffLLCode + 4 * lane) = LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24);
@@ -316,8 +323,11 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
     uint8_t* const lit_base = a.lit_scratch + (size_t)blockIdx.x * G * a.lit_stride;
     const uint32_t ngroups = (a.nsmall + G - 1) / G;
 
+    bool first_group = true;
+    (void)first_group;
     for (;;) {
         uint32_t g = 0;
+        SSTAMP(0);
         if (lane == 0) g = atomicAdd(&a.counter[5], 1u);
         g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
         if (g >= ngroups) break;
@@ -484,6 +494,27 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
             }
         }
         bool live = ok && !done; // a compressed block to decode
+        SSTAMP(1);
+
+        // =============================== staging: the Huffman tree descriptions -> LDS (lane = (file, quarter))
+        // (a lone lane parsing bits out of HBM pays a round trip per window, and every lane of the group at another moment)
+        if (G == 16) {
+            const uint32_t f = (uint32_t)lane >> 2, q = (uint32_t)lane & 3;
+            const uint64_t tl = __ballot(live && lit_type == 2); // files with a tree
+            const uint32_t toff = (uint32_t)__shfl((int)tree_off, (int)f);
+            if ((tl >> f) & 1) {
+                const FileLds& F = fl<G>(f);
+                const uint8_t* sp = (const uint8_t*)(uintptr_t)F.src;
+                const uint32_t dst_off = LY::main_off(f) + kTreeStage + q * 48;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { // <= 129 bytes of tree; nothing is read past the input + its padding
+                    const uint32_t at = toff + q * 48 + 8 * k;
+                    const uint64_t v = (q * 48 + 8 * k < 144 && at + 8 <= F.n + MZD_SRC_PADDING) ? gu64(sp + at) : 0ull;
+                    __builtin_memcpy(lds + dst_off + 8 * k, &v, 8);
+                }
+            }
+            wave_sync();
+        }
 
         // =============================== phase B + C: Huffman weights and table (lane = file; G = 16 only)
         uint32_t huf_log = di.huf_log, huf_off = dict_off + 5120; // treeless: the dictionary's table
@@ -493,24 +524,20 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
                 bool good = false;
                 uint32_t nw = 0;
                 do {
-                    const uint8_t* tp = src + tree_off;
-                    const uint32_t hb = gu8(tp);
+                    const uint32_t tp = mo + kTreeStage; // the staged tree description
+                    const uint32_t hb = L8(tp);
                     if (hb >= 128) { // direct: 4 bits per weight, high nibble first
                         nw = hb - 127;
-                        for (uint32_t i = 0; i < nw; i += 16) {
-                            const uint64_t w8 = gu64(tp + 1 + i / 2);
-#pragma unroll
-                            for (uint32_t k = 0; k < 16; k++) {
-                                const uint32_t by = (uint32_t)(w8 >> (8 * (k / 2))) & 0xFF;
-                                if (i + k < nw) L8(ao + i + k) = (uint8_t)((k & 1) ? (by & 15) : (by >> 4));
-                            }
+                        for (uint32_t i = 0; i < nw; i++) {
+                            const uint32_t by = L8(tp + 1 + i / 2);
+                            L8(ao + i) = (uint8_t)((i & 1) ? (by & 15) : (by >> 4));
                         }
                     } else {
                         uint32_t nsym = 0, log = 0;
                         const uint32_t hdr = read_ncount_lane(tp + 1, hb, 6, 255, 16, mo + 1024, nsym, log);
                         if (hdr == 0 || hdr >= hb) break;
                         if (!build_fse_lane(mo, mo + 1024, nsym, log, 3)) break;
-                        BackBits rd;
+                        LBack rd;
                         if (!rd.init(tp + 1 + hdr, hb - hdr)) break;
                         rd.refill();
                         uint32_t s1 = rd.read(log), s2 = rd.read(log);
@@ -553,7 +580,7 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
                     uint32_t pos = 0; // rank counters -> start positions (weight 1 = longest codes first)
                     for (uint32_t r = 1; r <= maxbits; r++) { const uint32_t c = L16(so + 2 * r); L16(so + 2 * r) = (uint16_t)pos; pos += c << (r - 1); }
                     if (pos != (1u << maxbits)) break; // also catches weights above maxbits
-                    for (uint32_t s = 0; s < nw; s++) {
+                    for (uint32_t s = 0; s < nw; s++) { // (the staged tree and the weights' FSE table are dead: the table takes their place)
                         const uint32_t w = L8(ao + s);
                         if (!w) continue;
                         const uint32_t cnt = 1u << (w - 1), at = L16(so + 2 * w);
@@ -574,49 +601,112 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
             if (!live) { F.live = 0; F.streams = 0; }
         }
         wave_sync();
+        SSTAMP(2);
+
+        // =============================== staging: the Huffman streams -> LDS, where they fit (lane = (file, part))
+        // A hot loop must not wait for HBM: the compiler guards every use of a loaded value with s_waitcnt vmcnt(0), which
+        // also waits for every store in flight.  So the streams of a file (one contiguous piece of its block) are copied
+        // into LDS first -- G = 16: behind the file's Huffman table in its slot; G = 64: into the file's stage.
+        uint32_t hs_lds = 0; // LDS byte offset of the first stream's first byte, or 0 (read from HBM)
+        if (live && lit_type >= 2) {
+            const uint32_t tbytes = (G == 16 && lit_type == 2) ? (2u << huf_log) : 0u; // (treeless: the dictionary's table, shared)
+            const uint32_t room0 = G == 16 ? LY::main_off((uint32_t)lane) + tbytes : stage64_off + (uint32_t)lane * LY::kSeqStageB;
+            const uint32_t room1 = G == 16 ? LY::main_off((uint32_t)lane) + LY::kMain : room0 + LY::kSeqStageB;
+            const uint32_t total = s_len0 + s_len1 + s_len2 + s_len3;
+            if (room0 + 16 + total + 8 <= room1) hs_lds = room0 + 16;
+        }
+        {
+            const uint32_t f = (uint32_t)lane / LPF, q = (uint32_t)lane % LPF;
+            const uint32_t to = (uint32_t)__shfl((int)hs_lds, (int)f), from = (uint32_t)__shfl((int)s_base, (int)f);
+            const uint32_t len = (uint32_t)__shfl((int)(s_len0 + s_len1 + s_len2 + s_len3), (int)f);
+            if (to) {
+                const uint8_t* sp = (const uint8_t*)(uintptr_t)fl<G>(f).src + from;
+                if (q == 0) { const uint64_t z = 0; __builtin_memcpy(lds + to - 16, &z, 8); __builtin_memcpy(lds + to - 8, &z, 8); }
+                uint32_t k = q * 8;
+                for (; k + 3 * LPF * 8 < len; k += 4 * LPF * 8) { // four loads in flight
+                    const uint64_t v0 = gu64(sp + k), v1 = gu64(sp + k + LPF * 8), v2 = gu64(sp + k + 2 * LPF * 8), v3 = gu64(sp + k + 3 * LPF * 8);
+                    __builtin_memcpy(lds + to + k, &v0, 8); __builtin_memcpy(lds + to + k + LPF * 8, &v1, 8);
+                    __builtin_memcpy(lds + to + k + 2 * LPF * 8, &v2, 8); __builtin_memcpy(lds + to + k + 3 * LPF * 8, &v3, 8);
+                }
+                for (; k < len; k += LPF * 8) { const uint64_t v = gu64(sp + k); __builtin_memcpy(lds + to + k, &v, 8); } // (reads <= 7 bytes past the streams: input padding; writes stay below room1)
+            }
+        }
+        if (lane < G) fl<G>((uint32_t)lane).hs_lds = hs_lds;
+        wave_sync();
 
         // =============================== phase D: Huffman streams -> literal scratch (lane = (file, stream))
         uint32_t lit_bad = 0; // per lane: a stream of file `lane / LPF` failed
         {
-            auto one_stream = [&](uint32_t f, uint32_t st) -> bool {
+            // One stream by one lane.  The unread bits sit MSB-aligned in `cur` (`av` of them are real window bits); the window
+            // is re-read from the staged bytes (or from HBM) when fewer than 22 are left; two symbols (<= 22 bits) per step.
+            auto one_stream = [&](uint32_t f, uint32_t st, auto staged_c) -> bool {
+                constexpr bool STAGED = decltype(staged_c)::value;
                 const FileLds& F = fl<G>(f);
+                const uint32_t rel = F.s_off[st] - F.s_off[0];
                 const uint8_t* sp = (const uint8_t*)(uintptr_t)F.src + F.s_off[st];
+                const uint32_t lbase = F.hs_lds + rel;
+                const bool in_lds = F.hs_lds != 0;
                 const uint32_t sl = F.s_len[st], seg = (F.nlit + 3) / 4;
                 const uint32_t nsym = F.streams == 1 ? F.nlit : (st < 3 ? seg : F.nlit - 3 * seg);
                 uint8_t* out = lit_base + (size_t)f * a.lit_stride + (F.streams == 1 ? 0u : st * seg);
                 const uint32_t L = F.huf_log, tab = F.huf_off;
-                BackBits rd;
-                if (!rd.init(sp, sl)) return false;
-                uint32_t k = 0;
-                while (k + 4 <= nsym) { // 4 symbols (<= 44 bits) per window
-                    rd.refill();
-                    uint32_t acc = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t e = L16(tab + 2 * rd.peek(L));
-                        acc |= (e & 0xFF) << (8 * j);
-                        rd.skip(e >> 8);
-                    }
-                    gs32(out + k, acc);
-                    k += 4;
+                if (sl == 0) return false;
+                const uint32_t last = (STAGED || in_lds) ? L8(lbase + sl - 1) : gu8(sp + sl - 1);
+                if (last == 0) return false;
+                int32_t h = (int32_t)((sl - 1) * 8) + hibit32(last); // unread bits
+                // the 64 bits below the read head, MSB-aligned; bits below the stream's start read as zero (A.4: the last symbols
+                // may peek past it).  Every stream is preceded by >= 8 readable bytes (header bytes of its file / the zero pad).
+                auto window = [&](int32_t hh, int32_t& av) -> uint64_t {
+                    int32_t b = (hh - 1) >> 3;
+                    b = b < -1 ? -1 : b;
+                    uint64_t w;
+                    if (STAGED || in_lds) w = lds_u64(lbase + (uint32_t)(b + 9) - 16);
+                    else w = gu64(sp + (b - 7));
+                    const uint32_t sh = (uint32_t)(8 * (b + 1) - hh) & 63;
+                    w <<= sh;
+                    av = 64 - (int32_t)sh;
+                    const uint64_t keep = hh >= 64 ? ~0ull : (hh <= 0 ? 0ull : ~0ull << (64 - hh));
+                    return w & keep;
+                };
+                int32_t av;
+                uint64_t cur = window(h, av);
+                uint32_t k = 0, acc = 0;
+                const uint32_t shL = 64 - L;
+                for (; k + 2 <= nsym; k += 2) {
+                    const uint32_t e0 = L16(tab + 2 * (uint32_t)(cur >> shL));
+                    cur <<= (e0 >> 8);
+                    const uint32_t e1 = L16(tab + 2 * (uint32_t)(cur >> shL));
+                    cur <<= (e1 >> 8);
+                    const int32_t used = (int32_t)((e0 >> 8) + (e1 >> 8));
+                    av -= used; h -= used;
+                    acc |= ((e0 & 0xFF) | ((e1 & 0xFF) << 8)) << (8 * (k & 2));
+                    if (k & 2) { gs32(out + k - 2, acc); acc = 0; }
+                    if (av < 22) cur = window(h, av);
                 }
+                // the tail: what is left of a group of four, and an odd last symbol
+                if (k & 2) { gs8(out + k - 2, acc & 0xFF); gs8(out + k - 1, (acc >> 8) & 0xFF); }
                 if (k < nsym) {
-                    rd.refill();
-                    for (; k < nsym; k++) {
-                        const uint32_t e = L16(tab + 2 * rd.peek(L));
-                        gs8(out + k, e & 0xFF);
-                        rd.skip(e >> 8);
-                    }
+                    const uint32_t e0 = L16(tab + 2 * (uint32_t)(cur >> shL));
+                    gs8(out + k, e0 & 0xFF);
+                    h -= (int32_t)(e0 >> 8);
                 }
-                return rd.h == 0; // consumed exactly
+                return h == 0; // consumed exactly
             };
+            // (wave-uniform choice: the staged form has no HBM load in its loop at all)
+            const bool all_staged = __ballot(live && lit_type >= 2 && hs_lds == 0) == 0;
             if (LPF == 4) {
                 const uint32_t f = (uint32_t)lane >> 2, st = (uint32_t)lane & 3;
-                if (st < fl<G>(f).streams && !one_stream(f, st)) lit_bad = 1;
+                if (st < fl<G>(f).streams) {
+                    const bool r = all_staged ? one_stream(f, st, std::true_type{}) : one_stream(f, st, std::false_type{});
+                    if (!r) lit_bad = 1;
+                }
             } else {
                 const uint32_t f = (uint32_t)lane;
                 const uint32_t ns = fl<G>(f).streams;
-                for (uint32_t st = 0; st < ns; st++) if (!one_stream(f, st)) { lit_bad = 1; break; }
+                for (uint32_t st = 0; st < ns; st++) {
+                    const bool r = all_staged ? one_stream(f, st, std::true_type{}) : one_stream(f, st, std::false_type{});
+                    if (!r) { lit_bad = 1; break; }
+                }
             }
         }
         if (LPF == 4) { // a failed stream condemns its file
@@ -629,16 +719,36 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
             uint8_t* out = lit_base + (size_t)lane * a.lit_stride;
             for (uint32_t k = 0; k < nlit; k += 4) gs32(out + k, v); // (slack past nlit)
         }
+        SSTAMP(3);
+
+        // =============================== staging: the sequences section headers -> LDS (the Huffman tables are dead)
+        wave_sync();
+        {
+            const uint32_t f = (uint32_t)lane / LPF, q = (uint32_t)lane % LPF;
+            const uint64_t lv = __ballot(live);
+            const uint32_t soff = (uint32_t)__shfl((int)seq_off, (int)f), slen = (uint32_t)__shfl((int)seq_len, (int)f);
+            if ((lv >> f) & 1) {
+                // kSeqStageB bytes per file (nbSeq, modes and three normalized-count descriptions take <= ~150; G = 64 needs
+                // only nbSeq, modes and the RLE symbols: 16), 8-byte pieces;
+                // nothing is read past the section's end + input padding
+                const uint8_t* sp = (const uint8_t*)(uintptr_t)fl<G>(f).src + soff;
+                const uint32_t dst_off = (G == 16 ? LY::main_off(f) : stage64_off + f * LY::kSeqStageB);
+                for (uint32_t k = q * 8; k < (G == 16 ? kSeqStage : 16u); k += LPF * 8) { const uint64_t v = k < slen + 8 ? gu64(sp + k) : 0ull; __builtin_memcpy(lds + dst_off + k, &v, 8); }
+            }
+        }
+        wave_sync();
 
         // =============================== phase E: sequences section header (lane = file)
         uint32_t nseq = 0, bs_off = 0, bs_len = 0;
         uint32_t tabL = 0, tabO = 0, tabM = 0, alL = 0, alO = 0, alM = 0;
-        uint32_t modes3 = 0, rle_syms = 0, nsyms = 0, als = 0;
+        uint32_t modes3 = 0, rle_syms = 0, nsyms = 0, als = 0, tab_bytes = 0;
         if (live) {
             bool good = false;
             do {
-                const uint8_t* sp = src + seq_off;
-                const uint64_t w = gu64(sp);
+                const uint32_t sp = (G == 16 ? LY::main_off((uint32_t)lane) : stage64_off + (uint32_t)lane * LY::kSeqStageB); // the staged header
+                const uint32_t stage_n = G == 16 ? kSeqStage : 16u;
+                const uint32_t staged = seq_len < stage_n - 8 ? seq_len : stage_n - 8;
+                const uint64_t w = lds_u64(sp);
                 uint32_t p = 1;
                 nseq = (uint32_t)w & 0xFF;
                 if (nseq > 0x7F) {
@@ -661,14 +771,15 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
                     uint32_t tab = 0, al = 0, rs = 0, ns = 0;
                     if (m == 0) { tab = kOffPredef / 4 + (t == 0 ? 0u : (t == 1 ? 64u : 96u)); al = t == 1 ? 5u : 6u; }
                     else if (m == 1) {
-                        if (p + 1 > seq_len) { tbad = true; break; }
-                        rs = gu8(sp + p); p++;
+                        if (p + 1 > seq_len || p >= staged) { tbad = true; break; }
+                        rs = L8(sp + p); p++;
                         if (rs > (uint32_t)max_sym) { tbad = true; break; }
                         tab = main_dw + used_entries; used_entries += 1; al = 0;
                     } else if (m == 2) {
-                        if (G != 16) { tbad = true; break; } // no room for private tables in this layout
+                        if (G != 16 || p >= staged) { tbad = true; break; } // (G = 64: no room for private tables in this layout)
                         const uint32_t noff = ao + (t == 0 ? 0u : (t == 1 ? 72u : 136u));
-                        const uint32_t used = read_ncount_lane(sp + p, seq_len - p, max_log, max_sym, max_sym + 1, noff, ns, al);
+                        const uint32_t avail = seq_len - p < staged - p ? seq_len - p : staged - p; // a description that runs past the staged bytes fails here: handed on
+                        const uint32_t used = read_ncount_lane(sp + p, avail, max_log, max_sym, max_sym + 1, noff, ns, al);
                         if (used == 0) { tbad = true; break; }
                         p += used;
                         tab = main_dw + used_entries; used_entries += 1u << al;
@@ -682,6 +793,7 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
                 if (tbad || used_entries * 4 > LY::kMain) break;
                 if (p >= seq_len) break; // the bitstream needs at least one byte
                 bs_off = seq_off + p; bs_len = seq_len - p;
+                tab_bytes = used_entries * 4;
                 good = true;
             } while (false);
             if (!good) { ok = false; live = false; }
@@ -693,8 +805,9 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
             F.tab[0] = tabL; F.tab[1] = tabO; F.tab[2] = tabM;
         }
         wave_sync();
+        SSTAMP(4);
 
-        // =============================== phase F: FSE decode tables (lane = (file, table); the Huffman table is dead)
+        // =============================== phase F: FSE decode tables (lane = (file, table); the staged header is dead)
         {
             uint32_t tb_bad = 0;
             auto one_table = [&](uint32_t f, int t) -> bool {
@@ -723,102 +836,247 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
             }
         }
         wave_sync();
+        SSTAMP(5);
 
-        // =============================== phase G: state walk + repeat offsets + execute (lane = file)
-        if (live) {
-            bool good = false;
+        // =============================== staging: the sequence bitstreams -> LDS, where they fit (lane = (file, part))
+        // G = 16: behind the file's tables in its slot; G = 64: in the file's 256-byte stage.  16 zero bytes in front: a window
+        // that reaches below the stream's start reads zeros.  A stream that does not fit is read from HBM (a round trip per sequence).
+        uint32_t bs_lds = 0; // LDS byte offset of stream byte 0, or 0
+        if (live && nseq) {
+            const uint32_t room0 = G == 16 ? LY::main_off((uint32_t)lane) + ((tab_bytes + 7) & ~7u) : stage64_off + (uint32_t)lane * LY::kSeqStageB;
+            const uint32_t room1 = G == 16 ? LY::main_off((uint32_t)lane) + LY::kMain : room0 + LY::kSeqStageB;
+            if (room0 + 16 + bs_len + 8 <= room1) bs_lds = room0 + 16;
+        }
+        {
+            const uint32_t f = (uint32_t)lane / LPF, q = (uint32_t)lane % LPF;
+            const uint32_t to = (uint32_t)__shfl((int)bs_lds, (int)f), from = (uint32_t)__shfl((int)bs_off, (int)f), len = (uint32_t)__shfl((int)bs_len, (int)f);
+            if (to) {
+                const uint8_t* sp = (const uint8_t*)(uintptr_t)fl<G>(f).src + from;
+                if (q == 0) { const uint64_t z = 0; __builtin_memcpy(lds + to - 16, &z, 8); __builtin_memcpy(lds + to - 8, &z, 8); }
+                uint32_t k = q * 8;
+                for (; k + 3 * LPF * 8 < len; k += 4 * LPF * 8) { // four loads in flight
+                    const uint64_t v0 = gu64(sp + k), v1 = gu64(sp + k + LPF * 8), v2 = gu64(sp + k + 2 * LPF * 8), v3 = gu64(sp + k + 3 * LPF * 8);
+                    __builtin_memcpy(lds + to + k, &v0, 8); __builtin_memcpy(lds + to + k + LPF * 8, &v1, 8);
+                    __builtin_memcpy(lds + to + k + 2 * LPF * 8, &v2, 8); __builtin_memcpy(lds + to + k + 3 * LPF * 8, &v3, 8);
+                }
+                for (; k < len; k += LPF * 8) { const uint64_t v = gu64(sp + k); __builtin_memcpy(lds + to + k, &v, 8); } // (reads <= 7 bytes past the stream: input padding; writes stay below room1)
+            }
+        }
+        wave_sync();
+
+        // =============================== phase G: FSE state walk + repeat offsets + execute (lane = file), four sequences per step
+        // Software pipeline.  Per step: (1) the HBM requests of the step's four sequences, in straight-line code without a
+        // branch around any load -- 16 literal bytes per sequence (up to 48 where the run is longer) and 16 / 32 bytes of every
+        // match whose source is older than the step's output or lies in the dictionary; (2) the WALK of the next four
+        // sequences -- three table reads and one window of the bitstream per sequence, all LDS, no branch on its data --
+        // which takes longer than the requests' round trip; (3) the step's stores, in order (whole 16-byte pieces: what
+        // spills past a piece is rewritten by the piece behind it).  A match that reads what its own step wrote, literal runs
+        // over 48 and matches over 32 bytes, and the last steps before the destination's end take the sequential path.
+        auto walk_execute = [&](auto staged_c) {
+            constexpr bool STAGED = decltype(staged_c)::value; // every bitstream of the group sits in LDS: no HBM load in the walk
+            const uint8_t* const sp = src + bs_off;
+            const bool in_lds = bs_lds != 0;
+            auto window = [&](int32_t hh) -> uint64_t { // the 8 stream bytes that end with the byte holding bit hh - 1
+                int32_t b = (hh - 1) >> 3;
+                b = b < -1 ? -1 : b; // (an over-read stream: flagged below; the read stays inside the zero pad / the file's header bytes)
+                uint64_t w;
+                if (STAGED || in_lds) w = lds_u64(bs_lds + (uint32_t)(b + 9) - 16);
+                else w = gu64(sp + (b - 7));
+                return w;
+            };
+            bool bad = false;
+            int32_t h = 0;
+            uint32_t sL = 0, sO = 0, sM = 0;
+            uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+            uint64_t W = 0;
+            if (nseq) {
+                const uint32_t lastb = (STAGED || in_lds) ? L8(bs_lds + bs_len - 1) : gu8(sp + bs_len - 1);
+                bad = lastb == 0;
+                h = (int32_t)((bs_len - 1) * 8) + hibit32(lastb | 1u);
+                const uint32_t need = alL + alO + alM; // <= 26
+                bad |= h < (int32_t)need;
+                const int32_t b = (h - 1) >> 3;
+                uint64_t cur = window(h) << ((8 * (b + 1) - h) & 63);
+                sL = alL ? (uint32_t)(cur >> (64 - alL)) : 0u; cur <<= alL;
+                sO = alO ? (uint32_t)(cur >> (64 - alO)) : 0u; cur <<= alO;
+                sM = alM ? (uint32_t)(cur >> (64 - alM)) : 0u;
+                h -= (int32_t)need;
+                if (with_d && di.formatted) { rep0 = di.rep[0]; rep1 = di.rep[1]; rep2 = di.rep[2]; }
+                W = window(h);
+            }
+            struct Seq4 { uint32_t ll[4], ml[4], off[4]; };
+            auto walk4 = [&](uint32_t i0, Seq4& q) { // sequences i0 .. i0 + 3 (zero past the last one)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    q.ll[k] = 0; q.ml[k] = 0; q.off[k] = 0;
+                    const uint32_t i = i0 + (uint32_t)k;
+                    if (i < nseq) {
+                        int32_t b = (h - 1) >> 3;
+                        b = b < -1 ? -1 : b;
+                        const uint32_t sh = (uint32_t)(8 * (b + 1) - h) & 63;
+                        const uint64_t cur = W << sh;
+                        const uint32_t avail = 64 - sh; // >= 57 while the stream lasts
+                        const uint32_t eL = L32(4 * (tabL + sL)), eO = L32(4 * (tabO + sO)), eM = L32(4 * (tabM + sM));
+                        const uint32_t xL = eL >> 22, xO = eO >> 22, xM = eM >> 22;
+                        const uint32_t nbL = (eL >> 10) & 15, nbO = (eO >> 10) & 15, nbM = (eM >> 10) & 15;
+                        const bool lastq = i + 1 == nseq;
+                        const uint32_t tot_x = xL + xM + xO, tot_s = lastq ? 0u : nbL + nbM + nbO, tot = tot_x + tot_s;
+                        const int32_t hn = h - (int32_t)tot;
+                        const uint64_t Wn = window(hn); // the next sequence's window: in flight from here on
+                        uint32_t vO, vM, vL, bL, bM, bO;
+                        if (__builtin_expect(tot <= avail, 1)) { // from the read head down: OF, ML, LL extra bits; LL, ML, OF state bits
+                            const uint64_t Y = tot ? cur >> (64 - tot) : 0ull;
+                            const uint32_t y = (uint32_t)Y;
+                            bO = y & ((1u << nbO) - 1);
+                            bM = (y >> nbO) & ((1u << nbM) - 1);
+                            bL = (y >> (nbO + nbM)) & ((1u << nbL) - 1);
+                            const uint64_t Y2 = Y >> tot_s; // (tot_s <= 26)
+                            vL = (uint32_t)Y2 & ((1u << xL) - 1);
+                            vM = (uint32_t)(Y2 >> xL) & ((1u << xM) - 1);
+                            vO = (uint32_t)((Y2 >> (xL + xM)) & ((1ull << xO) - 1));
+                        } else { // more than a window's worth of extra bits (about one sequence in hundreds): three looks
+                            vO = xO ? (uint32_t)(cur >> (64 - xO)) : 0u;
+                            const int32_t h2 = h - (int32_t)xO;
+                            const int32_t b2 = (h2 - 1) >> 3;
+                            uint64_t c2 = window(h2) << ((uint32_t)(8 * ((b2 < -1 ? -1 : b2) + 1) - h2) & 63);
+                            vM = xM ? (uint32_t)(c2 >> (64 - xM)) : 0u; c2 <<= xM;
+                            vL = xL ? (uint32_t)(c2 >> (64 - xL)) : 0u;
+                            const int32_t h3 = h2 - (int32_t)(xM + xL);
+                            const int32_t b3 = (h3 - 1) >> 3;
+                            uint64_t c3 = window(h3) << ((uint32_t)(8 * ((b3 < -1 ? -1 : b3) + 1) - h3) & 63);
+                            bL = nbL ? (uint32_t)(c3 >> (64 - nbL)) : 0u; c3 <<= nbL;
+                            bM = nbM ? (uint32_t)(c3 >> (64 - nbM)) : 0u; c3 <<= nbM;
+                            bO = nbO ? (uint32_t)(c3 >> (64 - nbO)) : 0u;
+                        }
+                        bad |= hn < 0;
+                        const uint32_t ofv = (1u << ((eO >> 14) & 0xFF)) + vO;
+                        const uint32_t ml = (L32(kOffMLCode + 4 * ((eM >> 14) & 0xFF)) & 0xFFFFFF) + vM;
+                        const uint32_t ll = (L32(kOffLLCode + 4 * ((eL >> 14) & 0xFF)) & 0xFFFFFF) + vL;
+                        sL = lastq ? sL : (eL & 0x3FF) + bL; sM = lastq ? sM : (eM & 0x3FF) + bM; sO = lastq ? sO : (eO & 0x3FF) + bO;
+                        // ---- repeat offsets (A.5), as selects
+                        const bool is_rep = ofv <= 3;
+                        const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u); // meaningful when is_rep
+                        const uint32_t pick = idx == 0 ? rep0 : (idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - 1));
+                        const uint32_t off = is_rep ? pick : ofv - 3;
+                        bad |= off == 0; // (only "rep0 - 1" can be zero)
+                        const bool keep = is_rep & (idx == 0), swap1 = is_rep & (idx == 1);
+                        const uint32_t n2 = (keep | swap1) ? rep2 : rep1, n1 = keep ? rep1 : rep0, n0 = keep ? rep0 : off;
+                        rep2 = n2; rep1 = n1; rep0 = n0;
+                        h = hn; W = Wn;
+                        // (a sequence that cannot fit the capacity, and whatever a failed walk decodes, is stopped by the step's
+                        //  validation: lengths are clamped so that the sums there cannot wrap)
+                        q.ll[k] = ll > 0xFFFFFF ? 0xFFFFFFu : ll; q.ml[k] = ml > 0xFFFFFF ? 0xFFFFFFu : ml; q.off[k] = off;
+                    }
+                }
+            };
             const uint8_t* lit = lit_type == 0 ? src + lit_off : lit_base + (size_t)lane * a.lit_stride;
             const uint8_t* const dlim = dst + cap;
             const uint32_t dict_len = with_d ? di.content_len : 0u;
             const uint8_t* const dict_end = with_d ? di.content + di.content_len : nullptr;
             uint32_t lpos = 0, opos = 0;
-            do {
-                if (nseq) {
-                    BackBits rd;
-                    if (!rd.init(src + bs_off, bs_len)) break;
-                    rd.refill();
-                    if (rd.h < (int32_t)(alL + alO + alM)) break;
-                    uint32_t sL = rd.read(alL), sO = rd.read(alO), sM = rd.read(alM);
-                    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
-                    if (with_d && di.formatted) { rep0 = di.rep[0]; rep1 = di.rep[1]; rep2 = di.rep[2]; }
-                    bool sbad = false;
-                    for (uint32_t i = 0; i < nseq; i++) {
-                        rd.refill();
-                        const uint32_t eL = L32(4 * (tabL + sL)), eO = L32(4 * (tabO + sO)), eM = L32(4 * (tabM + sM));
-                        const uint32_t xL = eL >> 22, xO = eO >> 22, xM = eM >> 22;
-                        const uint32_t nbL = (eL >> 10) & 15, nbO = (eO >> 10) & 15, nbM = (eM >> 10) & 15;
-                        const bool lastq = i + 1 == nseq;
-                        const uint32_t tot_s = lastq ? 0u : nbL + nbM + nbO, tot = xL + xM + xO + tot_s;
-                        uint32_t vO, vM, vL, bL = 0, bM = 0, bO = 0;
-                        if ((int32_t)tot <= rd.avail) { // one window holds the whole sequence (from the read head down: OF, ML, LL extra bits; LL, ML, OF state bits)
-                            const uint64_t Y = tot ? rd.cur >> (64 - tot) : 0ull;
-                            if (!lastq) {
-                                const uint32_t y = (uint32_t)Y;
-                                bO = y & ((1u << nbO) - 1);
-                                bM = (y >> nbO) & ((1u << nbM) - 1);
-                                bL = (y >> (nbO + nbM)) & ((1u << nbL) - 1);
-                            }
-                            const uint64_t Y2 = Y >> tot_s;
-                            vL = (uint32_t)Y2 & ((1u << xL) - 1);
-                            vM = (uint32_t)(Y2 >> xL) & ((1u << xM) - 1);
-                            vO = (uint32_t)((Y2 >> (xL + xM)) & ((1ull << xO) - 1));
-                            rd.skip(tot);
-                        } else { // long extra-bit fields: field by field
-                            vO = rd.read(xO); vM = rd.read(xM); vL = rd.read(xL);
-                            if (!lastq) { bL = rd.read(nbL); bM = rd.read(nbM); bO = rd.read(nbO); }
-                        }
-                        if (rd.h < 0) { sbad = true; break; }
-                        const uint32_t cO = (eO >> 14) & 0xFF;
-                        const uint32_t ofv = (1u << cO) + vO;
-                        const uint32_t ml = (L32(kOffMLCode + 4 * ((eM >> 14) & 0xFF)) & 0xFFFFFF) + vM;
-                        const uint32_t ll = (L32(kOffLLCode + 4 * ((eL >> 14) & 0xFF)) & 0xFFFFFF) + vL;
-                        if (!lastq) { sL = (eL & 0x3FF) + bL; sM = (eM & 0x3FF) + bM; sO = (eO & 0x3FF) + bO; }
-                        // ---- repeat offsets (A.5)
-                        uint32_t off;
-                        if (ofv > 3) { off = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                        else {
-                            const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
-                            if (idx == 0) off = rep0;
-                            else if (idx == 1) { off = rep1; rep1 = rep0; rep0 = off; }
-                            else if (idx == 2) { off = rep2; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                            else { off = rep0 - 1; if (off == 0) { sbad = true; break; } rep2 = rep1; rep1 = rep0; rep0 = off; }
-                        }
-                        // ---- execute
-                        if (ll > nlit - lpos || (uint64_t)ll + ml > cap - opos) { sbad = true; break; }
-                        copy_lane(dst + opos, lit + lpos, ll, dlim);
-                        opos += ll; lpos += ll;
-                        if (off > opos + dict_len) { sbad = true; break; }
-                        uint8_t* d = dst + opos;
-                        uint32_t m = ml;
-                        if (off > opos) { // starts in the dictionary content (logically just before the frame)
-                            const uint32_t back = off - opos;
+            bool sbad = false;
+            Seq4 cur4, nxt4;
+            walk4(0, cur4);
+#ifdef MZD_SMALL_STAMPS
+            uint64_t tq = 0, tw = 0, ts = 0, t0_ = 0, t1_ = 0;
+#define GSTAMP(acc) do { t1_ = __builtin_readcyclecounter(); acc += t1_ - t0_; t0_ = t1_; } while (0)
+            t0_ = __builtin_readcyclecounter();
+#else
+#define GSTAMP(acc)
+#endif
+            for (uint32_t i = 0; i < nseq; i += 4) {
+                uint32_t ll[4], ml[4], off[4], lp[4], op[4];
+                uint32_t lp_run = lpos, op_run = opos;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    off[k] = cur4.off[k]; ll[k] = cur4.ll[k]; ml[k] = cur4.ml[k];
+                    lp[k] = lp_run; op[k] = op_run;
+                    lp_run += ll[k]; op_run += ll[k] + ml[k];
+                }
+                // validation in stream order: literals left, room in the destination, offset within the history (A.5)
+                bool vbad = bad;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    vbad |= (lp[k] + ll[k] > nlit) | (op[k] + ll[k] + ml[k] > cap) | (off[k] > op[k] + ll[k] + dict_len);
+                if (vbad) { sbad = true; break; }
+                const bool roomy = op_run + 64 <= cap; // whole-width stores spill up to 47 bytes past a piece
+                V16 Lw[4][3] = {}, Mw[4][2] = {};
+                bool lin[4], pre[4];
+                // ---- (1) requests (every address is readable whatever the sequence is: no branch around the first piece)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    lin[k] = roomy & (ll[k] <= 48) & (ll[k] != 0);
+                    Lw[k][0] = gv16(lit + lp[k]); // (literal buffers and inputs are readable 16 bytes past their end)
+                    // (a memory instruction costs the wavefront ~100+ cycles of L1-miss traffic whatever its lanes do: the pieces that
+                    //  few sequences need sit behind a branch -- ~5 % of the literal runs are longer than 16 bytes, ~15 % of the matches)
+                    if (lin[k] & (ll[k] > 16)) { Lw[k][1] = gv16(lit + lp[k] + 16); Lw[k][2] = gv16(lit + lp[k] + (ll[k] > 32 ? 32u : 16u)); }
+                    const uint32_t mpos = op[k] + ll[k]; // output position of the match
+                    const bool in_dict = off[k] > mpos;
+                    const bool whole_dict = in_dict & (off[k] - mpos >= ml[k]);
+                    const bool old = !in_dict & (off[k] >= (mpos - opos) + ml[k]); // the source ends before this step's output begins
+                    pre[k] = roomy & (ml[k] <= 32) & (old | whole_dict) & (ml[k] != 0);
+                    const uint8_t* mp = whole_dict ? dict_end - (off[k] - mpos) : dst + mpos - off[k];
+                    mp = pre[k] ? mp : lit; // (anything readable)
+                    Mw[k][0] = gv16(mp); // (dictionary buffers are padded; output reads end below the step's start + 32 <= cap)
+                    if (pre[k] & (ml[k] > 16)) Mw[k][1] = gv16(mp + 16);
+                }
+                GSTAMP(tq);
+                // ---- (2) the next step's sequences, in the shadow of the requests
+                walk4(i + 4, nxt4);
+                GSTAMP(tw);
+                // ---- (3) stores, in order
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint8_t* d = dst + op[k];
+                    if (lin[k]) { gsv16(d, Lw[k][0]); if (ll[k] > 16) { gsv16(d + 16, Lw[k][1]); gsv16(d + 32, Lw[k][2]); } } // (16 or 48 bytes: a run of 17..32 rewrites [32, 48) with what the pieces behind it bring)
+                    else if (ll[k]) copy_lane(d, lit + lp[k], ll[k], dlim);
+                    d += ll[k];
+                    if (pre[k]) { gsv16(d, Mw[k][0]); if (ml[k] > 16) gsv16(d + 16, Mw[k][1]); }
+                    else if (ml[k]) {
+                        uint32_t m = ml[k];
+                        const uint32_t mpos = op[k] + ll[k];
+                        if (off[k] > mpos) { // starts in the dictionary content (logically just before the frame)
+                            const uint32_t back = off[k] - mpos;
                             const uint32_t n1 = m < back ? m : back;
-                            const uint8_t* dp = dict_end - back;
-                            if (d + n1 + 8 <= dlim) for (uint32_t k = 0; k < n1; k += 8) gs64(d + k, gu64(dp + k));
-                            else for (uint32_t k = 0; k < n1; k++) gs8(d + k, gu8(dp + k));
+                            copy_lane(d, dict_end - back, n1, dlim);
                             d += n1; m -= n1;
                         }
-                        if (m) match_lane(d, off, m, dlim);
-                        opos += ml;
+                        if (m) match_lane(d, off[k], m, dlim);
                     }
-                    if (sbad || rd.h != 0) break; // the bitstream must be consumed exactly
                 }
+                lpos = lp_run; opos = op_run;
+                cur4 = nxt4;
+                GSTAMP(ts);
+            }
+#ifdef MZD_SMALL_STAMPS
+            if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[9] = tq; a.stamps[10] = tw; a.stamps[11] = ts; }
+#endif
+            bad |= sbad | (nseq != 0 && h != 0); // the bitstream must be consumed exactly
+            bool good = !bad;
+            if (good) {
                 const uint32_t rest = nlit - lpos;
-                if (rest > cap - opos) break;
-                copy_lane(dst + opos, lit + lpos, rest, dlim);
-                opos += rest;
-                if (has_fcs && opos != fcs) break;
-                out_len = opos;
-                good = true;
-            } while (false);
+                good = rest <= cap - opos;
+                if (good) {
+                    copy_lane(dst + opos, lit + lpos, rest, dlim);
+                    opos += rest;
+                    good = !(has_fcs && opos != fcs);
+                    out_len = opos;
+                }
+            }
             if (!good) { ok = false; live = false; }
+        };
+        {
+            const bool all_staged = __ballot(live && nseq != 0 && bs_lds == 0) == 0; // (wave-uniform)
+            if (live) { if (all_staged) walk_execute(std::true_type{}); else walk_execute(std::false_type{}); }
         }
+        SSTAMP(6);
         if (lane < G) {
             FileLds& F = fl<G>((uint32_t)lane);
             F.out_len = out_len;
             F.live = (ok && has_ck && n != 0) ? 1u : 0u; // to be hashed
         }
         wave_sync();
+        SSTAMP(7);
 
         // =============================== phase H: XXH64 (lane = (file, accumulator))
         {
@@ -881,22 +1139,21 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
             if (ok) { a.jobs[job].out_len = out_len; a.jobs[job].status = MZD_OK; }
             else { const uint32_t k = atomicAdd(&a.counter[4], 1u); a.redo_list[k] = job; }
         }
+        SSTAMP(8);
+        first_group = false;
         wave_sync(); // the LDS slots are rewritten by the next group
     }
 }
 
-void launch_small(const SmallArgs& a, uint32_t grid, int g, void* stream) {
-    if (g == 64) {
-        const uint32_t bytes = Lay<64>::kDict + (a.with_dict ? kDictBytes : 0u);
-        hipLaunchKernelGGL(mzd_small_kernel<64>, dim3(grid), dim3(64), bytes, (hipStream_t)stream, a);
-    } else {
-        const uint32_t bytes = Lay<16>::kDict + (a.with_dict ? kDictBytes : 0u);
-        hipLaunchKernelGGL(mzd_small_kernel<16>, dim3(grid), dim3(64), bytes, (hipStream_t)stream, a);
-    }
+uint32_t small_lds_bytes(int g, int with_dict) {
+    return (g == 64 ? Lay<64>::kDict + 64 * Lay<64>::kSeqStageB : Lay<16>::kDict) + (with_dict ? kDictBytes : 0u);
 }
 
-uint32_t small_lds_bytes(int g, int with_dict) {
-    return (g == 64 ? Lay<64>::kDict : Lay<16>::kDict) + (with_dict ? kDictBytes : 0u);
+void launch_small(const SmallArgs& a, uint32_t grid, int g, uint32_t lds_at_least, void* stream) {
+    uint32_t bytes = small_lds_bytes(g, a.with_dict != 0);
+    if (bytes < lds_at_least) bytes = lds_at_least; // (mzd_host.cpp: fewer workgroups per CU, spread over all of them)
+    if (g == 64) hipLaunchKernelGGL(mzd_small_kernel<64>, dim3(grid), dim3(64), bytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(mzd_small_kernel<16>, dim3(grid), dim3(64), bytes, (hipStream_t)stream, a);
 }
 
 } // namespace mzd

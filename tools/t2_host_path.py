@@ -1,23 +1,32 @@
-"""Diagnostic (T2 of SURVEY.md 8d): wall time of mzd_decode_batch on HOST buffers (pinned staging -> H2D -> kernel -> D2H),
-i.e. the PCIe-inclusive rate of the cfg2 corpus.  Not the bench's headline value."""
-import ctypes as C, os, sys, time
+"""Diagnostic (T2 of SURVEY.md 8d): wall time of mzd_decode_batch on HOST buffers (the chunked pipeline of mzd_host.cpp:
+copy in | decode | copy out on separate streams), i.e. the PCIe-inclusive rate of a corpus.  Not the bench's headline value.
+  python tools/t2_host_path.py [workload] [files] [pinned|pageable]"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import corpus, fuse_zstd_amd as mzd
+import bench, corpus, fuse_zstd_amd as mzd
 from fuse_zstd_amd import api
 mzd.init()
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-cp = corpus.build_corpus("json", 2, [131072] * n)
-out = np.zeros(int(cp.raw_offs[-1] + cp.raw_sizes[-1]) + 64, dtype=np.uint8)
-jobs = api.make_jobs([cp.comp.ctypes.data + int(o) for o in cp.comp_offs], cp.comp_sizes,
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else bench.DEFAULT_FILES[wl]
+pinned = (sys.argv[3] if len(sys.argv) > 3 else "pinned") == "pinned"
+kind, cfg, km, _ = bench.WORKLOADS[wl]
+cp = corpus.build_corpus(kind, cfg, bench.file_sizes(wl, n, 0, 1), kind_mod=km)
+end = int(cp.raw_offs[-1] + cp.raw_sizes[-1])
+if pinned:
+    hin = mzd.HostBuffer(len(cp.comp)); hin.a[:] = cp.comp; src = hin.a
+    hout = mzd.HostBuffer(end + 64); out = hout.a
+else:
+    src = cp.comp; out = np.zeros(end + 64, dtype=np.uint8)
+jobs = api.make_jobs([src.ctypes.data + int(o) for o in cp.comp_offs], cp.comp_sizes,
                      [out.ctypes.data + int(o) for o in cp.raw_offs], cp.raw_sizes)
 L = api.lib()
 for rep in range(6):
+    out[:end] = 0
     t0 = time.perf_counter()
     rc = L.mzd_decode_batch(jobs, n)
     dt = time.perf_counter() - t0
     assert rc == 0 and all(j.status == 0 for j in jobs)
-    end = int(cp.raw_offs[-1] + cp.raw_sizes[-1])
     ok = bool((out[:end] == cp.raw[:end]).all())
-    print("pass %d: %.3f ms wall, %.2f GiB/s decompressed (host -> host), kernel %.3f ms, bytes ok %s" % (
-        rep, dt * 1e3, cp.raw_sizes.sum() / dt / 2**30, mzd.last_kernel_ms(0), ok), flush=True)
+    print("pass %d: %.3f ms wall, %.2f GiB/s decompressed (host -> host, %s), kernels %.3f ms summed over chunks, bytes ok %s" % (
+        rep, dt * 1e3, cp.raw_sizes.sum() / dt / 2**30, "pinned" if pinned else "pageable", mzd.last_kernel_ms(0), ok), flush=True)
