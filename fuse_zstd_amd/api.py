@@ -19,7 +19,7 @@ EXPORTS = [
     "mzd_decode_batch_device", "mzd_batch_prepare", "mzd_batch_launch", "mzd_batch_collect", "mzd_batch_free",
     "mzd_load_dict", "mzd_unload_dict", "mzd_debug_last_block", "mzd_debug_set_driver", "mzd_debug_counters", "mzd_debug_stamps", "mzd_debug_tfin_all",
     "mzd_host_alloc", "mzd_host_free", "mzd_last_kernel_ms", "mzd_strerror", "mzd_version",
-    "mzd_fs_new", "mzd_fs_free", "mzd_fs_open", "mzd_fs_read", "mzd_fs_release", "mzd_fs_decode_count",
+    "mzd_fs_new", "mzd_fs_free", "mzd_fs_open", "mzd_fs_open_lazy", "mzd_fs_read", "mzd_fs_release", "mzd_fs_decode_count", "mzd_fs_decoded_bytes",
 ]
 
 
@@ -103,6 +103,10 @@ def lib():
         L.mzd_fs_free.restype = None
         L.mzd_fs_open.restype = C.c_int64
         L.mzd_fs_open.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]
+        L.mzd_fs_open_lazy.restype = C.c_int64
+        L.mzd_fs_open_lazy.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]
+        L.mzd_fs_decoded_bytes.restype = C.c_uint64
+        L.mzd_fs_decoded_bytes.argtypes = [C.c_void_p]
         L.mzd_fs_read.restype = C.c_int64
         L.mzd_fs_read.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_uint32, C.c_void_p]
         L.mzd_fs_release.argtypes = [C.c_void_p, C.c_uint64]
@@ -311,11 +315,13 @@ class ZstdFS:
     def __init__(self):
         self._h = lib().mzd_fs_new()
 
-    def open(self, ino, flags, zst_bytes):
-        """-> (fh, real_size).  real_size is what open_wrapper stores in user.real_size (BE u64)."""
+    def open(self, ino, flags, zst_bytes, lazy=False):
+        """-> (fh, real_size).  real_size is what open_wrapper stores in user.real_size (BE u64).
+        lazy: nothing is decoded until a read needs it (mzd_fs_open_lazy)."""
         zst_bytes = bytes(zst_bytes)
         rs = C.c_uint64(0)
-        fh = lib().mzd_fs_open(self._h, ino, flags, zst_bytes, len(zst_bytes), C.byref(rs))
+        fn = lib().mzd_fs_open_lazy if lazy else lib().mzd_fs_open
+        fh = fn(self._h, ino, flags, zst_bytes, len(zst_bytes), C.byref(rs))
         if fh < 0:
             raise OSError(-fh, os.strerror(-fh))
         return fh, rs.value
@@ -335,6 +341,10 @@ class ZstdFS:
     @property
     def decode_count(self):
         return lib().mzd_fs_decode_count(self._h)
+
+    @property
+    def decoded_bytes(self):
+        return lib().mzd_fs_decoded_bytes(self._h)
 
     def close(self):
         if self._h:

@@ -1012,8 +1012,21 @@ const char* mzd_version(void) { return "mzd 0.2 (gfx950)"; }
 // ---------------------------------------------------------------------------------------
 // Host mirror of OpenedFiles (reference src/file.rs) + open/read/release wrappers.
 // ---------------------------------------------------------------------------------------
+// Lazy / seekable files: what the host's header walk finds in a file whose frames all carry a content size
+struct LazyBlock { size_t hdr; uint32_t type, size; bool last; };   // a block header at input offset `hdr`
+struct LazyFrame {
+    size_t in_off, in_len;        // the frame's bytes in the file
+    size_t hdr_len;               // its header
+    uint64_t out_off, out_len;    // where its content lies in the decoded file
+    uint32_t window_log;          // a Window_Descriptor exponent that covers the frame's window (prefix decodes)
+    std::vector<LazyBlock> blocks;
+    uint64_t valid = 0;           // decoded bytes of this frame present in `bytes` (a prefix)
+};
 struct DecodedFile { // plays the role of the anonymous tempfile (reference src/main.rs:462)
     std::vector<uint8_t> bytes;
+    bool lazy = false;
+    std::vector<uint8_t> zst;     // lazy: the compressed file (kept: reads decode from it)
+    std::vector<LazyFrame> frames;
 };
 
 struct FileHandler { // reference src/file.rs:20-28
@@ -1028,6 +1041,7 @@ struct mzd_fs {
     std::map<uint64_t, std::set<uint64_t>> inode_map; // mount_point_inode_mapping, src/file.rs:12
     std::map<uint64_t, FileHandler> handlers;         // src/file.rs:13
     uint64_t decodes = 0;
+    uint64_t decoded_bytes = 0;   // bytes the GPU produced for this table so far
     std::mutex mu;
 
     bool new_fh(uint64_t* out) { // smallest free handle number, src/file.rs:38-45
@@ -1067,7 +1081,7 @@ int64_t mzd_fs_open(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t* zst,
         size_t out_len = 0;
         int rc = mzd_decode(zst, zst_len, file->bytes.data(), cap, &out_len);
         fs->decodes++;
-        if (rc == MZD_OK) { file->bytes.resize(out_len); break; }
+        if (rc == MZD_OK) { file->bytes.resize(out_len); fs->decoded_bytes += out_len; break; }
         if (rc == MZD_E_DSTSIZE && want == MZD_CONTENTSIZE_UNKNOWN && attempt < 7) { cap *= 4; continue; }
         return -EFAULT;
     }
@@ -1079,15 +1093,154 @@ int64_t mzd_fs_open(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t* zst,
     return (int64_t)fh;
 }
 
+// ---- N4: lazy open.  Nothing is decoded at open; the host walks frame and block headers (no entropy decoding) and every
+// read decodes what it needs: the frames that cover the range -- frames are independent -- and, inside a frame, the blocks up
+// to the range's end (a block needs its predecessors' window, tables and repeat offsets, so a frame is decoded from its
+// start: as a shorter frame made of its first blocks).  What has been decoded stays (reference read_wrapper only ever
+// slices: src/main.rs:495-513).  Files with a frame that carries no content size are decoded eagerly, as by mzd_fs_open.
+static bool lazy_index(const uint8_t* src, size_t n, std::vector<LazyFrame>& frames, uint64_t* total) {
+    size_t pos = 0;
+    uint64_t out = 0;
+    while (pos < n) {
+        if (n - pos < 4) return false;
+        const uint32_t magic = rd32(src + pos);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+            if (n - pos < 8) return false;
+            const uint64_t sz = rd32(src + pos + 4);
+            if (n - pos - 8 < sz) return false;
+            pos += 8 + (size_t)sz;
+            continue;
+        }
+        if (magic != 0xFD2FB528u || n - pos < 5) return false;
+        const uint32_t fhd = src[pos + 4];
+        const uint32_t fcsf = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+        if ((fhd & 8) || did) return false; // (dictionary frames: decoded eagerly, with the caller's dictionary)
+        const size_t fcs_sz = fcsf == 0 ? single : (1u << fcsf);
+        const size_t hs = 5 + (single ? 0 : 1) + fcs_sz;
+        if (n - pos < hs || fcs_sz == 0) return false; // no content size: not seekable
+        const uint8_t* q = src + pos + hs - fcs_sz;
+        uint64_t fcs = fcsf == 0 ? *q : (fcsf == 1 ? (uint64_t)rd16(q) + 256 : (fcsf == 2 ? rd32(q) : rd64(q)));
+        uint64_t window = fcs;
+        if (!single) { const uint32_t b = src[pos + 5]; const uint32_t wl = 10 + (b >> 3); window = (1ull << wl) + ((1ull << wl) >> 3) * (b & 7); }
+        if (window > (1ull << 27)) return false;
+        LazyFrame f;
+        f.in_off = pos; f.hdr_len = hs; f.out_off = out; f.out_len = fcs;
+        f.window_log = 10;
+        while ((1ull << f.window_log) < window) f.window_log++;
+        size_t p = pos + hs;
+        for (;;) {
+            if (n - p < 3) return false;
+            const uint32_t bh = rd16(src + p) | ((uint32_t)src[p + 2] << 16);
+            LazyBlock b{p, (bh >> 1) & 3, bh >> 3, (bh & 1) != 0};
+            if (b.type == 3) return false;
+            const size_t adv = b.type == 1 ? 1 : b.size;
+            if (n - p - 3 < adv) return false;
+            f.blocks.push_back(b);
+            p += 3 + adv;
+            if (b.last) break;
+        }
+        if (fhd & 4) { if (n - p < 4) return false; p += 4; }
+        f.in_len = p - pos;
+        out += fcs;
+        pos = p;
+        frames.push_back(std::move(f));
+    }
+    *total = out;
+    return true;
+}
+
+int64_t mzd_fs_open_lazy(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t* zst, size_t zst_len, uint64_t* real_size) {
+    if (!fs) return -EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(fs->mu);
+        auto it = fs->inode_map.find(ino);
+        if (it != fs->inode_map.end() && !it->second.empty()) { // another handle of the inode: share its file (src/file.rs:67-102)
+            const FileHandler& h = fs->handlers.at(*it->second.begin());
+            uint64_t fh;
+            fs->new_fh(&fh);
+            fs->handlers[fh] = FileHandler{flags, false, h.file, true, ino};
+            it->second.insert(fh);
+            if (real_size) *real_size = h.file->bytes.size();
+            return (int64_t)fh;
+        }
+    }
+    auto file = std::make_shared<DecodedFile>();
+    uint64_t total = 0;
+    if (!lazy_index(zst, zst_len, file->frames, &total) || total > (1ull << 40)) return mzd_fs_open(fs, ino, flags, zst, zst_len, real_size);
+    if (mzd_device_count() == 0) return -EFAULT; // (no GPU: the first read could not decode either; fail at open like the eager path)
+    file->lazy = true;
+    file->zst.assign(zst, zst + zst_len);
+    file->bytes.resize((size_t)total); // (untouched pages cost nothing until a read decodes into them)
+    std::lock_guard<std::mutex> lk(fs->mu);
+    uint64_t fh;
+    if (!fs->new_fh(&fh)) return -EBUSY;
+    fs->handlers[fh] = FileHandler{flags, false, file, true, ino};
+    fs->inode_map[ino].insert(fh);
+    if (real_size) *real_size = total; // every frame states its content size: this is what user.real_size gets (src/main.rs:473-482)
+    return (int64_t)fh;
+}
+
+// decode what [lo, hi) of a lazy file needs; false: the file is corrupt (the reference would have failed at open with EFAULT)
+static bool lazy_fill(mzd_fs* fs, DecodedFile& f, uint64_t lo, uint64_t hi) {
+    struct Want { LazyFrame* fr; uint64_t upto; size_t nblocks; std::vector<uint8_t> synth; };
+    for (int round = 0; round < 40; round++) {
+        std::vector<Want> want;
+        for (auto& fr : f.frames) {
+            if (fr.out_off + fr.out_len <= lo || fr.out_off >= hi) continue;
+            const uint64_t need = std::min<uint64_t>(hi, fr.out_off + fr.out_len) - fr.out_off; // bytes of the frame wanted, from its start
+            if (fr.valid >= need) continue;
+            // blocks to decode: a block regenerates at most 128 KiB; if that guess falls short the next round takes more
+            size_t nb = std::min<size_t>(fr.blocks.size(), (size_t)((need + kBlockMax - 1) / kBlockMax) + (size_t)round * (1u + (size_t)round));
+            if (nb == 0) nb = 1;
+            if (round >= 6) nb = fr.blocks.size(); // (a frame of many tiny blocks: stop guessing)
+            want.push_back(Want{&fr, need, nb, {}});
+        }
+        if (want.empty()) return true;
+        std::vector<mzd_job> jobs(want.size());
+        for (size_t k = 0; k < want.size(); k++) {
+            Want& w = want[k];
+            LazyFrame& fr = *w.fr;
+            mzd_job& j = jobs[k];
+            memset(&j, 0, sizeof(j));
+            j.dst = f.bytes.data() + fr.out_off;
+            if (w.nblocks >= fr.blocks.size()) { // the whole frame, as it is (content size and checksum verified)
+                j.src = f.zst.data() + fr.in_off; j.src_len = fr.in_len; j.dst_cap = (size_t)fr.out_len;
+            } else { // its first blocks as a frame of their own: a header without content size / checksum, the last kept block marked last
+                const LazyBlock& lb = fr.blocks[w.nblocks - 1];
+                const size_t body_end = lb.hdr + 3 + (lb.type == 1 ? 1 : lb.size);
+                w.synth.reserve(6 + (body_end - (fr.in_off + fr.hdr_len)) + MZD_SRC_PADDING);
+                const uint8_t head[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x00, (uint8_t)((fr.window_log - 10) << 3)};
+                w.synth.assign(head, head + 6);
+                w.synth.insert(w.synth.end(), f.zst.begin() + (ptrdiff_t)(fr.in_off + fr.hdr_len), f.zst.begin() + (ptrdiff_t)body_end);
+                w.synth[6 + (lb.hdr - (fr.in_off + fr.hdr_len))] |= 1; // Last_Block
+                j.src = w.synth.data(); j.src_len = w.synth.size();
+                j.dst_cap = (size_t)std::min<uint64_t>(fr.out_len, (uint64_t)w.nblocks * kBlockMax);
+            }
+        }
+        if (mzd_decode_batch(jobs.data(), jobs.size()) != MZD_OK) return false;
+        fs->decodes += jobs.size();
+        for (size_t k = 0; k < want.size(); k++) {
+            if (jobs[k].status != MZD_OK) return false;
+            LazyFrame& fr = *want[k].fr;
+            fs->decoded_bytes += jobs[k].out_len;
+            fr.valid = std::max<uint64_t>(fr.valid, jobs[k].out_len);
+            if (want[k].nblocks >= fr.blocks.size() && jobs[k].out_len != fr.out_len) return false;
+        }
+    }
+    return false;
+}
+
 int64_t mzd_fs_read(mzd_fs* fs, uint64_t fh, int64_t offset, uint32_t size, uint8_t* out) {
     if (!fs) return -EINVAL;
     std::lock_guard<std::mutex> lk(fs->mu);
     auto it = fs->handlers.find(fh);
     if (it == fs->handlers.end()) return -ENOENT; // src/main.rs:505
-    const std::vector<uint8_t>& b = it->second.file->bytes;
+    DecodedFile& f = *it->second.file;
+    const std::vector<uint8_t>& b = f.bytes;
     if (offset < 0) return -EINVAL;
     if ((uint64_t)offset >= b.size()) return 0; // read_at past EOF -> 0 bytes, then truncate (src/main.rs:506-511)
     size_t nread = std::min<size_t>(size, b.size() - (size_t)offset);
+    if (f.lazy && nread && !lazy_fill(fs, f, (uint64_t)offset, (uint64_t)offset + nread)) return -EFAULT; // (what the reference reports at open)
     if (nread && out) memcpy(out, b.data() + offset, nread);
     return (int64_t)nread;
 }
@@ -1106,5 +1259,6 @@ int mzd_fs_release(mzd_fs* fs, uint64_t fh) {
 }
 
 uint64_t mzd_fs_decode_count(const mzd_fs* fs) { return fs ? fs->decodes : 0; }
+uint64_t mzd_fs_decoded_bytes(const mzd_fs* fs) { return fs ? fs->decoded_bytes : 0; }
 
 } // extern "C"

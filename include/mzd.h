@@ -157,12 +157,20 @@ void mzd_fs_free(mzd_fs* fs);
  * else decode `zst` (the bytes of <data_dir>/name.zst) on the GPU and insert (:47-65).
  * *real_size receives what goes into the user.real_size xattr (:473-482). */
 int64_t mzd_fs_open(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t* zst, size_t zst_len, uint64_t* real_size);
+/* open without decoding (SURVEY.md 8f "lazy / seekable read"): the host walks frame and block headers; each read then decodes
+ * only the frames that cover its range and, inside a frame, the blocks up to the range's end (kept for later reads).  Same
+ * return values as mzd_fs_open; *real_size is the sum of the frames' content sizes.  A file with a frame that states no
+ * content size is decoded eagerly (mzd_fs_open).  A corrupt file shows as -EFAULT at the first read that touches the damage
+ * (the reference finds it at open: src/main.rs:467). */
+int64_t mzd_fs_open_lazy(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t* zst, size_t zst_len, uint64_t* real_size);
 /* read: bytes [offset, offset+size) of the decoded file, short at EOF (:506-511). */
 int64_t mzd_fs_read(mzd_fs* fs, uint64_t fh, int64_t offset, uint32_t size, uint8_t* out);
 /* release: drops the handle; the decoded bytes go when the last handle of the inode goes. */
 int mzd_fs_release(mzd_fs* fs, uint64_t fh);
 /* number of GPU decodes performed so far (second opens of an inode must not add one). */
 uint64_t mzd_fs_decode_count(const mzd_fs* fs);
+/* bytes the GPU has produced for this table so far (a lazy file read in part decodes less than its size). */
+uint64_t mzd_fs_decoded_bytes(const mzd_fs* fs);
 
 #ifdef __cplusplus
 }

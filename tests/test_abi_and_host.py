@@ -81,6 +81,8 @@ def test_no_gpu_fails_loudly_never_falls_back(lib):
     fs = mzd.ZstdFS()
     with pytest.raises(OSError):  # open() maps every decode failure to EFAULT (reference src/main.rs:467)
         fs.open(1, 0, good.comp)
+    with pytest.raises(OSError):  # the lazy open has nothing to decode yet, but promises reads it could never serve
+        fs.open(2, 0, good.comp, lazy=True)
     fs.close()
 
 

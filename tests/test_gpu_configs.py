@@ -240,3 +240,69 @@ def test_multi_gpu_product_path_round_robin():
     finally:
         mzd.shutdown()
         mzd.init()
+
+
+@needs_zstd
+def test_lazy_open_decodes_only_what_reads_need():
+    """mzd_fs_open_lazy decodes nothing; a read decodes the frames that cover its range and, inside a
+    multi-block frame, only the blocks up to the range's end.  Bytes equal the oracle's; the decoded-bytes counter stays
+    below the file size until everything has been read."""
+    Z = oracle.LibZstd
+    rng = np.random.RandomState(4)
+    parts, raws = [], []
+    for k in range(12):  # a file of 12 frames (20..400 KB each: single- and multi-block) with skippable frames in between
+        size = int(rng.randint(20000, 400000))
+        raw = corpus.gen(["json", "text", "markup"][k % 3], 90 + k, 1, size)
+        raws.append(raw)
+        parts.append(Z.compress(raw, 3, True))
+        if k % 4 == 1:
+            parts.append((0x184D2A50 + k).to_bytes(4, "little") + (5).to_bytes(4, "little") + b"skip!")
+    comp = b"".join(parts)
+    whole = b"".join(raws)
+    rc, ref = oracle.decode(comp, cap=len(whole))
+    assert rc == 0 and ref == whole
+    fs = mzd.ZstdFS()
+    fh, size = fs.open(7, 0, comp, lazy=True)
+    assert size == len(whole) and fs.decoded_bytes == 0 and fs.decode_count == 0
+    for _ in range(12):  # random 4 KiB reads
+        off = int(rng.randint(0, len(whole) - 4096))
+        assert fs.read(fh, off, 4096) == whole[off:off + 4096]
+    assert 0 < fs.decoded_bytes < len(whole), (fs.decoded_bytes, len(whole))
+    before = fs.decoded_bytes
+    assert fs.read(fh, 0, 100) == whole[:100]  # the first frame's first block at most
+    assert fs.decoded_bytes - before <= 131072
+    fh2, size2 = fs.open(7, 0, comp, lazy=True)  # a second handle shares the file and what has been decoded
+    assert size2 == size
+    got = b"".join(fs.read(fh2, o, 131072) for o in range(0, len(whole) + 131072, 131072))
+    assert got == whole
+    assert fs.read(fh, len(whole) - 10, 4096) == whole[-10:]  # short read at EOF
+    fs.release(fh); fs.release(fh2)
+    # one big frame (24 blocks): reading its start decodes a block, reading its end everything
+    raw = corpus.gen("json", 5, 2, 3 << 20)
+    comp1 = Z.compress(raw, 3, True)
+    fh, size = fs.open(8, 0, comp1, lazy=True)
+    d0 = fs.decoded_bytes
+    assert fs.read(fh, 1000, 5000) == raw[1000:6000]
+    assert fs.decoded_bytes - d0 <= 2 * 131072
+    assert fs.read(fh, 1 << 20, 70000) == raw[1 << 20:(1 << 20) + 70000]
+    assert fs.decoded_bytes - d0 < 2 * ((1 << 20) + 70000 + 131072) + 131072
+    assert fs.read(fh, size - 3, 10) == raw[-3:]
+    fs.release(fh)
+    # a frame without a content size: decoded eagerly at open, like mzd_fs_open
+    nofcs = next(v for v in VECS if v.name == "nofcs_stream_300k")
+    d1 = fs.decoded_bytes
+    fh, size = fs.open(9, 0, nofcs.comp, lazy=True)
+    assert size == nofcs.out_len and fs.decoded_bytes - d1 == nofcs.out_len
+    assert fs.read(fh, 5, 50) == nofcs.expected()[5:55]
+    fs.release(fh)
+    # damage in the last frame: open succeeds (headers are intact), the read that needs the frame reports EFAULT
+    bad = bytearray(comp)
+    bad[len(comp) - 40] ^= 0x55
+    fh, size = fs.open(10, 0, bytes(bad), lazy=True)
+    assert fs.read(fh, 0, 64) == whole[:64]
+    import errno
+    with pytest.raises(OSError) as e:
+        fs.read(fh, len(whole) - 5000, 4096)
+    assert e.value.errno == errno.EFAULT
+    fs.release(fh)
+    fs.close()
