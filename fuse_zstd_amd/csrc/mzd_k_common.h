@@ -1,0 +1,149 @@
+// mzd_k_common.h -- part of the block pipeline of mzd_kernels.hip (see the map at the top of that file).  Included there, inside
+// namespace mzd, in dependency order; not a translation unit of its own.
+#pragma once
+// ------------------------------------------------------------------------------------ LDS
+constexpr int kRingBytes = 8192; // sequence-bitstream ring: 8 chunks of 1 KiB (+16 mirrored bytes)
+constexpr int kChunk = 1024;
+constexpr int kRingChunks = kRingBytes / kChunk;
+
+struct Ctl {
+    uint64_t pos;        // next unread input byte of the file
+    uint64_t out;        // bytes produced for this file
+    uint64_t frame_out0; // `out` at the start of the current frame
+    uint64_t fcs;
+    uint64_t lit_off;    // file offset of the raw literals / first Huffman stream
+    uint64_t seq_off;    // file offset of the sequence bitstream
+    int32_t err;
+    uint32_t action;     // 0 frame, 1 skip, 2 done
+    uint32_t job;
+    uint32_t has_fcs, has_cksum, block_max;
+    uint32_t btype, bsize, last;
+    uint32_t lit_type, nlit, streams, huf_log, huf_valid, huf_nw;
+    uint32_t s_off[4], s_len[4], s_out[4], s_n[4];
+    uint32_t lit_is_raw;
+    uint32_t huf_tree_off, huf_tree_len;           // Huffman tree description inside the block
+    uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
+    uint32_t next_stream, streams_done, streams_mask; // Huffman streams are handed out to whichever wavefront is free; mask: bit k = stream k decoded
+    uint32_t tables_ready, plan_prog, copy_prog, plan_lit_used; // walker -> planner -> copier
+    uint32_t plan_too_long; // 1: the plan ends with a chunk that cannot be executed (literals run out / output passes 128 KiB); 2: only the literals after
+                            // the last sequence pass 128 KiB.  No error yet: the copier, which reports in stream order, gives the verdict
+    uint32_t seq_parsed;                           // the sequence header is parsed: nseq, seq_off, seq_len, modes are final
+    uint32_t exec_done;                            // the copying wavefront has finished the block
+    uint64_t exec_pos;                             // output bytes complete and visible (published by the executor)
+    uint32_t diag_slow;                            // diagnostic build: walker iterations that needed a lower window
+    uint32_t nseq, mode[3], al[3], nsym[3], fse_valid, seq_len;
+    uint32_t rep[3];
+    uint32_t rep_op[4];                             // the block's repeat-offset transform (start slots -> end slots): s, v0, v1, v2
+    uint32_t dict_content_len;
+    const uint8_t* dict_content;
+    // the task (one block of one file) and what its predecessor published
+    uint32_t lds_dict_fse, lds_dict_huf;            // driver 1: dictionary (handle) whose FSE / Huffman tables sit unmodified in LDS, or 0
+    uint32_t t_valid, task, in_frame, with_dict;
+    uint32_t pred_ready;                            // the predecessor's state is in pred_* (LDS flag of the block pipeline)
+    int32_t pred_err;
+    uint32_t pred_rep[3];
+    uint32_t tables_published;
+    uint64_t pred_out, pred_frame_out0, pred_xstripes, pred_xxh[4];
+};
+
+struct __attribute__((aligned(16))) Shared {
+    uint8_t ring[kRingBytes + 16]; // first: at LDS offset 0 the walker's window address needs no base add
+    // FSE decode entries, 8 bytes: low dword = byte offset of the next state's entry before the
+    // fresh bits are added (8 * nextStateBase); high dword = nbBits | (extra+nbBits) << 8 | symbol << 16 | extra << 24
+    uint64_t ll[512];
+    uint64_t ml[512];
+    uint64_t of[256];
+    uint8_t stage[3 * (2048 + 16)]; // K5 staging: the run being assembled and the two before it (kStage each)
+    uint8_t hseg2[2048 + 64];       // Huffman stream segment of wavefront 2 (it still decodes while the copier already uses `stage`)
+    uint32_t ll_base[36], ml_base[53]; // code -> base value (copied once from constant memory)
+#ifdef MZD_STAMPS
+    uint64_t cdiag[8];
+#endif
+#if defined(MZD_STAMPS) || defined(MZD_TFIN)
+    uint64_t ttask, tstart, tfin[12]; // block start; finish of walker / copier / hasher / planner; literals ready; tables ready
+#endif
+    uint16_t huf[2048]; // sym | len << 8
+    int16_t norm[3][64];
+    uint16_t next[3][64];
+    alignas(16) int16_t wnorm[256]; // FSE table of the Huffman weights.  wnorm + wtab + weights (1 KiB, contiguous) double as the
+                                    // copier's literal scratch (kLitScratch): the copying wavefront is the one that decodes the weights, earlier
+    uint32_t wtab[64];  // sym | nb << 8 | base << 16
+    uint8_t weights[256];
+    Ctl c;
+    // driver 1, files of one block: while the copier and the hasher finish file A, the idle walking wavefront takes the
+    // next file and parses its headers into `c2` (header bytes staged in a free part of the ring)
+    Ctl c2;
+    uint32_t pre_job, pre_valid; // the job taken ahead (kNoJob: none) and whether c2 holds its parsed first block
+    // driver 1: the small fields of the dictionary the workgroup used last (config 5: every file names the same one --
+    // reading them from HBM again for each file costs a round trip per dependent load)
+    struct { uint32_t id, formatted, al[3], huf_log, rep[3], content_len; const uint8_t* content; } dcache;
+    struct { const uint8_t* src; uint64_t n; uint8_t* dst; uint64_t cap; uint32_t dict; } pj; // the job table entry of pre_job (read once, by pre_parse_next)
+};
+
+// The workgroup's LDS image.  File scope, so that every device function addresses it with DS
+// instructions and immediate offsets (a `Shared&` parameter would be a flat pointer).
+__shared__ Shared S;
+
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t ld24(const uint8_t* p) { return ld16(p) | ((uint32_t)p[2] << 16); }
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return ld16(p) | (ld16(p + 2) << 16); }
+__device__ __forceinline__ uint64_t ld64(const uint8_t* p) { return (uint64_t)ld32(p) | ((uint64_t)ld32(p + 4) << 32); }
+__device__ __forceinline__ uint32_t ldu32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint64_t ldu64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ int hibit(uint32_t v) { return 31 - __builtin_clz(v); }
+
+__device__ __forceinline__ void wg_fence() {
+    // make this wave's global stores visible to later loads of the same workgroup (same CU, same L1)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// bits [bitpos, bitpos+n) of the little-endian integer p[0..nbytes); indices < 0 and >= 8*nbytes
+// read as 0.  n <= 32.  Lane-0 parsing helper (the input is readable MZD_SRC_PADDING past its end).
+__device__ __noinline__ uint32_t bits_at(const uint8_t* p, uint32_t nbytes, int32_t bitpos, int n) {
+    if (n == 0) return 0;
+    if (bitpos < 0) {
+        int neg = -bitpos;
+        if (neg >= n) return 0;
+        return bits_at(p, nbytes, 0, n - neg) << neg;
+    }
+    uint32_t byte = (uint32_t)bitpos >> 3;
+    if (byte >= nbytes) return 0;
+    uint64_t v = ldu64(p + byte);
+    uint32_t avail = nbytes - byte;
+    if (avail < 8) v &= (1ull << (avail * 8)) - 1;
+    v >>= (bitpos & 7);
+    return (uint32_t)(v & ((1ull << n) - 1));
+}
+
+// Intra-workgroup flags in LDS (the block pipeline): relaxed atomics + workgroup fences.  Every spin
+// also ends when an error is posted, and is bounded.
+__device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void flag_store(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+// first error wins: a wavefront that merely gave up because another one failed must not overwrite the cause
+__device__ __forceinline__ void post_err(int32_t* err, int rc) {
+    if (rc) { int32_t expected = 0; __atomic_compare_exchange_n(err, &expected, rc, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); }
+}
+// (a wait that runs out is a failure of the launch -- a co-tenant starved the workgroup, a role died -- not of the input:
+//  it posts MZD_E_DEVICE, and whatever the waiting role reports afterwards loses to it)
+__device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want, int32_t* err) {
+    for (uint32_t it = 0; it < (1u << 24); it++) {
+        if (flag_load(p) >= want) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
+        if (__atomic_load_n(err, __ATOMIC_RELAXED)) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    post_err(err, MZD_E_DEVICE);
+    return false;
+}
+
+
+// wave-wide inclusive scans on the DPP path (row_shr / row_bcast: no LDS traffic, no ds_bpermute latency)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+    (void)lane;
+    using WS = rocprim::warp_scan<uint32_t, 64>;
+    WS::storage_type* st = nullptr; // the DPP implementation keeps no state in LDS
+    uint32_t r;
+    WS().inclusive_scan(v, r, *st, rocprim::plus<uint32_t>());
+    return r;
+}
+

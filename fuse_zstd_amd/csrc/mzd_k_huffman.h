@@ -1,0 +1,134 @@
+// mzd_k_huffman.h -- part of the block pipeline of mzd_kernels.hip (see the map at the top of that file).  Included there, inside
+// namespace mzd, in dependency order; not a translation unit of its own.
+#pragma once
+// ------------------------------------------------------------------------------------ K2
+// One Huffman stream decoded by the 64 lanes of a wavefront (A.4), ~2 KiB of stream at a time:
+//   * the segment is staged in LDS with coalesced 16-byte loads (`seg`, 2 KiB + 64 bytes, private to the wavefront);
+//   * lane k starts at bit k*C of the segment (a guess for k > 0); lanes then re-start from their
+//     predecessor's exit position until the chain is consistent.  Text-like codes self-synchronise within a
+//     few symbols, so that takes a round or two.  Near-flat codes (noisy samples, already-compressed bytes)
+//     do not: there the truth travels one lane per round -- but a lane can only ever be entered at one of
+//     L bit offsets (a code word straddles its lower boundary by < L bits), so every lane keeps the
+//     results of the offsets it has already walked (12 bits each) and a round normally costs a shuffle and a
+//     lookup, not a walk;
+//   * a DPP scan of the symbol counts gives the output offsets, and a last pass writes.
+// A walk reads the stream through a 64-bit window loaded once per five symbols (5 * 11 bits <= 57).
+constexpr int32_t kSegBits = 64 * 248; // 31 bytes per lane: lane windows fall into different LDS banks
+
+#ifndef MZD_HUF_MINC
+#define MZD_HUF_MINC 16
+#endif
+__device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int lane) {
+    if (sl == 0) return MZD_E_CORRUPT;
+    uint32_t last = sp[sl - 1];
+    if (last == 0) return MZD_E_CORRUPT;
+    const int32_t nbits = (int32_t)((sl - 1) * 8 + (uint32_t)hibit(last));
+    const uint32_t mask = (1u << L) - 1;
+    const uint16_t* const tab = S.huf;
+    int32_t pos = 0;        // bits consumed so far (wave-uniform, exact)
+    uint32_t done = 0;      // symbols written so far
+    while (pos < nbits) {
+        const int32_t s0 = pos, s1 = pos + kSegBits < nbits ? pos + kSegBits : nbits;
+        // stage stream bytes [blo - 16, bhi): everything the segment can touch (16 bits of slack below it) behind a
+        // 16-byte prefix, so that a window may start up to 8 bytes below the lowest byte needed; bytes below the
+        // stream start read as zero (bits below bit 0 of a backward stream are zero)
+        const int32_t lowbit = nbits - s1 - 16;
+        const uint32_t blo = lowbit > 0 ? ((uint32_t)lowbit >> 3) & ~15u : 0u;
+        const uint32_t bhi = (uint32_t)((nbits - s0) + 7) >> 3; // <= sl
+        for (uint32_t o = (uint32_t)lane * 16; o < bhi - blo + 16; o += 1024) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (blo + o >= 16) __builtin_memcpy(&v, sp + (blo + o - 16), 16); // may over-read <= 15 bytes past the stream (input padding)
+            *reinterpret_cast<uint4*>(seg + o) = v;
+        }
+        const int32_t seg_bias = 16 - (int32_t)blo; // stream byte j lives at seg[j + seg_bias] (the index is formed first: a pointer below `seg` would be out of bounds)
+        int32_t C = (s1 - s0 + 63) / 64;
+        if (C < MZD_HUF_MINC) C = MZD_HUF_MINC;
+        int32_t q0 = s0 + lane * C, q1 = q0 + C;
+        if (q0 > s1) q0 = s1;
+        if (q1 > s1) q1 = s1;
+        if (lane == 63) q1 = s1;
+        const int32_t lim = nbits - q1;
+        // decode from stream position `from` until the lane's upper boundary; returns the exit position
+        auto walk = [&](int32_t from, uint32_t& cnt, uint8_t* dst) -> int32_t {
+            int32_t rem = nbits - from; // bits below the read point
+            uint32_t c = 0;
+            uint64_t acc = 0; // the write pass packs 8 symbols per HBM store (byte stores cost a sector write each)
+            while (rem > lim) {
+                const int32_t bi = (rem - 57) >> 3; // window = stream bytes [bi, bi + 8): the 57..64 bits below the read point
+                uint64_t W;
+                __builtin_memcpy(&W, seg + (uint32_t)(bi + seg_bias), 8);
+                int32_t h = rem - bi * 8;           // read point inside the window
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const bool act = rem > lim;
+                    const uint32_t e = tab[(uint32_t)(W >> (uint32_t)(h - (int32_t)L)) & mask];
+                    uint32_t l = e >> 8;
+                    l = l ? l : 1u;
+                    if (dst && act) {
+                        acc |= (uint64_t)(e & 0xFF) << ((c & 7) * 8);
+                        if ((c & 7) == 7) { __builtin_memcpy(dst + (c & ~7u), &acc, 8); acc = 0; }
+                    }
+                    l = act ? l : 0u;
+                    c += act ? 1u : 0u;
+                    h -= (int32_t)l;
+                    rem -= (int32_t)l;
+                }
+            }
+            if (dst) for (uint32_t k = c & ~7u; k < c; k++) { dst[k] = (uint8_t)acc; acc >>= 8; }
+            cnt = c;
+            return nbits - rem;
+        };
+        // results of the entry offsets already walked: 12 bits per offset j = start - q0 (0..10):
+        // (exit - q1 + 1) | count << 4; 0 = not walked yet
+        uint64_t m0 = 0, m1 = 0; uint32_t m2 = 0;
+        auto memo_get = [&](uint32_t j) -> uint32_t {
+            const uint64_t w = j < 5 ? m0 : (j < 10 ? m1 : (uint64_t)m2);
+            const uint32_t sh = 12 * (j < 5 ? j : (j < 10 ? j - 5 : 0u));
+            return j <= 10 ? (uint32_t)(w >> sh) & 0xFFFu : 0u;
+        };
+        auto memo_put = [&](uint32_t j, uint32_t e) {
+            if (j < 5) m0 |= (uint64_t)e << (12 * j);
+            else if (j < 10) m1 |= (uint64_t)e << (12 * (j - 5));
+            else if (j == 10) m2 = e;
+        };
+        int32_t start = q0;
+        uint32_t cnt = 0;
+        int32_t exitp = walk(start, cnt, nullptr);
+        if (cnt < 256 && (uint32_t)(exitp - q1) < 15) memo_put(0, (uint32_t)(exitp - q1 + 1) | (cnt << 4));
+        for (int round = 0; round < 64; round++) {
+            int32_t pe = __shfl_up(exitp, 1);
+            int32_t ns = lane == 0 ? s0 : pe;
+            bool changed = ns != start;
+            if (!__any(changed)) break;
+            bool need = false;
+            uint32_t j = 0;
+            if (changed) {
+                start = ns;
+                j = (uint32_t)(start - q0); // < L for a lane that is entered from below; anything else is simply walked
+                const uint32_t e = memo_get(j);
+                if (e) { exitp = q1 + (int32_t)(e & 15) - 1; cnt = e >> 4; }
+                else need = true;
+            }
+            if (__any(need)) {
+                if (need) {
+                    exitp = walk(start, cnt, nullptr);
+                    if (cnt < 256 && (uint32_t)(exitp - q1) < 15) memo_put(j, (uint32_t)(exitp - q1 + 1) | (cnt << 4));
+                }
+#ifdef MZD_STAMPS
+                if (lane == 0) atomicAdd(&S.c.diag_slow, 1u); // diagnostic: synchronisation rounds that had to walk
+#endif
+            }
+        }
+        const uint32_t incl = wave_incl_scan(cnt, lane);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        const int32_t endp = __builtin_amdgcn_readlane(exitp, 63);
+        if (done + total > nsym || endp > nbits) return MZD_E_CORRUPT; // never write past this stream's share of the literals
+        uint32_t dummy;
+        walk(start, dummy, out + done + (incl - cnt));
+        done += total;
+        pos = endp;
+    }
+    if (done != nsym) return MZD_E_CORRUPT; // pos == nbits here: the stream was consumed exactly
+    return 0;
+}
+
