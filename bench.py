@@ -290,11 +290,13 @@ def t2_end_to_end(w, mzd, reps=5):
     dids = [w.dict_id] * n if w.dict_id else None
     out = {}
 
-    def run(jobs):
+    def run(jobs, check=True):
         t0 = time.perf_counter()
         rc = L.mzd_decode_batch(jobs, n)
         dt = time.perf_counter() - t0
-        assert rc == 0 and all(j.status == 0 for j in jobs), "T2 decode failed"
+        assert rc == 0, "T2 decode failed"
+        if check:  # (outside the timed region; the threaded leg checks once at its end: this loop holds the interpreter lock)
+            assert all(j.status == 0 for j in jobs), "T2 decode failed"
         return dt
 
     def bench(src_arr, dst_arr, label):
@@ -323,7 +325,7 @@ def t2_end_to_end(w, mzd, reps=5):
 
         def worker(jobs):
             for _ in range(rounds):
-                run(jobs)
+                run(jobs, check=False)
         ths = [threading.Thread(target=worker, args=(j,)) for j in (jobs_a, jobs_b)]
         t0 = time.perf_counter()
         for t in ths:
@@ -331,7 +333,7 @@ def t2_end_to_end(w, mzd, reps=5):
         for t in ths:
             t.join()
         dt = time.perf_counter() - t0
-        ok = bool((pin_out2.a[:w.end] == cp.raw[:w.end]).all())
+        ok = all(j.status == 0 for j in jobs_a) and all(j.status == 0 for j in jobs_b) and bool((pin_out2.a[:w.end] == cp.raw[:w.end]).all())
         out["pinned_two_calls_in_flight"] = {"ms_per_batch": round(dt / (2 * rounds) * 1e3, 3), "value": round(2 * rounds * w.U / dt / GIB, 2), "unit": "GiB/s", "byte_exact": ok}
     finally:
         pin_in.free(); pin_out.free(); pin_out2.free()

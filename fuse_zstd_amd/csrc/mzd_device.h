@@ -20,6 +20,8 @@ struct DevJob {
     uint64_t out_len;
     int32_t status;
     uint32_t dict;
+    uint8_t* dst2;   // optional mirror of the output in the caller's pinned HOST memory, written by the kernel as the file is
+                     // decoded (the host path: the copy back over PCIe overlaps the decode instead of following it); null: none
 };
 
 // A parsed dictionary resident in HBM (A.7): tables are stored exactly as the kernel keeps

@@ -44,6 +44,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr int kSlots = 4;                       // launches of the host path that may be in flight on one device
 constexpr size_t kSmallLitBytes = 512u << 20;   // literal scratch of the small-file kernel: every resident file's literals (shared by the slots)
 constexpr uint32_t kMaxDicts = 64;
+constexpr size_t kMaxChunks = 16;               // ... and at most this many chunks per call
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
 std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic
@@ -330,8 +331,8 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     return MZD_OK;
 }
 
-void fill_devjob(DevJob& j, const void* src, size_t src_len, void* dst, size_t cap, uint32_t dict, const Device& d) {
-    j.src = (const uint8_t*)src; j.src_len = src_len; j.dst = (uint8_t*)dst; j.dst_cap = cap;
+void fill_devjob(DevJob& j, const void* src, size_t src_len, void* dst, size_t cap, uint32_t dict, const Device& d, void* dst2 = nullptr) {
+    j.src = (const uint8_t*)src; j.src_len = src_len; j.dst = (uint8_t*)dst; j.dst_cap = cap; j.dst2 = (uint8_t*)dst2;
     j.out_len = 0; j.status = MZD_E_DEVICE;
     j.dict = (dict >= 1 && dict <= kMaxDicts && d.dict_used[dict - 1]) ? dict : (dict ? 0xFFFFFFFFu : 0u); // an unloaded handle: MZD_E_DICT
 }
@@ -395,6 +396,19 @@ void parallel_memcpy(uint8_t* d, const uint8_t* s, size_t n) {
     parallel_for(np, n, [=](size_t k) { const size_t o = k * piece; memcpy(d + o, s + o, std::min(piece, n - o)); });
 }
 
+// what mzd_host_alloc handed out: [base, base + size), looked up per job (hipPointerGetAttributes costs microseconds)
+std::mutex g_pin_mu;
+std::map<uintptr_t, size_t> g_pinned;
+bool in_pinned_registry(const void* p, size_t len) {
+    if (len == 0) return true;
+    if (!p) return false;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = g_pinned.upper_bound((uintptr_t)p);
+    if (it == g_pinned.begin()) return false;
+    --it;
+    return (uintptr_t)p + len <= it->first + it->second;
+}
+
 bool is_pinned_host(const void* p) {
     hipPointerAttribute_t at;
     memset(&at, 0, sizeof(at));
@@ -456,13 +470,19 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
     struct Give { Device& d; Staging* s; ~Give() { give_staging(d, s); } } give{d, st};
     const Layout Lin = make_layout(jobs, idx, true, MZD_SRC_PADDING), Lout = make_layout(jobs, idx, false, 16);
     // straight from / into the caller's memory?  Only when it is pinned and the runs are few (a copy call costs microseconds)
-    auto direct_ok = [&](const Layout& L) {
-        if (L.run_dev.size() > std::max<size_t>(8, n / 64)) return false;
+    const auto few_runs = [&](const Layout& L) { return L.run_dev.size() <= std::max<size_t>(8, n / 64); };
+    auto pinned = [&](const Layout& L, bool input) {
+        bool reg = true; // every buffer inside an mzd_host_alloc allocation?
+        for (size_t k = 0; k < n && reg; k++) reg = input ? in_pinned_registry(jobs[idx[k]].src, jobs[idx[k]].src_len) : in_pinned_registry(jobs[idx[k]].dst, jobs[idx[k]].dst_cap);
+        if (reg) return true;
+        if (!few_runs(L)) return false; // memory pinned by other means: asked of the runtime, run by run
         for (size_t r = 0; r < L.run_dev.size(); r++)
             if (L.run_len[r] && !(L.run_host[r] && is_pinned_host(L.run_host[r]) && is_pinned_host(L.run_host[r] + L.run_len[r] - 1))) return false;
         return true;
     };
-    const bool in_direct = direct_ok(Lin), out_direct = direct_ok(Lout);
+    // inputs cross the link straight from the caller's memory when that is pinned and the runs are few (a copy call costs
+    // microseconds); outputs are written into pinned caller memory by the kernels themselves, wherever the buffers lie
+    const bool in_direct = few_runs(Lin) && pinned(Lin, true), out_direct = pinned(Lout, false);
     auto grow_dev = [&](uint8_t*& p, size_t& cap, size_t want) -> int {
         if (want <= cap) return MZD_OK;
         hipFree(p); p = nullptr; cap = 0;
@@ -488,12 +508,16 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
     if ((rc = ensure_staging_jobs(*st, n))) return rc;
     for (size_t k = 0; k < n; k++) {
         const mzd_job& j = jobs[idx[k]];
-        fill_devjob(st->h_jobs[k], st->d_in + Lin.off[k], j.src_len, st->d_out + Lout.off[k], j.dst_cap, j.dict_id, d);
+        // out_direct: the caller's buffers are pinned -- the kernels mirror every file into them while they decode (DevJob::dst2),
+        // so the way back over PCIe overlaps the decode instead of following it
+        fill_devjob(st->h_jobs[k], st->d_in + Lin.off[k], j.src_len, st->d_out + Lout.off[k], j.dst_cap, j.dict_id, d, out_direct ? j.dst : nullptr);
     }
     // chunks: at least kSlots when the batch is worth splitting, ~kChunkBytes each, cut at job boundaries
     size_t bytes_total = 0;
     for (size_t k = 0; k < n; k++) bytes_total += jobs[idx[k]].src_len + jobs[idx[k]].dst_cap;
-    size_t nchunks = bytes_total < (8u << 20) ? 1 : std::max<size_t>(kSlots, (bytes_total + kChunkBytes - 1) / kChunkBytes);
+    // (a chunk's launch lasts at least as long as its longest file's block chain: many small chunks of a big batch would add those up)
+    size_t nchunks = bytes_total < (8u << 20) ? 1 : std::max<size_t>(kSlots, std::min<size_t>(kMaxChunks, (bytes_total + kChunkBytes - 1) / kChunkBytes));
+    if (out_direct) nchunks = std::min<size_t>(nchunks, kSlots); // (nothing to copy back: chunks only let the first kernels start before the last inputs arrive)
     nchunks = std::min(nchunks, n);
     std::vector<size_t> cut{0};
     {
@@ -576,11 +600,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
             if (!out_direct) {
                 const size_t lo = Lout.off[c0], hi = Lout.off[c1 - 1] + jobs[idx[c1 - 1]].dst_cap;
                 if (hi > lo) e = hipMemcpyAsync(st->h_out + lo, st->d_out + lo, hi - lo, hipMemcpyDeviceToHost, d.copy_out);
-            } else {
-                for_run_pieces(Lout, c0, c1, false, [&](size_t dev_off, const uint8_t* host, size_t len) {
-                    if (len && e == hipSuccess) e = hipMemcpyAsync(const_cast<uint8_t*>(host), st->d_out + dev_off, len, hipMemcpyDeviceToHost, d.copy_out);
-                });
-            }
+            } // (else: the kernels have written the caller's buffers themselves)
         }
         if (e == hipSuccess && erc == MZD_OK) e = hipEventRecord(k.done, d.copy_out);
         if (e != hipSuccess || erc != MZD_OK) result = erc != MZD_OK ? erc : MZD_E_DEVICE;
@@ -695,9 +715,14 @@ int mzd_device_count(void) {
 void* mzd_host_alloc(size_t n) {
     void* p = nullptr;
     if (hipHostMalloc(&p, n ? n : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    { std::lock_guard<std::mutex> lk(g_pin_mu); g_pinned[(uintptr_t)p] = n ? n : 1; }
     return p;
 }
-void mzd_host_free(void* p) { if (p) hipHostFree(p); }
+void mzd_host_free(void* p) {
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(g_pin_mu); g_pinned.erase((uintptr_t)p); }
+    hipHostFree(p);
+}
 
 // Frame header walk (RFC 8878 3.1.1): no entropy decoding, so it stays on the host.
 uint64_t mzd_content_size(const uint8_t* src, size_t n) {

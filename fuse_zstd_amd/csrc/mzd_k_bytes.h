@@ -89,3 +89,18 @@ __device__ __noinline__ void wave_pattern(uint8_t* d, uint32_t off, uint32_t n, 
     }
 }
 
+
+// 64 lanes copy bytes [lo, hi) of a file's output to its mirror in the caller's pinned host memory (DevJob::dst2): 16 bytes
+// per lane and store, i.e. 1 KiB per instruction pair over PCIe (tools/micro/hostwrite_micro.hip: shader stores reach the
+// link's rate, 55 GB/s, from as few as 64 workgroups).  The bytes are final when this is called and only the host reads
+// the mirror, after the launch: no ordering beyond the end of the kernel is needed.
+__device__ __noinline__ void mirror_wave(const uint8_t* from, uint8_t* to, uint64_t lo, uint64_t hi, int lane) {
+    uint64_t o = lo + (uint64_t)lane * 16;
+    for (; o + 16 <= hi; o += 1024) {
+        uint4 v;
+        __builtin_memcpy(&v, from + o, 16);
+        __builtin_memcpy(to + o, &v, 16);
+    }
+    const uint64_t tail = lo + ((hi - lo) & ~15ull); // the last partial 16 bytes: a byte per lane
+    if (tail + (uint64_t)lane < hi) to[tail + lane] = from[tail + lane];
+}

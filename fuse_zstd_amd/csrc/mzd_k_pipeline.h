@@ -19,6 +19,7 @@
 struct BlockArgs {
     const uint8_t* src; uint64_t n;       // the file
     uint8_t* dst; uint64_t cap;
+    uint8_t* dst2;                        // mirror of the output in pinned host memory, or null
     const uint8_t* blk; uint32_t bsize;   // the block's content
     uint64_t pos0;                        // its offset in the file
     uint64_t out0;                        // TASKS = false: output position at the block's start
@@ -196,7 +197,7 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
 
 // ---- waves 1 and 2: K1 Huffman table (wave 1), K2 literal streams, then the copying half of K5 (wave 1) / K7 behind it (wave 2)
 template <bool TASKS>
-__device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, uint64_t& xv, uint64_t& xstripes) {
+__device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored) {
     Ctl& c = S.c;
     const BlockArgs& b = r.b;
     const KernelArgs& a = r.a;
@@ -287,7 +288,8 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
             }
         }
         TFIN(1);
-    } else if (b.hashing) { // wave 2, K7: hash behind the copier while it works
+    } else if (b.hashing || b.dst2) { // wave 2: K7 hash and / or the host mirror, behind the copier while it works
+        const bool hashing = b.hashing, mirror = b.dst2 != nullptr;
         bool run = true;
         uint64_t fstart = c.frame_out0;
         if (TASKS) { // state from the predecessor
@@ -299,6 +301,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
                     fstart = frame_first ? c.pred_out : c.pred_frame_out0;
                     xv = frame_first ? xxh_init(lane) : c.pred_xxh[lane & 3];
                     xstripes = frame_first ? 0 : c.pred_xstripes;
+                    mirrored = c.pred_out; // a task mirrors its own block
                 }
             }
         }
@@ -308,12 +311,18 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
                 const uint32_t fin = flag_load(&c.exec_done);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const uint64_t pos = (TASKS && fin) ? c.out : __atomic_load_n(&c.exec_pos, __ATOMIC_RELAXED);
-                uint64_t upto = pos > fstart ? (pos - fstart) / 32 : 0;
-                if (!fin) upto = upto >= xstripes + 64 ? xstripes + ((upto - xstripes) & ~7ull) : xstripes; // >= 2 KiB at a time, whole groups of 8 stripes
-                if (upto > xstripes) xxh_advance(xv, xstripes, upto, fp, lane);
-                else if (fin || __atomic_load_n(&c.err, __ATOMIC_RELAXED)) break;
-                else __builtin_amdgcn_s_sleep(8);
+                bool did = false;
+                if (hashing) {
+                    uint64_t upto = pos > fstart ? (pos - fstart) / 32 : 0;
+                    if (!fin) upto = upto >= xstripes + 64 ? xstripes + ((upto - xstripes) & ~7ull) : xstripes; // >= 2 KiB at a time, whole groups of 8 stripes
+                    if (upto > xstripes) { xxh_advance(xv, xstripes, upto, fp, lane); did = true; }
+                }
+                if (mirror && !(TASKS && fin)) { // (a task leaves the rest to its completion: its successor must not wait for PCIe)
+                    const uint64_t to = fin ? pos : (pos >= mirrored + 2048 ? mirrored + ((pos - mirrored) & ~1023ull) : mirrored); // >= 2 KiB at a time, whole KiB
+                    if (to > mirrored) { mirror_wave(dst, b.dst2, mirrored, to, lane); mirrored = to; did = true; }
+                }
                 if (fin) break;
+                if (!did) { if (__atomic_load_n(&c.err, __ATOMIC_RELAXED)) break; __builtin_amdgcn_s_sleep(8); }
             }
         }
         TFIN(2);
@@ -322,7 +331,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
 
 // One compressed block.  Returns false when its headers already failed (c.err is set): nothing was started.
 template <bool TASKS>
-__device__ __forceinline__ bool compressed_block(const KernelArgs& a, const BlockArgs& b, uint64_t& xv, uint64_t& xstripes, int tid, int lane, int wave) {
+__device__ __forceinline__ bool compressed_block(const KernelArgs& a, const BlockArgs& b, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored, int tid, int lane, int wave) {
     Ctl& c = S.c;
     int err = 0;
     // K0/K1/K3 headers: where everything is; nothing is decoded yet.  The two header regions (<= 256 bytes each: literals
@@ -359,6 +368,6 @@ __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const Bloc
                       TASKS ? b.dst : b.dst + b.out0};
     if (wave == 0) role_walk<TASKS>(r);
     else if (wave == 3) role_plan<TASKS>(r);
-    else role_literals_then_copy_or_hash<TASKS>(r, xv, xstripes);
+    else role_literals_then_copy_or_hash<TASKS>(r, xv, xstripes, mirrored);
     return true;
 }

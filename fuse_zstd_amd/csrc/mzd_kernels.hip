@@ -163,6 +163,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
         uint8_t* const dst = stashed ? S.pj.dst : a.jobs[j].dst;
         const uint64_t cap = stashed ? S.pj.cap : a.jobs[j].dst_cap;
         const uint32_t job_dict = stashed ? S.pj.dict : a.jobs[j].dict;
+        uint8_t* const dst2 = a.jobs[j].dst2; // (host mirror of the output, or null)
+        uint64_t mirrored = 0;                // bytes of the file already mirrored (wave 2's)
         if (pre) { // the prepared control block replaces the current one: by all threads, a dword each (what must survive was read above)
             static_assert(sizeof(Ctl) % 4 == 0, "copied by dwords");
             for (uint32_t k = (uint32_t)tid; k < sizeof(Ctl) / 4; k += kWG) reinterpret_cast<uint32_t*>(&c)[k] = reinterpret_cast<const uint32_t*>(&S.c2)[k];
@@ -244,8 +246,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                         if (tid == 0) { c.out = out0 + bsize; c.pos = pos0 + 1; }
                     }
                 } else {
-                    BlockArgs ba{src, n, dst, cap, src + pos0, bsize, pos0, out0, lit_buf, seqs, walk, last, hashing, block_pre, 0u, false, true, nullptr, nullptr, j};
-                    if (!compressed_block<false>(a, ba, xv, xstripes, tid, lane, wave)) break;
+                    BlockArgs ba{src, n, dst, cap, dst2, src + pos0, bsize, pos0, out0, lit_buf, seqs, walk, last, hashing, block_pre, 0u, false, true, nullptr, nullptr, j};
+                    if (!compressed_block<false>(a, ba, xv, xstripes, mirrored, tid, lane, wave)) break;
                 }
                 if (btype == 2) { // the block's repeat-offset transform (the planner leaves it symbolic) -> the offsets after it
                     __syncthreads();
@@ -286,6 +288,11 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
                 WG_SNAPSHOT(err = c.err);
                 if (err) break;
             }
+        }
+        if (dst2) { // what the mirror has not seen yet: raw / RLE blocks, the last bytes of the file
+            uint64_t out_final = 0;
+            WG_SNAPSHOT(err = c.err; out_final = c.out);
+            if (wave == 2 && !err && out_final > mirrored) mirror_wave(dst, dst2, mirrored, out_final, lane);
         }
         if (tid == 0) { a.jobs[j].out_len = c.out; a.jobs[j].status = c.err; }
         STAMP_FLUSH();
@@ -344,6 +351,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         uint8_t* const dst = a.jobs[j].dst;
         const uint64_t cap = a.jobs[j].dst_cap;
         const uint32_t job_dict = a.jobs[j].dict;
+        uint8_t* const dst2 = a.jobs[j].dst2; // (host mirror of the output, or null)
+        uint64_t mirrored = 0;                // wave 2: how far this task's block has been mirrored
+        bool have_mirrored = false;           // ... `mirrored` is valid (a compressed block whose copier ran)
         FileState* const fs = &a.fstate[j];
         TableArea* const ta = &a.tables[j];
         if (tid == 0) {
@@ -447,8 +457,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                 xxh_advance(xv, xstripes, (out_end - frame_start) / 32, dst + frame_start, lane);
             }
         } else if (have_block) {
-            BlockArgs ba{src, n, dst, cap, src + pos0, bsize, pos0, 0, lit_buf, seqs, walk, last, hashing, false, t, frame_first, is_final, fs, ta, j};
-            compressed_block<true>(a, ba, xv, xstripes, tid, lane, wave);
+            BlockArgs ba{src, n, dst, cap, dst2, src + pos0, bsize, pos0, 0, lit_buf, seqs, walk, last, hashing, false, t, frame_first, is_final, fs, ta, j};
+            compressed_block<true>(a, ba, xv, xstripes, mirrored, tid, lane, wave);
+            have_mirrored = true;
             WG_SNAPSHOT(err = c.err);
             STAMP(6);
             pred_loaded = c.pred_ready != 0;
@@ -463,6 +474,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         WG_SNAPSHOT(perr = c.pred_err; pred_out = c.pred_out; fstart = frame_first ? c.pred_out : c.pred_frame_out0; err = c.err; out_now = c.out; pos_now = c.pos; has_ck = c.has_cksum; last = c.last);
         if (!have_block) out_now = pred_out; // a task without a block (end of file, or a header error) produces nothing
         int final_err = perr ? perr : err;
+        const bool mirror_rest = dst2 && !final_err && out_now > pred_out; // this task's bytes the host mirror has not seen yet (all of a raw / RLE block)
+        const uint64_t mirror_from = (have_mirrored && mirrored >= pred_out && mirrored <= out_now) ? mirrored : pred_out;
         if (!final_err && have_block && last) { // frame trailer: content size and checksum
             if (tid == 0) {
                 if (c.has_fcs && out_now - fstart != c.fcs) c.err = MZD_E_CORRUPT;
@@ -532,6 +545,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
             a.jobs[j].status = final_err;
             atomicAdd(&a.counter[3], 1u);
         }
+        // the host mirror of this task's block: behind the hand-over -- the successor copies on, this wavefront feeds PCIe
+        if (mirror_rest && wave == 2 && out_now > mirror_from) mirror_wave(dst, dst2, mirror_from, out_now, lane);
         TTASK_END();
         STAMP_FLUSH();
         TFIN_FLUSH();

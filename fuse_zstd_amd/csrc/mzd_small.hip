@@ -69,7 +69,7 @@ constexpr uint32_t kSeqStage = 192;    // staged bytes of a sequences section he
 constexpr uint32_t kDictBytes = (512 + 512 + 256) * 4 + 2048 * 2;
 
 struct FileLds { // what lanes other than the file's own need to know
-    uint64_t src, dst;
+    uint64_t src, dst, dst2;
     uint32_t live, streams, huf_off, huf_log; // huf_off: byte offset of the Huffman table in LDS
     uint32_t hs_lds;                          // LDS byte offset of the staged Huffman streams, or 0
     uint32_t s_off[4], s_len[4];
@@ -338,10 +338,11 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
         uint32_t job = 0;
         const uint8_t* src = nullptr; uint8_t* dst = nullptr;
         uint32_t n = 0, cap = 0, jdict = 0;
+        uint8_t* dst2 = nullptr; // host mirror of the output, or null
         if (have) {
             job = a.small_list[fidx];
             const DevJob& dj = a.jobs[job];
-            src = dj.src; dst = dj.dst; n = (uint32_t)dj.src_len; cap = (uint32_t)dj.dst_cap; jdict = dj.dict;
+            src = dj.src; dst = dj.dst; n = (uint32_t)dj.src_len; cap = (uint32_t)dj.dst_cap; jdict = dj.dict; dst2 = dj.dst2;
         }
         // the group's dictionary: the first one named (the host sorts the list by dictionary)
         if (a.with_dict) {
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
         // publish what other lanes need
         if (lane < G) {
             FileLds& F = fl<G>((uint32_t)lane);
-            F.src = (uint64_t)(uintptr_t)src; F.dst = (uint64_t)(uintptr_t)dst; F.n = n;
+            F.src = (uint64_t)(uintptr_t)src; F.dst = (uint64_t)(uintptr_t)dst; F.dst2 = (uint64_t)(uintptr_t)dst2; F.n = n;
             F.live = (ok && !done) ? 1u : 0u;
             F.streams = (ok && !done && lit_type >= 2) ? streams : 0u;
             F.nlit = nlit;
@@ -1131,6 +1132,24 @@ __global__ __launch_bounds__(64) void mzd_small_kernel(SmallArgs a) {
                     hh = xxh_tail(hh, q, p + len);
                     if ((uint32_t)hh != gu32(src + n - 4)) ok = false;
                 }
+            }
+        }
+
+        // =============================== the host mirror (DevJob::dst2): the decoded files to the caller's pinned memory, all 64
+        // lanes per file, 16 bytes per lane (the bytes were written by other lanes of this wavefront: the sync above)
+        {
+            uint64_t m = __ballot(have && ok && dst2 != nullptr && out_len != 0);
+            if (m) wave_sync();
+            while (m) {
+                const int fl_ = __builtin_ctzll(m);
+                m &= m - 1;
+                const FileLds& F = fl<G>((uint32_t)fl_);
+                const uint8_t* from = (const uint8_t*)(uintptr_t)F.dst;
+                uint8_t* to = (uint8_t*)(uintptr_t)F.dst2;
+                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)out_len, fl_);
+                for (uint32_t o = (uint32_t)lane * 16; o + 16 <= len; o += 1024) gsv16(to + o, gv16(from + o));
+                const uint32_t tail = len & ~15u;
+                if (tail + (uint32_t)lane < len) gs8(to + tail + lane, gu8(from + tail + lane));
             }
         }
 
