@@ -397,6 +397,7 @@ void parallel_memcpy(uint8_t* d, const uint8_t* s, size_t n) {
 }
 
 // what mzd_host_alloc handed out: [base, base + size), looked up per job (hipPointerGetAttributes costs microseconds)
+std::atomic<int> g_direct_chunks{kSlots};
 std::mutex g_pin_mu;
 std::map<uintptr_t, size_t> g_pinned;
 bool in_pinned_registry(const void* p, size_t len) {
@@ -517,7 +518,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
     for (size_t k = 0; k < n; k++) bytes_total += jobs[idx[k]].src_len + jobs[idx[k]].dst_cap;
     // (a chunk's launch lasts at least as long as its longest file's block chain: many small chunks of a big batch would add those up)
     size_t nchunks = bytes_total < (8u << 20) ? 1 : std::max<size_t>(kSlots, std::min<size_t>(kMaxChunks, (bytes_total + kChunkBytes - 1) / kChunkBytes));
-    if (out_direct) nchunks = std::min<size_t>(nchunks, kSlots); // (nothing to copy back: chunks only let the first kernels start before the last inputs arrive)
+    if (out_direct) nchunks = std::min<size_t>(nchunks, (size_t)g_direct_chunks.load(std::memory_order_relaxed)); // (nothing to copy back: chunks only let the first kernels start before the last inputs arrive)
     nchunks = std::min(nchunks, n);
     std::vector<size_t> cut{0};
     {
@@ -543,11 +544,24 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         }
     };
     // Per chunk: its inputs on the copy-in stream, its kernels on a lane (round-robin), its outputs on the copy-out stream,
-    // tied together by events.  Everything is submitted without waiting; then the chunks are retired in order.
+    // tied together by events.
+    // Everything is submitted without waiting; then the chunks are retired in order.
     struct Chunk { int lane = -1; hipEvent_t in = nullptr, k0 = nullptr, k1 = nullptr, done = nullptr; };
     std::vector<Chunk> ch(nchunks);
     int result = MZD_OK;
     size_t submitted = 0;
+    // what each chunk's launch runs, and the whole job table (+ lists) in one copy ahead of the inputs
+    std::vector<Plan> plans(nchunks);
+    bool any_small = false;
+    for (size_t c = 0; c < nchunks; c++) {
+        plans[c] = make_plan(st->h_jobs + cut[c], cut[c + 1] - cut[c], st->h_lists + 2 * cut[c], d.lane[0].nwg);
+        any_small = any_small || plans[c].nsmall != 0;
+    }
+    {
+        hipError_t e = hipMemcpyAsync(st->d_jobs, st->h_jobs, n * sizeof(DevJob), hipMemcpyHostToDevice, d.copy_in);
+        if (e == hipSuccess && any_small) e = hipMemcpyAsync(st->d_lists, st->h_lists, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, d.copy_in);
+        if (e != hipSuccess) result = MZD_E_DEVICE;
+    }
     for (size_t c = 0; c < nchunks && result == MZD_OK; c++) {
         const size_t c0 = cut[c], c1 = cut[c + 1];
         Chunk& k = ch[c];
@@ -555,11 +569,18 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         if (e == hipSuccess) e = hipEventCreate(&k.k0);
         if (e == hipSuccess) e = hipEventCreate(&k.k1);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&k.done, hipEventDisableTiming);
+        if (e != hipSuccess) { result = MZD_E_DEVICE; break; }
+        const int ln = lane_begin(d, submitted != 0);
+        k.lane = ln;
+        submitted = c + 1;
+        Lane& l = d.lane[ln];
+        const Plan& p = plans[c];
+        int erc = MZD_OK;
         // inputs
-        if (e == hipSuccess && !in_direct) {
+        if (e == hipSuccess && erc == MZD_OK && !in_direct) {
             size_t bytes = 0;
             for (size_t q = c0; q < c1; q++) bytes += jobs[idx[q]].src_len;
-            if (Lin.run_dev.size() <= std::max<size_t>(8, n / 64)) { // few long runs: big copies split by bytes
+            if (few_runs(Lin)) { // few long runs: big copies split by bytes
                 for_run_pieces(Lin, c0, c1, true, [&](size_t dev_off, const uint8_t* host, size_t len) { if (len && host) parallel_memcpy(st->h_in + dev_off, host, len); });
             } else {
                 parallel_for(c1 - c0, bytes, [&](size_t r) {
@@ -569,24 +590,13 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
             }
             const size_t lo = Lin.off[c0], hi = Lin.off[c1 - 1] + jobs[idx[c1 - 1]].src_len;
             if (hi > lo) e = hipMemcpyAsync(st->d_in + lo, st->h_in + lo, hi - lo, hipMemcpyHostToDevice, d.copy_in);
-        } else if (e == hipSuccess) {
+        } else if (e == hipSuccess && erc == MZD_OK) {
             for_run_pieces(Lin, c0, c1, true, [&](size_t dev_off, const uint8_t* host, size_t len) {
                 if (len && e == hipSuccess) e = hipMemcpyAsync(st->d_in + dev_off, host, len, hipMemcpyHostToDevice, d.copy_in);
             });
         }
-        if (e != hipSuccess) { result = MZD_E_DEVICE; break; }
-        const int ln = lane_begin(d, submitted != 0);
-        k.lane = ln;
-        submitted = c + 1;
-        Lane& l = d.lane[ln];
-        // job table (+ lists) of the chunk behind its inputs
-        const Plan p = make_plan(st->h_jobs + c0, c1 - c0, st->h_lists + 2 * c0, l.nwg);
-        e = hipMemcpyAsync(st->d_jobs + c0, st->h_jobs + c0, (c1 - c0) * sizeof(DevJob), hipMemcpyHostToDevice, d.copy_in);
-        if (e == hipSuccess && p.nsmall) e = hipMemcpyAsync(st->d_lists + 2 * c0, st->h_lists + 2 * c0, (c1 - c0) * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, d.copy_in);
         if (e == hipSuccess) e = hipEventRecord(k.in, d.copy_in);
-        // the kernels
-        int erc = MZD_OK;
-        if (e == hipSuccess) {
+        if (e == hipSuccess) { // the kernels
             std::lock_guard<std::mutex> sub(l.submit_mu);
             if (c == 0) d.job0_counter = l.counter;
             e = hipStreamWaitEvent(l.stream, k.in, 0);
@@ -712,6 +722,12 @@ int mzd_device_count(void) {
 }
 
 // Pinned host memory every initialised device can copy from / into directly (no staging copy on the host path).
+// Diagnostic knob of the host path.  what 2: at most `value` chunks per call when the outputs are mirrored by the kernels.
+int mzd_debug_host_path(int device, int what, int value) {
+    (void)device;
+    if (what == 2) { g_direct_chunks.store(value < 1 ? 1 : value); return MZD_OK; }
+    return MZD_E_PARAM;
+}
 void* mzd_host_alloc(size_t n) {
     void* p = nullptr;
     if (hipHostMalloc(&p, n ? n : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }

@@ -95,12 +95,23 @@ __device__ __noinline__ void wave_pattern(uint8_t* d, uint32_t off, uint32_t n, 
 // link's rate, 55 GB/s, from as few as 64 workgroups).  The bytes are final when this is called and only the host reads
 // the mirror, after the launch: no ordering beyond the end of the kernel is needed.
 __device__ __noinline__ void mirror_wave(const uint8_t* from, uint8_t* to, uint64_t lo, uint64_t hi, int lane) {
-    uint64_t o = lo + (uint64_t)lane * 16;
-    for (; o + 16 <= hi; o += 1024) {
+    typedef __attribute__((address_space(1))) const uint8_t* GSrc;
+    typedef __attribute__((address_space(1))) uint8_t* GDst;
+    GSrc f = (GSrc)from; GDst t = (GDst)to;
+    uint64_t b = lo; // wave-uniform
+    for (; b + 4096 <= hi; b += 4096) { // 4 KiB in flight per wavefront: four loads, then four stores
+        const uint64_t o = b + (uint64_t)lane * 16;
+        uint4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, f + o, 16); __builtin_memcpy(&v1, f + o + 1024, 16);
+        __builtin_memcpy(&v2, f + o + 2048, 16); __builtin_memcpy(&v3, f + o + 3072, 16);
+        __builtin_memcpy(t + o, &v0, 16); __builtin_memcpy(t + o + 1024, &v1, 16);
+        __builtin_memcpy(t + o + 2048, &v2, 16); __builtin_memcpy(t + o + 3072, &v3, 16);
+    }
+    for (uint64_t o = b + (uint64_t)lane * 16; o + 16 <= hi; o += 1024) {
         uint4 v;
-        __builtin_memcpy(&v, from + o, 16);
-        __builtin_memcpy(to + o, &v, 16);
+        __builtin_memcpy(&v, f + o, 16);
+        __builtin_memcpy(t + o, &v, 16);
     }
     const uint64_t tail = lo + ((hi - lo) & ~15ull); // the last partial 16 bytes: a byte per lane
-    if (tail + (uint64_t)lane < hi) to[tail + lane] = from[tail + lane];
+    if (tail + (uint64_t)lane < hi) t[tail + lane] = f[tail + lane];
 }

@@ -11,6 +11,14 @@ template <int W> __global__ void copy_k(const uint8_t* __restrict__ src, uint8_t
         else { uint64_t v = *reinterpret_cast<const uint64_t*>(src + i); *reinterpret_cast<uint64_t*>(dst + i) = v; }
     }
 }
+// the mirror's pattern: wavefront w owns region w (region bytes), all wavefronts advance through their regions together,
+// `piece` bytes per visit (16 B per lane per store)
+__global__ void regions_k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t region, size_t piece) {
+    const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint8_t* s = src + w * region; uint8_t* d = dst + w * region;
+    for (size_t o = 0; o < region; o += piece)
+        for (size_t i = lane * 16; i < piece; i += 1024) { uint4 v = *reinterpret_cast<const uint4*>(s + o + i); *reinterpret_cast<uint4*>(d + o + i) = v; }
+}
 int main() {
     const size_t n = 128u << 20;
     uint8_t *d_src, *h_dst;
@@ -29,6 +37,16 @@ int main() {
             }
             printf("shader stores to host, %2d B per lane, %4d workgroups: %.3f ms = %.1f GB/s\n", w, grid, best, n / best / 1e6);
         }
+    }
+    for (size_t piece : {1024, 2048, 8192, 32768, 131072}) {
+        float best = 1e9;
+        for (int rep = 0; rep < 4; rep++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(regions_k, dim3(1024), dim3(64), 0, 0, d_src, h_dst, (size_t)131072, piece);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+        }
+        printf("1024 wavefronts, a 128 KiB region each, %6zu B per visit: %.3f ms = %.1f GB/s\n", piece, best, n / best / 1e6);
     }
     float best = 1e9;
     for (int rep = 0; rep < 4; rep++) {
