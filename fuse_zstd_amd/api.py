@@ -258,7 +258,8 @@ def unload_dict(dict_id):
 
 
 def set_driver(driver):
-    """Diagnostics: 0 automatic, 1 / 2 that general driver only (no small-file kernel)."""
+    """Diagnostics: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 4 / 5 block tasks with / without
+    blocks resolved ahead of their predecessors."""
     rc = lib().mzd_debug_set_driver(int(driver))
     if rc != OK:
         raise MzdError(rc, "mzd_debug_set_driver")

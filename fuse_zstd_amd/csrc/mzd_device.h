@@ -9,6 +9,7 @@ constexpr int kWG = 256;                     // threads per workgroup = 4 wavefr
 constexpr uint32_t kBlockMax = 128u * 1024u; // Block_Maximum_Size upper bound (RFC 8878 3.1.1.2.4)
 constexpr uint32_t kMaxSeq = 43691u;         // a block regenerates <= 128 KiB and every match is >= 3 bytes
 constexpr uint32_t kLitStride = kBlockMax + 64;
+constexpr uint32_t kResMapStride = kBlockMax + 64; // words per workgroup slot of the resolve map (mzd_k_resolve.h)
 constexpr uint32_t kSeqStride = kMaxSeq + 21; // uint4 entries per workgroup (multiple of 64 keeps 16-B alignment)
 
 // One file.  Device mirror of mzd_job (include/mzd.h).
@@ -72,7 +73,11 @@ struct FileState { // zeroed per launch
     uint64_t frame_out0;    // `out` at the start of the current frame
     uint64_t xstripes;      // XXH64: 32-byte stripes of the current frame absorbed so far
     uint64_t xxh[4];        // XXH64 accumulators
-    uint64_t pad[3];
+    // launches that resolve blocks ahead of their predecessors (KernelArgs::resolve): the repeat offsets travel on a chain
+    // of their own, as soon as a task's plan is complete -- rep_e = the offsets after task rep_ver - 1
+    uint32_t rep_ver;
+    uint32_t rep_e[3];
+    uint64_t pad[1];
 };
 static_assert(sizeof(FileState) == 128, "FileState layout");
 
@@ -119,6 +124,11 @@ struct KernelArgs {
     const uint32_t* job_list;
     uint32_t nlist_fixed;
     uint32_t wg0;         // first workgroup slot of this launch in the scratch arrays (several launches may be in flight)
+    // Block-task launches with few tasks for the machine (a single big file: the in-order copy stage is the whole critical
+    // path): every block's sequences are resolved to a byte map -- each output byte's ultimate source, a literal or a byte
+    // older than the block -- BEFORE its predecessor has finished (mzd_k_resolve.h), so that the in-order stage is a gather.
+    uint32_t* resolve_map; // kBlockMax words per workgroup slot, or null
+    uint32_t resolve;      // 1: use it
 };
 
 // ---- the small-file kernel (mzd_small.hip): one lane per file, a group of G files per wavefront ------------------------

@@ -47,7 +47,8 @@ constexpr uint32_t kMaxDicts = 64;
 constexpr size_t kMaxChunks = 16;               // ... and at most this many chunks per call
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
-std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic
+std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic,
+                                    // 4 / 5 block tasks with / without blocks resolved ahead (mzd_k_resolve.h) whatever the launch's size
 
 // What one launch runs on: a stream, a counter block, a range of workgroup slots of the scratch arrays, a share of the
 // small-file kernel's literal scratch, the per-launch state of the block-task driver.  The host path keeps up to kSlots of
@@ -84,6 +85,7 @@ struct Device {
     uint4* seq_scratch = nullptr;
     uint4* walk_scratch = nullptr;
     uint8_t* small_lit = nullptr;
+    uint32_t* resolve_map = nullptr; // kResMapStride words per workgroup slot (mzd_k_resolve.h)
     DebugSlot* debug = nullptr;
     uint32_t* counters = nullptr; // (kSlots + 1) blocks of kCounterWords
     Lane lane[kSlots];
@@ -120,7 +122,7 @@ void free_lane(Lane& l, bool own_stream) {
 void free_device(Device& d) {
     hipSetDevice(d.hip_id);
     hipDeviceSynchronize();
-    hipFree(d.lit_scratch); hipFree(d.seq_scratch); hipFree(d.walk_scratch); hipFree(d.small_lit); hipFree(d.debug); hipFree(d.counters); hipFree(d.d_dicts);
+    hipFree(d.lit_scratch); hipFree(d.seq_scratch); hipFree(d.walk_scratch); hipFree(d.small_lit); hipFree(d.resolve_map); hipFree(d.debug); hipFree(d.counters); hipFree(d.d_dicts);
     for (void* p : d.dict_bufs) hipFree(p);
     for (auto& s : d.staging) {
         hipFree(s.d_in); hipFree(s.d_out); hipFree(s.d_jobs); hipFree(s.d_lists);
@@ -151,6 +153,7 @@ int init_device(Device& d, int hip_id, int index) {
     HIPCHK(hipMalloc(&d.seq_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
     HIPCHK(hipMalloc(&d.walk_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
     HIPCHK(hipMalloc(&d.small_lit, kSmallLitBytes));
+    HIPCHK(hipMalloc(&d.resolve_map, (size_t)d.max_wg * kResMapStride * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&d.debug, (size_t)d.max_wg * sizeof(DebugSlot)));
     HIPCHK(hipMemset(d.debug, 0, (size_t)d.max_wg * sizeof(DebugSlot)));
     HIPCHK(hipMalloc(&d.counters, (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
@@ -245,6 +248,7 @@ struct Plan {
     bool with_dict = false, multi = false;
     uint32_t lit_stride = 0;   // literal scratch per small file: largest capacity + 64
     uint32_t big_tasks = 0;    // workgroups worth launching for the files that are not small
+    uint64_t blocks = 0;       // block tasks of those files, estimated from their capacities
 };
 // lists: [0, njobs) small list (job indices sorted by dictionary), [njobs, 2 njobs) job list of the general driver
 Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_wg) {
@@ -266,6 +270,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
         } else {
             big[p.nbig++] = (uint32_t)i;
             if (j.dst_cap > kBlockMax) p.multi = true;
+            p.blocks += 1 + j.dst_cap / kBlockMax;
             if (tasks < max_wg) tasks += 1 + j.src_len / 2048;
         }
     }
@@ -276,7 +281,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
             std::stable_sort(small, small + p.nsmall, [&](uint32_t x, uint32_t y) { return jobs[x].dict < jobs[y].dict; });
     }
     if (force == 1) p.multi = false;
-    if (force == 2) p.multi = true;
+    if (force == 2 || force == 4 || force == 5) p.multi = true;
     p.big_tasks = (uint32_t)std::min<uint64_t>(tasks, max_wg);
     return p;
 }
@@ -298,6 +303,10 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     }
     ka.fstate = l.fstate; ka.tables = l.tables; ka.ring = l.ring; ka.ring_cap = (uint32_t)l.task_cap + 1; ka.epoch = l.epoch;
     ka.use_tasks = use_tasks ? 1u : 0u;
+    // few tasks for the lane's workgroups: the in-order copy stage is the critical path -- resolve blocks ahead (mzd_k_resolve.h)
+    const int force = g_force_driver.load(std::memory_order_relaxed);
+    ka.resolve_map = d.resolve_map;
+    ka.resolve = use_tasks && force != 5 && (force == 4 || p.blocks <= 2ull * l.nwg) ? 1u : 0u;
     HIPCHK(hipMemsetAsync(l.counter, 0, kCounterWords * sizeof(uint32_t), s));
     HIPCHK(hipEventRecord(ev0, s));
     uint32_t grid;
@@ -937,7 +946,7 @@ int mzd_unload_dict(uint32_t dict_id) {
 }
 
 int mzd_debug_set_driver(int driver) {
-    if (driver < 0 || driver > 3) return MZD_E_PARAM;
+    if (driver < 0 || driver > 5) return MZD_E_PARAM;
     g_force_driver.store(driver, std::memory_order_relaxed);
     return MZD_OK;
 }

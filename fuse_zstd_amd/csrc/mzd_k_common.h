@@ -25,6 +25,7 @@ struct Ctl {
     uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
     uint32_t next_stream, streams_done, streams_mask; // Huffman streams are handed out to whichever wavefront is free; mask: bit k = stream k decoded
     uint32_t tables_ready, plan_prog, copy_prog, plan_lit_used; // walker -> planner -> copier
+    uint32_t plan_out;      // output bytes of the block's sequences (the literals behind the last one not counted), once the plan is complete
     uint32_t plan_too_long; // 1: the plan ends with a chunk that cannot be executed (literals run out / output passes 128 KiB); 2: only the literals after
                             // the last sequence pass 128 KiB.  No error yet: the copier, which reports in stream order, gives the verdict
     uint32_t seq_parsed;                           // the sequence header is parsed: nseq, seq_off, seq_len, modes are final
@@ -73,6 +74,8 @@ struct __attribute__((aligned(16))) Shared {
     // driver 1, files of one block: while the copier and the hasher finish file A, the idle walking wavefront takes the
     // next file and parses its headers into `c2` (header bytes staged in a free part of the ring)
     Ctl c2;
+    uint32_t res[4];             // mzd_k_resolve.h: bad offset seen, farthest reach before the block, a round left entries open; [3] spare
+    uint32_t res_rep[3];         // ... the repeat offsets the task starts with (rep_hop)
     uint32_t pre_job, pre_valid; // the job taken ahead (kNoJob: none) and whether c2 holds its parsed first block
     // driver 1: the small fields of the dictionary the workgroup used last (config 5: every file names the same one --
     // reading them from HBM again for each file costs a round trip per dependent load)

@@ -112,6 +112,8 @@ struct PlanCtx { // what the planning wavefront needs
     uint32_t nlit;
     uint32_t rep_known;      // the repeat offsets at the start of the block are known (first block of a frame)
     uint32_t rep[3];
+    uint4* chunk_base;       // [k] = {output, literals} of the block before chunk k (for mzd_k_resolve.h): the walk records' array, whose
+                             // entry k the planner has consumed by the time it plans chunk k
 };
 
 // Offsets in the plan: a plain value, or -- when the block starts before its predecessor has finished, so that
@@ -175,6 +177,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
         const uint32_t i = base + (uint32_t)lane;
         const bool valid = (uint32_t)lane < cnt;
+        if (lane == 0) cx.chunk_base[chunk] = make_uint4(opos, lpos, 0, 0);
         // everything this wavefront stored an iteration ago has landed: chunk k-1 of the plan is public
         wg_fence();
         if (lane == 0) flag_store(&S.c.plan_prog, chunk);
@@ -254,7 +257,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
     wg_fence();
     if (lane == 0) {
         S.c.rep_op[0] = R.s; S.c.rep_op[1] = (uint32_t)R.v0; S.c.rep_op[2] = (uint32_t)R.v1; S.c.rep_op[3] = (uint32_t)R.v2;
-        S.c.plan_lit_used = lpos;
+        S.c.plan_lit_used = lpos; S.c.plan_out = opos;
         if (opos + rest > kBlockMax) S.c.plan_too_long = 2; // only the literals after the last sequence pass the limit: every chunk is published
         flag_store(&S.c.plan_prog, chunk);
     }

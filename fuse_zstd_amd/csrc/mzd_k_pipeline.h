@@ -179,7 +179,7 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
         int rc = MZD_E_CORRUPT;
         if (spin_ge(&c.tables_ready, 1, &c.err)) {
             // (a task plans before its predecessor has finished: the repeat offsets at its start are unknown unless it opens the frame)
-            PlanCtx px{b.walk, b.src + r.seq_off, &c.walk_prog, r.nlit, (!TASKS || b.frame_first) ? 1u : 0u, {c.rep[0], c.rep[1], c.rep[2]}};
+            PlanCtx px{b.walk, b.src + r.seq_off, &c.walk_prog, r.nlit, (!TASKS || b.frame_first) ? 1u : 0u, {c.rep[0], c.rep[1], c.rep[2]}, b.walk};
             __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
             rc = plan_wave(b.seqs, r.nseq, px, lane);
             __builtin_amdgcn_s_setprio(0);
@@ -192,12 +192,16 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
         }
         TFIN(3);
     }
+    if (TASKS && r.a.resolve) { // resolving launches: the repeat offsets go on to the successor as soon as this block's transform is known
+        if (lane == 0) S.res[3] = rep_hop(b.fs, b.t, b.frame_first, seq_ok && r.nseq != 0 && !__atomic_load_n(&c.err, __ATOMIC_RELAXED), S.res_rep) ? 1u : 0u;
+    }
     r.huf_helper(); // the ring (its staging area) is free: the walker has finished before the planner does
 }
 
 // ---- waves 1 and 2: K1 Huffman table (wave 1), K2 literal streams, then the copying half of K5 (wave 1) / K7 behind it (wave 2)
+// phase: 3 both halves; 1 the literals only (a resolving task: mzd_k_resolve.h executes the block); 2 copy / hash only (its fallback)
 template <bool TASKS>
-__device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored) {
+__device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored, int phase) {
     Ctl& c = S.c;
     const BlockArgs& b = r.b;
     const KernelArgs& a = r.a;
@@ -206,6 +210,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
     uint8_t* const dst = b.dst;
     const bool frame_first = b.frame_first;
     int rc = 0;
+    if (phase & 1) {
     // the literals gate the copier (the tail of the block): the copying wavefront's tree + first stream run at the
     // copier's priority, the remaining streams just below
     if (wave == 1) __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); else __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
@@ -243,7 +248,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
         for (uint32_t k = (uint32_t)(tid - 64) * 16; k < nlit; k += 128 * 16)
             *reinterpret_cast<uint4*>(b.lit_buf + k) = make_uint4(w, w, w, w); // lit_buf has slack past nlit
     } else if (lit_type >= 2 && !failed && r.get_seq()) { // K2: the copying wavefront decodes one stream and then
-        r.huf_streams(wave == 1 && !r.lit_in_place() ? 1u : 4u); // copies behind the literals; wavefront 2 (and idle ones) drain the queue
+        r.huf_streams(wave == 1 && !r.lit_in_place() && (phase & 2) ? 1u : 4u); // copies behind the literals; wavefront 2 (and idle ones) drain the queue
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) {
@@ -252,6 +257,8 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
     }
     __builtin_amdgcn_s_setprio(0);
     if (wave == 1) TFIN(4);
+    }
+    if (!(phase & 2)) return;
     if (wave == 1) { // the copying half of K5
         uint64_t opos = b.out0;
         rc = MZD_E_CORRUPT;
@@ -331,7 +338,8 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
 
 // One compressed block.  Returns false when its headers already failed (c.err is set): nothing was started.
 template <bool TASKS>
-__device__ __forceinline__ bool compressed_block(const KernelArgs& a, const BlockArgs& b, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored, int tid, int lane, int wave) {
+__device__ __forceinline__ bool compressed_block(const KernelArgs& a, const BlockArgs& b, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored, int tid, int lane, int wave,
+                                                 bool defer_copy = false) {
     Ctl& c = S.c;
     int err = 0;
     // K0/K1/K3 headers: where everything is; nothing is decoded yet.  The two header regions (<= 256 bytes each: literals
@@ -368,6 +376,15 @@ __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const Bloc
                       TASKS ? b.dst : b.dst + b.out0};
     if (wave == 0) role_walk<TASKS>(r);
     else if (wave == 3) role_plan<TASKS>(r);
-    else role_literals_then_copy_or_hash<TASKS>(r, xv, xstripes, mirrored);
+    else role_literals_then_copy_or_hash<TASKS>(r, xv, xstripes, mirrored, defer_copy ? 1 : 3);
     return true;
+}
+
+// The deferred second half (a task that could not be resolved after all): wavefront 1 copies, wavefront 2 hashes / mirrors.
+__device__ __forceinline__ void compressed_block_copy(const KernelArgs& a, const BlockArgs& b, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored, int tid, int lane, int wave) {
+    Ctl& c = S.c;
+    if (wave != 1 && wave != 2) return;
+    BlockRun<true> r{a, b, tid, lane, wave, c.lit_type, c.nlit, c.streams, 0u, c.seq_len, c.lit_off, c.seq_off,
+                     c.lit_type == 0 ? b.src + c.lit_off : b.lit_buf, wave == 1 ? S.stage + 2064 : S.hseg2, b.dst};
+    role_literals_then_copy_or_hash<true>(r, xv, xstripes, mirrored, 2);
 }

@@ -1,0 +1,159 @@
+// mzd_k_resolve.h -- part of the block-task driver of mzd_kernels.hip.  Included there, inside namespace mzd, behind the block
+// pipeline; not a translation unit of its own.
+#pragma once
+// ------------------------------------------------------------------------------------ K5, resolved ahead of the predecessor
+// A multi-block frame is entropy-decoded block-parallel but executed in order, and sequence execution is a chain of
+// dependent copies (record after record in JSON): ~0.45 ms per 128 KiB block for the copying wavefront, the whole
+// critical path of a big file on an otherwise idle machine.  When a launch has few tasks for the machine
+// (KernelArgs::resolve) the chain is taken out of the in-order stage:
+//   1. as soon as a block's plan is complete -- long before its predecessor has finished -- the workgroup writes a BYTE MAP
+//      of the block: for every output byte its source, which is a literal (index into the block's literals), a byte OLDER
+//      than the block (distance before the block's start), or an earlier byte of the block itself (position);
+//   2. pointer jumping (map[p] = map[map[p]] while that is a position in the block) removes the third kind in
+//      log2(longest chain) rounds of 256 independent lanes -- no data is touched, only indices;
+//   3. in task order, the block is then a GATHER: every byte comes from the literals or from output that is complete.
+// The repeat offsets a block starts with travel on a chain of their own (FileState::rep_ver), handed on as soon as a
+// task's plan is complete, so that step 1 never meets a symbolic offset.
+// Anything unusual -- an error, a dictionary reference, a block that does not fit, rounds that do not converge --
+// falls back to the copying wavefront (copy_wave), which reports errors in the reference's order: nothing has been
+// written when the decision is taken.
+constexpr uint32_t kResLit = 0x80000000u;   // map entry: literal, bits 0-29 index into the block's literals
+constexpr uint32_t kResPrev = 0x40000000u;  // map entry: output older than the block, bits 0-29 = distance before the block start - 1
+constexpr uint32_t kResIdx = 0x3FFFFFFFu;
+constexpr uint32_t kResRounds = 24;         // > log2(128 Ki) + slack (reads race with writes of the same round, which only helps)
+
+// Step 1, all four wavefronts (chunks of 64 sequences dealt round-robin; lane = sequence).  cbase[k] = {output, literals}
+// before chunk k (plan_wave).  Leaves in S.res: [0] != 0 an offset of 0 was seen (the copier must give the verdict),
+// [1] the largest distance any match reaches before the block start.
+__device__ __noinline__ void resolve_build(uint32_t* map, const uint4* plan, const uint4* cbase, uint32_t nseq_in, uint32_t out_seqs, uint32_t lit_used,
+                                           uint32_t nlit, uint32_t rep0, uint32_t rep1, uint32_t rep2, uint4* plan_wb, int lane, int wave) {
+    const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
+    const uint32_t nchunks = (nseq + 63) / 64;
+    uint32_t bad = 0, maxprev = 0;
+    for (uint32_t chunk = (uint32_t)wave; chunk < nchunks; chunk += 4) {
+        const uint32_t i = chunk * 64 + (uint32_t)lane;
+        const bool valid = i < nseq;
+        const uint4 pe = valid ? plan[i] : make_uint4(0, 0, 1, 0);
+        const uint4 cb = cbase[chunk];
+        const uint32_t ll = pe.x, ml = pe.y, ex_t = pe.w;
+        uint32_t off = pe.z;
+        if (off & kOffTag) { // start slot + delta (plan_wave): the chain has delivered the start offsets
+            off = (uint32_t)sel3((off >> 29) & 3, (int32_t)rep0, (int32_t)rep1, (int32_t)rep2) + (off & 0x1FFFFFFFu) - (uint32_t)kOffBias;
+            if (plan_wb && valid) plan_wb[i].z = off;
+        }
+        const uint32_t p_l = cb.x + ex_t, p_m = p_l + ll;
+        const uint32_t li = cb.y + (wave_incl_scan(ll, lane) - ll);
+        if (valid && (off == 0 || off >= (1u << 30))) bad = 1;
+        if (valid && ml && off > p_m) { const uint32_t d = off - p_m; maxprev = d > maxprev ? d : maxprev; }
+        // short pieces: every lane its own, four entries per store (16 bytes, 4-byte aligned), as many steps as the longest needs
+        typedef __attribute__((address_space(1))) uint32_t* gmap;
+        auto ent = [&](uint32_t pos) -> uint32_t { const int32_t q = (int32_t)pos - (int32_t)off; return q >= 0 ? (uint32_t)q : (kResPrev | (uint32_t)(-q - 1)); };
+        {
+            const uint32_t n = (valid && ll <= 64) ? ll : 0;
+            gmap const m = (gmap)(map + p_l);
+            for (uint32_t k = 0; __any(k < n); k += 4) {
+                const uint32_t e = kResLit | (li + k);
+                if (k + 4 <= n) { const uint4 v = make_uint4(e, e + 1, e + 2, e + 3); __builtin_memcpy(m + k, &v, 16); }
+                else if (k < n) { m[k] = e; if (k + 1 < n) m[k + 1] = e + 1; if (k + 2 < n) m[k + 2] = e + 2; }
+            }
+        }
+        {
+            const uint32_t n = (valid && ml <= 64) ? ml : 0;
+            gmap const m = (gmap)(map + p_m);
+            for (uint32_t k = 0; __any(k < n); k += 4) {
+                const uint32_t e0 = ent(p_m + k), e1 = ent(p_m + k + 1), e2 = ent(p_m + k + 2), e3 = ent(p_m + k + 3);
+                if (k + 4 <= n) { const uint4 v = make_uint4(e0, e1, e2, e3); __builtin_memcpy(m + k, &v, 16); }
+                else if (k < n) { m[k] = e0; if (k + 1 < n) m[k + 1] = e1; if (k + 2 < n) m[k + 2] = e2; }
+            }
+        }
+        // long pieces: one after the other, by the whole wavefront
+        uint64_t lm = __ballot(valid && ll > 64);
+        while (lm) {
+            const int sl = __builtin_ctzll(lm);
+            const uint32_t n = __builtin_amdgcn_readlane(ll, sl), p = __builtin_amdgcn_readlane(p_l, sl), l0 = __builtin_amdgcn_readlane(li, sl);
+            for (uint32_t k = (uint32_t)lane; k < n; k += 64) map[p + k] = kResLit | (l0 + k);
+            lm &= lm - 1;
+        }
+        uint64_t mm = __ballot(valid && ml > 64);
+        while (mm) {
+            const int sl = __builtin_ctzll(mm);
+            const uint32_t n = __builtin_amdgcn_readlane(ml, sl), p = __builtin_amdgcn_readlane(p_m, sl), o = __builtin_amdgcn_readlane(off, sl);
+            for (uint32_t k = (uint32_t)lane; k < n; k += 64) { const int32_t q = (int32_t)(p + k) - (int32_t)o; map[p + k] = q >= 0 ? (uint32_t)q : (kResPrev | (uint32_t)(-q - 1)); }
+            mm &= mm - 1;
+        }
+    }
+    if (wave == 0) { // the literals behind the last sequence, and the padding up to a whole 16 bytes of entries
+        const uint32_t rest = nlit - lit_used;
+        for (uint32_t k = (uint32_t)lane; k < rest; k += 64) map[out_seqs + k] = kResLit | (lit_used + k);
+        if (lane < 4) map[out_seqs + rest + (uint32_t)lane] = kResLit;
+    }
+    if (__any(bad != 0) && lane == 0) __atomic_fetch_or(&S.res[0], 1u, __ATOMIC_RELAXED);
+    for (int sh = 32; sh; sh >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxprev, sh); maxprev = o > maxprev ? o : maxprev; }
+    if (lane == 0) __atomic_fetch_max(&S.res[1], maxprev, __ATOMIC_RELAXED);
+}
+
+// Step 2, all 256 threads (workgroup barriers inside).  true: no entry refers to the block any more.
+__device__ __noinline__ bool resolve_jump(uint32_t* map, uint32_t B, int tid) {
+    const uint32_t n4 = (B + 3) / 4;
+    uint4* const m4 = reinterpret_cast<uint4*>(map);
+    for (uint32_t round = 0; round < kResRounds; round++) {
+        if (tid == 0) S.res[2] = 0;
+        __syncthreads();
+        uint32_t open = 0;
+        // four vectors of four entries per step: their loads, then their (up to 16) dependent loads, are in flight together
+        for (uint32_t q0 = (uint32_t)tid; q0 < n4; q0 += 4 * kWG) {
+            uint4 v[4];
+            bool live[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t q = q0 + (uint32_t)u * kWG; live[u] = q < n4; v[u] = live[u] ? m4[q] : make_uint4(kResLit, kResLit, kResLit, kResLit); }
+            uint4 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                w[u].x = v[u].x < kResPrev ? map[v[u].x] : v[u].x; w[u].y = v[u].y < kResPrev ? map[v[u].y] : v[u].y;
+                w[u].z = v[u].z < kResPrev ? map[v[u].z] : v[u].z; w[u].w = v[u].w < kResPrev ? map[v[u].w] : v[u].w;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool any = (v[u].x < kResPrev) | (v[u].y < kResPrev) | (v[u].z < kResPrev) | (v[u].w < kResPrev);
+                if (live[u] && any) {
+                    m4[q0 + (uint32_t)u * kWG] = w[u];
+                    open |= (uint32_t)(w[u].x < kResPrev) | (uint32_t)(w[u].y < kResPrev) | (uint32_t)(w[u].z < kResPrev) | (uint32_t)(w[u].w < kResPrev);
+                }
+            }
+        }
+        if (open) __atomic_store_n(&S.res[2], 1u, __ATOMIC_RELAXED);
+        wg_fence();
+        __syncthreads();
+        const bool done = __atomic_load_n(&S.res[2], __ATOMIC_RELAXED) == 0;
+        __syncthreads();
+        if (done) return true;
+    }
+    return false;
+}
+
+// Step 3, all 256 threads, in task order: out[out0 + p] = literal or older output.  The caller has checked that the block
+// fits and that no match reaches before the frame.
+__device__ __noinline__ void resolve_gather(const uint32_t* map, uint32_t B, const uint8_t* lit, uint8_t* dst, uint64_t out0, int tid) {
+    const uint4* const m4 = reinterpret_cast<const uint4*>(map);
+    const uint8_t* const hist = dst + out0 - 1; // hist[-d]: d bytes before the block's last older byte
+    uint8_t* const o = dst + out0;
+    const uint32_t n4 = (B + 3) / 4;
+    auto byte_of = [&](uint32_t e) -> uint32_t {
+        const uint32_t ix = e & kResIdx;
+        return (e & kResLit) ? (uint32_t)lit[ix] : (uint32_t)*(hist - ix);
+    };
+    for (uint32_t q0 = (uint32_t)tid; q0 < n4; q0 += 4 * kWG) { // four dwords per step: 16 byte loads in flight together
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t q = q0 + (uint32_t)u * kWG; v[u] = q < n4 ? m4[q] : make_uint4(kResLit, kResLit, kResLit, kResLit); }
+        uint32_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = byte_of(v[u].x) | (byte_of(v[u].y) << 8) | (byte_of(v[u].z) << 16) | (byte_of(v[u].w) << 24);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = (q0 + (uint32_t)u * kWG) * 4;
+            if (p + 4 <= B) __builtin_memcpy(o + p, &w[u], 4);
+            else for (uint32_t k = 0; p + k < B; k++) o[p + k] = (uint8_t)(w[u] >> (8 * k));
+        }
+    }
+}

@@ -130,8 +130,26 @@ __device__ __noinline__ bool load_pred(const FileState* fs, uint32_t t) {
     return true;
 }
 
+// One lane.  The repeat-offset chain: wait for the predecessor's, apply this task's transform (identity unless it planned
+// sequences), publish.  `rin` receives the offsets this task starts with.  false: the launch is broken (timeout).
+__device__ __noinline__ bool rep_hop(FileState* fs, uint32_t t, bool frame_first, bool planned, uint32_t* rin) {
+    Ctl& c = S.c;
+    const bool ok = g_wait_ge(&fs->rep_ver, t);
+    uint32_t r0 = c.rep[0], r1 = c.rep[1], r2 = c.rep[2]; // a frame starts with its own (1, 4, 8 or the dictionary's)
+    if (!frame_first) { r0 = g_ld(&fs->rep_e[0]); r1 = g_ld(&fs->rep_e[1]); r2 = g_ld(&fs->rep_e[2]); }
+    rin[0] = r0; rin[1] = r1; rin[2] = r2;
+    RepOp Rf;
+    if (planned) { Rf.s = c.rep_op[0]; Rf.v0 = (int32_t)c.rep_op[1]; Rf.v1 = (int32_t)c.rep_op[2]; Rf.v2 = (int32_t)c.rep_op[3]; }
+    else { Rf.s = 0 | (1 << 2) | (2 << 4); Rf.v0 = 0; Rf.v1 = 0; Rf.v2 = 0; }
+    g_st(&fs->rep_e[0], rep_eval(Rf, 0, r0, r1, r2)); g_st(&fs->rep_e[1], rep_eval(Rf, 1, r0, r1, r2)); g_st(&fs->rep_e[2], rep_eval(Rf, 2, r0, r1, r2));
+    g_settle();
+    g_store(&fs->rep_ver, t + 1);
+    return ok;
+}
+
 
 #include "mzd_k_pipeline.h"
+#include "mzd_k_resolve.h"
 
 // ---- driver 1: one workgroup decodes a whole file, block after block.  Used when no file of the launch can have more
 // than one block (every output capacity <= 128 KiB): nothing is forked, nothing is published, the file's state
@@ -354,6 +372,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         uint8_t* const dst2 = a.jobs[j].dst2; // (host mirror of the output, or null)
         uint64_t mirrored = 0;                // wave 2: how far this task's block has been mirrored
         bool have_mirrored = false;           // ... `mirrored` is valid (a compressed block whose copier ran)
+        bool rep_hopped = false;              // resolving launches: this task has passed the repeat-offset chain on
         FileState* const fs = &a.fstate[j];
         TableArea* const ta = &a.tables[j];
         if (tid == 0) {
@@ -431,6 +450,11 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
             }
         }
 
+        if (a.resolve && !(have_block && btype == 2)) { // resolving launches: a task that plans nothing hands the repeat offsets on at once
+            if (tid == 0) rep_hop(fs, t, frame_first, false, S.res_rep);
+            rep_hopped = true;
+        }
+
         // ---------------- the block
         uint64_t out0 = 0, frame_start = 0, out_end = 0;
         bool pred_loaded = false; // (workgroup-uniform) c.pred_* is filled in
@@ -457,12 +481,75 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                 xxh_advance(xv, xstripes, (out_end - frame_start) / 32, dst + frame_start, lane);
             }
         } else if (have_block) {
+            // (launch-wide: every task then keeps the repeat-offset chain going.  A file's first block has no predecessor to
+            //  wait for: its copier and hasher follow its walker as they always do, and the file's checksum chain starts early)
+            const bool resolving = a.resolve != 0 && t != 0;
             BlockArgs ba{src, n, dst, cap, dst2, src + pos0, bsize, pos0, 0, lit_buf, seqs, walk, last, hashing, false, t, frame_first, is_final, fs, ta, j};
-            compressed_block<true>(a, ba, xv, xstripes, mirrored, tid, lane, wave);
-            have_mirrored = true;
+            const bool started = compressed_block<true>(a, ba, xv, xstripes, mirrored, tid, lane, wave, resolving);
+            bool resolved = false;
+            if (resolving && started) {
+                __syncthreads(); // walk, plan and literals are complete (every role has returned); nothing of the block has been written yet
+                TFIN(7); // (diagnostic builds: the resolve timeline reuses the literal-side slots 7, 8, 4 and the copier's 9, 1, 2)
+                if (tid == 0) { S.res[0] = 0; S.res[1] = 0; } // (the planning wavefront has passed the repeat-offset chain on: S.res_rep, S.res[3])
+                uint32_t nseq = 0, nlit = 0, pout = 0, lused = 0, too_long = 0, lit_type = 0, r0 = 0, r1 = 0, r2 = 0, hop_ok = 0;
+                uint64_t lit_off = 0;
+                WG_SNAPSHOT(err = c.err; nseq = c.nseq; nlit = c.nlit; pout = c.plan_out; lused = c.plan_lit_used; too_long = c.plan_too_long; lit_type = c.lit_type;
+                            lit_off = c.lit_off; r0 = S.res_rep[0]; r1 = S.res_rep[1]; r2 = S.res_rep[2]; hop_ok = S.res[3]);
+                uint32_t* const map = a.resolve_map + (size_t)slot * kResMapStride;
+                const uint32_t B = pout + (nlit - lused);
+                bool ok = !err && hop_ok && nseq != 0 && !too_long && lused <= nlit && B <= kBlockMax;
+                if (ok) {
+                    resolve_build(map, seqs, walk, nseq, pout, lused, nlit, r0, r1, r2, a.debug ? seqs : nullptr, lane, wave);
+                    wg_fence();
+                    uint32_t bad = 0;
+                    WG_SNAPSHOT(bad = S.res[0]);
+                    TFIN(8);
+                    ok = !bad && resolve_jump(map, B, tid);
+                    TFIN(4);
+                }
+                if (ok) { // in task order from here
+                    if (tid == 0) load_pred(fs, t);
+                    int perr = 0;
+                    uint64_t fstart0 = 0;
+                    uint32_t reach = 0;
+                    WG_SNAPSHOT(perr = c.pred_err; out0 = c.pred_out; fstart0 = frame_first ? c.pred_out : c.pred_frame_out0; reach = S.res[1]);
+                    pred_loaded = true;
+                    TFIN(9);
+                    if (!perr && B <= cap - out0 && reach <= out0 - fstart0) {
+                        if (t) g_acquire(); // the predecessors' output (another XCD's L2 may have held it)
+                        resolve_gather(map, B, lit_type == 0 ? src + lit_off : lit_buf, dst, out0, tid);
+                        wg_fence();
+                        if (tid == 0) { c.out = out0 + B; c.pos = pos0 + bsize; }
+                        __syncthreads();
+                        TFIN(1);
+                        if (wave == 2 && hashing) { // K7: this block's stripes (the state travels from task to task)
+                            xv = frame_first ? xxh_init(lane) : c.pred_xxh[lane & 3];
+                            xstripes = frame_first ? 0 : c.pred_xstripes;
+                            xxh_advance(xv, xstripes, (out0 + B - fstart0) / 32, dst + fstart0, lane);
+                            TFIN(2);
+                        }
+                        if (a.debug && tid == 0) {
+                            DebugSlot& ds = a.debug[a.wg0 + blockIdx.x];
+                            ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0; ds.lit_raw_ptr = (uint64_t)(uintptr_t)(lit_type == 0 ? src + lit_off : lit_buf);
+                            if (j == 0) atomicMax(&a.counter[1], (t << 12) | (a.wg0 + blockIdx.x));
+                        }
+                        resolved = true;
+                    } else if (perr) { // the file has already failed: nothing to execute (the error travels on)
+                        if (tid == 0) { c.out = out0; c.pos = pos0 + bsize; }
+                        resolved = true;
+                    }
+                }
+            }
+            if (started) rep_hopped = true; // (role_plan)
+            if (resolving && started && !resolved) { compressed_block_copy(a, ba, xv, xstripes, mirrored, tid, lane, wave); have_mirrored = true; }
+            else if (!resolving) have_mirrored = true;
             WG_SNAPSHOT(err = c.err);
             STAMP(6);
-            pred_loaded = c.pred_ready != 0;
+            if (!resolved) pred_loaded = c.pred_ready != 0;
+        }
+        if (a.resolve && !rep_hopped) { // (a compressed block whose headers failed)
+            if (tid == 0) rep_hop(fs, t, frame_first, false, S.res_rep);
+            rep_hopped = true;
         }
 
         // ---------------- completion, in task order: frame trailer (K7), then the state for the successor

@@ -124,7 +124,8 @@ int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit
                          uint32_t* seq4, size_t seq_cap, size_t* n_seq);
 
 /* Diagnostics (tests, tools/): which kernel a launch takes.  0 / 3 automatic (small files: the lane-per-file kernel; then a
- * workgroup per file, or block tasks when a file can have several blocks), 1 / 2: that general driver only. */
+ * workgroup per file, or block tasks when a file can have several blocks), 1 / 2: that general driver only; 4 / 5: block
+ * tasks, with / without resolving blocks ahead of their predecessors whatever the size of the launch. */
 int mzd_debug_set_driver(int driver);
 /* The 8 counter words of the launch that decoded job 0 of the most recent call: [0] queue tickets, [2] block tasks pushed,
  * [3] files finished by the block-task driver, [4] small files the lane-per-file kernel handed on to the general driver,

@@ -20,12 +20,13 @@ def gpu():
     mzd.shutdown()
 
 
-DRIVERS = ["auto", "1", "2"]  # auto: small files take the lane-per-file kernel, the rest (and what it hands on) a general driver
+DRIVERS = ["auto", "1", "4", "5"]  # auto: small files take the lane-per-file kernel, the rest (and what it hands on) a general driver;
+                                    # 4 / 5: block tasks with / without blocks resolved ahead of their predecessors (mzd_k_resolve.h)
 
 
 @pytest.fixture
 def force_driver():
-    """mzd_debug_set_driver for one test: 'auto' or the general driver '1' / '2' alone."""
+    """mzd_debug_set_driver for one test: 'auto' or one general driver alone ('1', '2', '4', '5')."""
     def set_(driver):
         mzd.set_driver(0 if driver == "auto" else int(driver))
     yield set_

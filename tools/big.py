@@ -1,4 +1,4 @@
-"""Diagnostic: kernel time of n files of one size under both drivers (mzd_debug_set_driver 1: a workgroup per file, 2: block tasks)."""
+"""Diagnostic: kernel time of n files of one size under both drivers (mzd_debug_set_driver 1: a workgroup per file, 5: block tasks, 4: block tasks with blocks resolved ahead)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fuse_zstd_amd as mzd, corpus
@@ -8,7 +8,7 @@ for size, n in ((1 << 20, 1), (1 << 20, 8), (1 << 20, 64), (1 << 18, 64), (1 << 
     cp = corpus.build_corpus(kind, 5, [size] * n)
     srcs = [cp.comp_file(i).tobytes() for i in range(n)]
     line = "%s %4d x %7d B:" % (kind, n, size)
-    for drv in ("1", "2"):
+    for drv in ("1", "5", "4"):
         mzd.set_driver(int(drv))
         for rep in range(3):
             res = mzd.decode_batch(srcs, [size] * n)
