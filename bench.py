@@ -412,6 +412,8 @@ def main():
     import fuse_zstd_amd as mzd
     mzd.build()
     mzd.init([local_rank])  # raises when the HIP library / GPU is missing: no fallback
+    if os.environ.get("MZD_DRIVER"):  # diagnostic (tools/): force one kernel choice, see mzd_debug_set_driver
+        mzd.set_driver(int(os.environ["MZD_DRIVER"]))
 
     stream = torch.cuda.Stream(dev)  # a real (non-NULL) stream: the kernels and the timing events share it
 

@@ -47,7 +47,8 @@ constexpr uint32_t kMaxDicts = 64;
 constexpr size_t kMaxChunks = 16;               // ... and at most this many chunks per call
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
-std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic,
+std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic with the
+                                    // small-file kernel for every eligible file however few,
                                     // 4 / 5 block tasks with / without blocks resolved ahead (mzd_k_resolve.h) whatever the launch's size
 
 // What one launch runs on: a stream, a counter block, a range of workgroup slots of the scratch arrays, a share of the
@@ -260,9 +261,15 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
     bool all_dict = true;
     uint64_t tasks = 0;
     size_t maxcap = 0;
+    // The lane-per-file kernel pays off from a few thousand small files on (its launch lasts ~0.6 ms however few they are,
+    // and runs before the general driver); fewer of them fill the general driver's idle workgroup slots for less
+    // (measured on the log-uniform mix cfg4lu, 13 % small files: 12.8 ms without it against 14.1 ms with it)
+    size_t eligible = 0;
+    for (size_t i = 0; i < njobs; i++) eligible += jobs[i].dst_cap <= kSmallCap && jobs[i].src_len <= kSmallSrcMax;
+    const bool small_ok = force == 3 || (force == 0 && eligible >= 8ull * max_wg); // (3: whenever a file is eligible -- tests)
     for (size_t i = 0; i < njobs; i++) {
         const DevJob& j = jobs[i];
-        const bool is_small = (force == 0 || force == 3) && j.dst_cap <= kSmallCap && j.src_len <= kSmallSrcMax;
+        const bool is_small = small_ok && j.dst_cap <= kSmallCap && j.src_len <= kSmallSrcMax;
         if (is_small) {
             small[p.nsmall++] = (uint32_t)i;
             if (j.dict) p.with_dict = true; else all_dict = false;
@@ -306,7 +313,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     // few tasks for the lane's workgroups: the in-order copy stage is the critical path -- resolve blocks ahead (mzd_k_resolve.h)
     const int force = g_force_driver.load(std::memory_order_relaxed);
     ka.resolve_map = d.resolve_map;
-    ka.resolve = use_tasks && force != 5 && (force == 4 || p.blocks <= 2ull * l.nwg) ? 1u : 0u;
+    ka.resolve = use_tasks && force != 5 && (force == 4 || p.blocks <= 4ull * l.nwg) ? 1u : 0u; // (measured crossover on cfg4lu: ~5 blocks per workgroup slot)
     HIPCHK(hipMemsetAsync(l.counter, 0, kCounterWords * sizeof(uint32_t), s));
     HIPCHK(hipEventRecord(ev0, s));
     uint32_t grid;

@@ -123,7 +123,8 @@ int mzd_unload_dict(uint32_t dict_id);
 int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit,
                          uint32_t* seq4, size_t seq_cap, size_t* n_seq);
 
-/* Diagnostics (tests, tools/): which kernel a launch takes.  0 / 3 automatic (small files: the lane-per-file kernel; then a
+/* Diagnostics (tests, tools/): which kernel a launch takes.  0 automatic (small files, when there are thousands of them:
+ * the lane-per-file kernel; 3: that kernel for every eligible file however few; then a
  * workgroup per file, or block tasks when a file can have several blocks), 1 / 2: that general driver only; 4 / 5: block
  * tasks, with / without resolving blocks ahead of their predecessors whatever the size of the launch. */
 int mzd_debug_set_driver(int driver);

@@ -112,6 +112,7 @@ def test_small_files_of_every_class_and_size(kind):
     (raw, RLE, Huffman 1 and 4 streams), predefined / RLE / FSE tables, raw and RLE blocks, long overlapping matches."""
     sizes = [0, 1, 2, 7, 15, 16, 17, 31, 32, 33, 63, 64, 100, 255, 256, 300, 511, 700, 1000, 1023, 1024, 2000, 3000, 4095, 4096, 4097,
              5000, 6000, 8191, 8192, 8193, 9000, 12000]
+    mzd.set_driver(3)  # the lane-per-file kernel for every eligible file (by itself it only takes thousands at a time)
     for level in (1, 3, 19):
         cp = corpus.build_corpus(kind, 77, sizes * 3, level=level)
         srcs = [cp.comp_file(i).tobytes() for i in range(cp.nfiles)]
@@ -120,6 +121,7 @@ def test_small_files_of_every_class_and_size(kind):
             assert st == 0 and out == cp.raw_file(i).tobytes(), (kind, level, int(cp.raw_sizes[i]), st)
         rc, ref = oracle.decode(srcs[7], cap=int(cp.raw_sizes[7]))
         assert rc == 0 and ref == cp.raw_file(7).tobytes()
+    mzd.set_driver(0)
 
 
 def test_small_kernel_hands_on_what_is_not_plain():
@@ -135,7 +137,11 @@ def test_small_kernel_hands_on_what_is_not_plain():
     caps += [v.out_len - 1 for v in vs if v.ok and v.out_len > 2]
     srcs += [v.comp for v in vs if v.ok]
     caps += [v.out_len + 5 for v in vs if v.ok]
-    res = mzd.decode_batch(srcs, caps)
+    mzd.set_driver(3)  # (the lane-per-file kernel however few the files)
+    try:
+        res = mzd.decode_batch(srcs, caps)
+    finally:
+        mzd.set_driver(0)
     for i, (st, out) in enumerate(res):
         rc, want = oracle.decode(srcs[i], cap=caps[i])
         assert st == rc, (i, st, rc)

@@ -20,7 +20,7 @@ def gpu():
     mzd.shutdown()
 
 
-DRIVERS = ["auto", "1", "4", "5"]  # auto: small files take the lane-per-file kernel, the rest (and what it hands on) a general driver;
+DRIVERS = ["auto", "1", "4", "5"]  # auto (mode 3): small files take the lane-per-file kernel however few they are, the rest (and what it hands on) a general driver;
                                     # 4 / 5: block tasks with / without blocks resolved ahead of their predecessors (mzd_k_resolve.h)
 
 
@@ -28,7 +28,7 @@ DRIVERS = ["auto", "1", "4", "5"]  # auto: small files take the lane-per-file ke
 def force_driver():
     """mzd_debug_set_driver for one test: 'auto' or one general driver alone ('1', '2', '4', '5')."""
     def set_(driver):
-        mzd.set_driver(0 if driver == "auto" else int(driver))
+        mzd.set_driver(3 if driver == "auto" else int(driver))
     yield set_
     mzd.set_driver(0)
 
