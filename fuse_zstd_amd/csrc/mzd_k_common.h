@@ -76,6 +76,7 @@ struct __attribute__((aligned(16))) Shared {
     Ctl c2;
     uint32_t res[4];             // mzd_k_resolve.h: bad offset seen, farthest reach before the block, a round left entries open; [3] spare
     uint32_t res_rep[3];         // ... the repeat offsets the task starts with (rep_hop)
+    uint32_t res_prog[3];        // ... steps the three gathering wavefronts have completed (resolve_gather3)
     uint32_t pre_job, pre_valid; // the job taken ahead (kNoJob: none) and whether c2 holds its parsed first block
     // driver 1: the small fields of the dictionary the workgroup used last (config 5: every file names the same one --
     // reading them from HBM again for each file costs a round trip per dependent load)

@@ -100,23 +100,24 @@ __device__ __noinline__ bool resolve_jump(uint32_t* map, uint32_t B, int tid) {
         if (tid == 0) S.res[2] = 0;
         __syncthreads();
         uint32_t open = 0;
-        // four vectors of four entries per step: their loads, then their (up to 16) dependent loads, are in flight together
-        for (uint32_t q0 = (uint32_t)tid; q0 < n4; q0 += 4 * kWG) {
-            uint4 v[4];
-            bool live[4];
+        // four vectors of four entries per step: their loads, then their (up to 16) dependent loads, are in flight together (more
+        // changes nothing: a round is bound by the CU's address path, ~3 scattered dwords per clock)
+        constexpr uint32_t U = 4;
+        for (uint32_t q0 = (uint32_t)tid; q0 < n4; q0 += U * kWG) {
+            uint4 v[U];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t q = q0 + (uint32_t)u * kWG; live[u] = q < n4; v[u] = live[u] ? m4[q] : make_uint4(kResLit, kResLit, kResLit, kResLit); }
-            uint4 w[4];
+            for (uint32_t u = 0; u < U; u++) { const uint32_t q = q0 + u * kWG; v[u] = q < n4 ? m4[q] : make_uint4(kResLit, kResLit, kResLit, kResLit); }
+            uint4 w[U];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (uint32_t u = 0; u < U; u++) {
                 w[u].x = v[u].x < kResPrev ? map[v[u].x] : v[u].x; w[u].y = v[u].y < kResPrev ? map[v[u].y] : v[u].y;
                 w[u].z = v[u].z < kResPrev ? map[v[u].z] : v[u].z; w[u].w = v[u].w < kResPrev ? map[v[u].w] : v[u].w;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (uint32_t u = 0; u < U; u++) {
                 const bool any = (v[u].x < kResPrev) | (v[u].y < kResPrev) | (v[u].z < kResPrev) | (v[u].w < kResPrev);
-                if (live[u] && any) {
-                    m4[q0 + (uint32_t)u * kWG] = w[u];
+                if (any) { // (vectors past the end hold no such entry)
+                    m4[q0 + u * kWG] = w[u];
                     open |= (uint32_t)(w[u].x < kResPrev) | (uint32_t)(w[u].y < kResPrev) | (uint32_t)(w[u].z < kResPrev) | (uint32_t)(w[u].w < kResPrev);
                 }
             }
@@ -156,4 +157,56 @@ __device__ __noinline__ void resolve_gather(const uint32_t* map, uint32_t B, con
             else for (uint32_t k = 0; p + k < B; k++) o[p + k] = (uint8_t)(w[u] >> (8 * k));
         }
     }
+}
+
+// Step 3 of a frame with a checksum: the XXH64 chain (46 cycles per 32-byte stripe, strictly serial through the frame) is the
+// longest thing left in the in-order stage, so it runs BESIDE the gather: wavefronts 0, 1 and 3 gather in ascending steps
+// of kResStep bytes and publish their progress (S.res_prog), wavefront 2 hashes behind the slowest of them.
+constexpr uint32_t kResU = 8;                          // dwords per lane and step (4 and 16 measured: no better)
+constexpr uint32_t kResStepDw = 3 * 64 * kResU;        // dwords per step of the three gathering wavefronts
+constexpr uint32_t kResStep = kResStepDw * 4;          // bytes
+__device__ __noinline__ void resolve_gather3(const uint32_t* map, uint32_t B, const uint8_t* lit, uint8_t* dst, uint64_t out0, int gw, int lane) {
+    const uint4* const m4 = reinterpret_cast<const uint4*>(map);
+    const uint8_t* const hist = dst + out0 - 1;
+    uint8_t* const o = dst + out0;
+    const uint32_t n4 = (B + 3) / 4;
+    auto byte_of = [&](uint32_t e) -> uint32_t {
+        const uint32_t ix = e & kResIdx;
+        return (e & kResLit) ? (uint32_t)lit[ix] : (uint32_t)*(hist - ix);
+    };
+    uint32_t step = 0;
+    for (uint32_t q0 = (uint32_t)gw * 64 + (uint32_t)lane; q0 - ((uint32_t)gw * 64 + (uint32_t)lane) < n4; q0 += kResStepDw, step++) {
+        uint4 v[kResU];
+#pragma unroll
+        for (uint32_t u = 0; u < kResU; u++) { const uint32_t q = q0 + u * 192; v[u] = q < n4 ? m4[q] : make_uint4(kResLit, kResLit, kResLit, kResLit); }
+        uint32_t w[kResU];
+#pragma unroll
+        for (uint32_t u = 0; u < kResU; u++) w[u] = byte_of(v[u].x) | (byte_of(v[u].y) << 8) | (byte_of(v[u].z) << 16) | (byte_of(v[u].w) << 24);
+#pragma unroll
+        for (uint32_t u = 0; u < kResU; u++) {
+            const uint32_t p = (q0 + u * 192) * 4;
+            if (p + 4 <= B) __builtin_memcpy(o + p, &w[u], 4);
+            else for (uint32_t k = 0; p + k < B; k++) o[p + k] = (uint8_t)(w[u] >> (8 * k));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // this step's bytes have landed
+        if (lane == 0) flag_store(&S.res_prog[gw], step + 1);
+    }
+}
+// wavefront 2 beside resolve_gather3: hashes the block's bytes as the steps complete.  fp: the frame's first byte;
+// rel0 = out0 - frame start.  false: a wait ran out (the launch is broken).
+__device__ __noinline__ bool resolve_hash_behind(uint64_t& xv, uint64_t& xstripes, const uint8_t* fp, uint64_t rel0, uint32_t B, int lane) {
+    const uint32_t nsteps = ((B + 3) / 4 + kResStepDw - 1) / kResStepDw;
+    for (uint32_t it = 0; it < (1u << 24); it++) {
+        const uint32_t p0 = flag_load(&S.res_prog[0]), p1 = flag_load(&S.res_prog[1]), p2 = flag_load(&S.res_prog[2]);
+        const uint32_t p = p0 < p1 ? (p0 < p2 ? p0 : p2) : (p1 < p2 ? p1 : p2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const bool fin = p >= nsteps;
+        const uint64_t ready = fin ? (uint64_t)B : (uint64_t)p * kResStep;
+        uint64_t upto = (rel0 + ready) / 32;
+        if (!fin) upto = upto >= xstripes + 64 ? xstripes + ((upto - xstripes) & ~7ull) : xstripes; // >= 2 KiB at a time, whole groups of 8 stripes
+        if (upto > xstripes) xxh_advance(xv, xstripes, upto, fp, lane);
+        else if (!fin) __builtin_amdgcn_s_sleep(8);
+        if (fin) return true;
+    }
+    return false;
 }

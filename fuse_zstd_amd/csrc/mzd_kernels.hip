@@ -516,18 +516,29 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                     pred_loaded = true;
                     TFIN(9);
                     if (!perr && B <= cap - out0 && reach <= out0 - fstart0) {
-                        if (t) g_acquire(); // the predecessors' output (another XCD's L2 may have held it)
-                        resolve_gather(map, B, lit_type == 0 ? src + lit_off : lit_buf, dst, out0, tid);
-                        wg_fence();
-                        if (tid == 0) { c.out = out0 + B; c.pos = pos0 + bsize; }
-                        __syncthreads();
-                        TFIN(1);
-                        if (wave == 2 && hashing) { // K7: this block's stripes (the state travels from task to task)
-                            xv = frame_first ? xxh_init(lane) : c.pred_xxh[lane & 3];
-                            xstripes = frame_first ? 0 : c.pred_xstripes;
-                            xxh_advance(xv, xstripes, (out0 + B - fstart0) / 32, dst + fstart0, lane);
-                            TFIN(2);
+                        // the predecessors' output (another XCD's L2 may have held it).  (Agent-scope byte loads instead of the fence --
+                        // to keep the map and the literals in this XCD's L2 -- were measured: 2.6x slower, every byte a memory request.)
+                        if (t) g_acquire();
+                        const uint8_t* const lits = lit_type == 0 ? src + lit_off : lit_buf;
+                        if (hashing) { // K7 beside the gather: wavefront 2 hashes behind the other three (the state travels from task to task)
+                            if (tid < 3) S.res_prog[tid] = 0;
+                            __syncthreads();
+                            if (wave == 2) {
+                                xv = frame_first ? xxh_init(lane) : c.pred_xxh[lane & 3];
+                                xstripes = frame_first ? 0 : c.pred_xstripes;
+                                if (!resolve_hash_behind(xv, xstripes, dst + fstart0, out0 - fstart0, B, lane) && lane == 0) post_err(&c.err, MZD_E_DEVICE);
+                                TFIN(2);
+                            } else {
+                                resolve_gather3(map, B, lits, dst, out0, wave == 3 ? 2 : wave, lane);
+                                if (wave == 0) TFIN(1);
+                            }
+                        } else {
+                            resolve_gather(map, B, lits, dst, out0, tid);
+                            wg_fence();
+                            TFIN(1);
                         }
+                        __syncthreads();
+                        if (tid == 0) { c.out = out0 + B; c.pos = pos0 + bsize; }
                         if (a.debug && tid == 0) {
                             DebugSlot& ds = a.debug[a.wg0 + blockIdx.x];
                             ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0; ds.lit_raw_ptr = (uint64_t)(uintptr_t)(lit_type == 0 ? src + lit_off : lit_buf);
