@@ -490,7 +490,7 @@ def main():
                 others[name] = {"workload": ow.desc, "files": ow.nfiles, "value": round(ow.U * steps / el / GIB, 3), "unit": "GiB/s",
                                 "files_per_s": round(ow.nfiles * steps / el), "ms_per_step": round(el / steps * 1e3, 4), "kernel_ms": round(kms, 4),
                                 "kernel": kernel_name(ow.cp), "roofline_frac": round(ach / HBM_PEAK_GBS, 5), "achieved_GBps": round(ach, 2),
-                                "algorithmic_bytes_per_launch": ow.C + ow.U, "buffer_sets_rotated": ow.nsets, "byte_exact": True, "steps": steps}
+                                "algorithmic_bytes_per_launch": ow.C + ow.U, "traffic": recorded_traffic(name), "buffer_sets_rotated": ow.nsets, "byte_exact": True, "steps": steps}
                 if name == "cfg4" and not args.no_t2:
                     others[name]["t2_end_to_end"] = t2_end_to_end(ow, mzd, reps=3)
                 ow.free()
