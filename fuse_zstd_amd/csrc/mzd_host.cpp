@@ -489,8 +489,22 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
     // straight from / into the caller's memory?  Only when it is pinned and the runs are few (a copy call costs microseconds)
     const auto few_runs = [&](const Layout& L) { return L.run_dev.size() <= std::max<size_t>(8, n / 64); };
     auto pinned = [&](const Layout& L, bool input) {
-        bool reg = true; // every buffer inside an mzd_host_alloc allocation?
-        for (size_t k = 0; k < n && reg; k++) reg = input ? in_pinned_registry(jobs[idx[k]].src, jobs[idx[k]].src_len) : in_pinned_registry(jobs[idx[k]].dst, jobs[idx[k]].dst_cap);
+        bool reg = true; // every buffer inside an mzd_host_alloc allocation?  (one lock; consecutive buffers mostly share an allocation)
+        {
+            std::lock_guard<std::mutex> lk(g_pin_mu);
+            uintptr_t lo = 1, hi = 0; // the allocation the previous buffer was found in
+            for (size_t k = 0; k < n && reg; k++) {
+                const uintptr_t p = (uintptr_t)(input ? (const void*)jobs[idx[k]].src : (const void*)jobs[idx[k]].dst);
+                const size_t len = input ? jobs[idx[k]].src_len : jobs[idx[k]].dst_cap;
+                if (len == 0) continue;
+                if (p >= lo && p + len <= hi) continue;
+                auto it = g_pinned.upper_bound(p);
+                if (!p || it == g_pinned.begin()) { reg = false; break; }
+                --it;
+                lo = it->first; hi = it->first + it->second;
+                reg = p + len <= hi;
+            }
+        }
         if (reg) return true;
         if (!few_runs(L)) return false; // memory pinned by other means: asked of the runtime, run by run
         for (size_t r = 0; r < L.run_dev.size(); r++)
@@ -573,6 +587,11 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         plans[c] = make_plan(st->h_jobs + cut[c], cut[c + 1] - cut[c], st->h_lists + 2 * cut[c], d.lane[0].nwg);
         any_small = any_small || plans[c].nsmall != 0;
     }
+    // One chunk with more block tasks than a lane has workgroup slots (a single big file): the whole device instead of a
+    // quarter of it (the call then waits until no other launch is in flight, like a call on device pointers).
+    constexpr int kWholeLane = -2;
+    const bool use_whole = nchunks == 1 && plans[0].blocks > d.lane[0].nwg;
+    if (use_whole) { plans[0] = make_plan(st->h_jobs, n, st->h_lists, d.max_wg); any_small = plans[0].nsmall != 0; }
     {
         hipError_t e = hipMemcpyAsync(st->d_jobs, st->h_jobs, n * sizeof(DevJob), hipMemcpyHostToDevice, d.copy_in);
         if (e == hipSuccess && any_small) e = hipMemcpyAsync(st->d_lists, st->h_lists, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, d.copy_in);
@@ -586,10 +605,11 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         if (e == hipSuccess) e = hipEventCreate(&k.k1);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&k.done, hipEventDisableTiming);
         if (e != hipSuccess) { result = MZD_E_DEVICE; break; }
-        const int ln = lane_begin(d, submitted != 0);
+        int ln = kWholeLane;
+        if (use_whole) take_whole(d); else ln = lane_begin(d, submitted != 0);
         k.lane = ln;
         submitted = c + 1;
-        Lane& l = d.lane[ln];
+        Lane& l = use_whole ? d.whole : d.lane[ln];
         const Plan& p = plans[c];
         int erc = MZD_OK;
         // inputs
@@ -633,7 +653,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
     }
     if (result != MZD_OK) { // something could not be submitted: let what is in flight finish, report the failure
         hipStreamSynchronize(d.copy_in);
-        for (size_t c = 0; c < submitted; c++) hipStreamSynchronize(d.lane[ch[c].lane].stream);
+        for (size_t c = 0; c < submitted; c++) hipStreamSynchronize(ch[c].lane == kWholeLane ? d.whole.stream : d.lane[ch[c].lane].stream);
         hipStreamSynchronize(d.copy_out);
     }
     float ms_sum = 0.f;
@@ -645,6 +665,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
             if (result == MZD_OK && hipEventElapsedTime(&ms, k.k0, k.k1) == hipSuccess) ms_sum += ms;
         }
         if (k.lane >= 0) lane_end(d, k.lane);
+        else if (k.lane == kWholeLane) give_whole(d);
         if (k.in) hipEventDestroy(k.in);
         if (k.k0) hipEventDestroy(k.k0);
         if (k.k1) hipEventDestroy(k.k1);

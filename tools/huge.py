@@ -1,3 +1,5 @@
+"""Diagnostic: a few very big files through the host path under each driver (1 a workgroup per file, 5 / 4 block tasks without /
+with blocks resolved ahead, 0 the library's own choice).  Kernel time only (PCIe excluded)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fuse_zstd_amd as mzd, corpus
@@ -5,7 +7,7 @@ mzd.init()
 for kind, size, n in (("json", 64 << 20, 1), ("text", 16 << 20, 4), ("xray", 32 << 20, 2)):
     cp = corpus.build_corpus(kind, 31, [size] * n)
     srcs = [cp.comp_file(i).tobytes() for i in range(n)]
-    for drv in ("1", "2"):
+    for drv in ("1", "5", "4", "0"):
         mzd.set_driver(int(drv))
         res = mzd.decode_batch(srcs, [size] * n)
         ok = all(st == 0 and out == cp.raw_file(i).tobytes() for i, (st, out) in enumerate(res))
