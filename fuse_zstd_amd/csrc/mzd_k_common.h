@@ -47,6 +47,7 @@ struct Ctl {
     uint64_t pred_out, pred_frame_out0, pred_xstripes, pred_xxh[4];
 };
 
+constexpr uint32_t kResSymMax = 30;
 struct __attribute__((aligned(16))) Shared {
     uint8_t ring[kRingBytes + 16]; // first: at LDS offset 0 the walker's window address needs no base add
     // FSE decode entries, 8 bytes: low dword = byte offset of the next state's entry before the
@@ -77,6 +78,7 @@ struct __attribute__((aligned(16))) Shared {
     uint32_t res[4];             // mzd_k_resolve.h: bad offset seen, farthest reach before the block, a round left entries open; [3] spare
     uint32_t res_rep[3];         // ... the repeat offsets the task starts with (rep_hop)
     uint32_t res_prog[3];        // ... steps the three gathering wavefronts have completed (resolve_gather3)
+    uint32_t res_nsym, res_sym[kResSymMax]; // ... chunks left out by the build that follows the planner: they hold offsets still symbolic
     uint32_t pre_job, pre_valid; // the job taken ahead (kNoJob: none) and whether c2 holds its parsed first block
     // driver 1: the small fields of the dictionary the workgroup used last (config 5: every file names the same one --
     // reading them from HBM again for each file costs a round trip per dependent load)
@@ -86,6 +88,7 @@ struct __attribute__((aligned(16))) Shared {
 
 // The workgroup's LDS image.  File scope, so that every device function addresses it with DS
 // instructions and immediate offsets (a `Shared&` parameter would be a flat pointer).
+static_assert(sizeof(Shared) <= 40 * 1024, "four workgroups per CU");
 __shared__ Shared S;
 
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }

@@ -258,6 +258,10 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
     __builtin_amdgcn_s_setprio(0);
     if (wave == 1) TFIN(4);
     }
+    if (phase == 1) { // a resolving task: these two wavefronts build the block's byte map behind the planner (mzd_k_resolve.h)
+        if (r.get_seq() && r.nseq) resolve_build_follow(a.resolve_map + (size_t)(a.wg0 + blockIdx.x) * kResMapStride, b.seqs, b.walk, r.nseq, (uint32_t)(wave - 1), lane);
+        return;
+    }
     if (!(phase & 2)) return;
     if (wave == 1) { // the copying half of K5
         uint64_t opos = b.out0;
@@ -354,6 +358,7 @@ __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const Bloc
         c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = TASKS ? 0 : b.out0;
         c.next_stream = 0; c.streams_done = 0; c.streams_mask = 0;
         c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.plan_too_long = 0; c.seq_parsed = 0;
+        S.res[0] = 0; S.res[1] = 0; S.res_nsym = 0;
         c.rep_op[0] = 0 | (1 << 2) | (2 << 4); c.rep_op[1] = 0; c.rep_op[2] = 0; c.rep_op[3] = 0; // identity: a block without sequences
         if (!b.block_pre) parse_literals(c, S.stage, b.bsize);
     }

@@ -22,74 +22,115 @@ constexpr uint32_t kResPrev = 0x40000000u;  // map entry: output older than the 
 constexpr uint32_t kResIdx = 0x3FFFFFFFu;
 constexpr uint32_t kResRounds = 24;         // > log2(128 Ki) + slack (reads race with writes of the same round, which only helps)
 
-// Step 1, all four wavefronts (chunks of 64 sequences dealt round-robin; lane = sequence).  cbase[k] = {output, literals}
-// before chunk k (plan_wave).  Leaves in S.res: [0] != 0 an offset of 0 was seen (the copier must give the verdict),
-// [1] the largest distance any match reaches before the block start.
-__device__ __noinline__ void resolve_build(uint32_t* map, const uint4* plan, const uint4* cbase, uint32_t nseq_in, uint32_t out_seqs, uint32_t lit_used,
-                                           uint32_t nlit, uint32_t rep0, uint32_t rep1, uint32_t rep2, uint4* plan_wb, int lane, int wave) {
-    const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
-    const uint32_t nchunks = (nseq + 63) / 64;
-    uint32_t bad = 0, maxprev = 0;
-    for (uint32_t chunk = (uint32_t)wave; chunk < nchunks; chunk += 4) {
-        const uint32_t i = chunk * 64 + (uint32_t)lane;
-        const bool valid = i < nseq;
-        const uint4 pe = valid ? plan[i] : make_uint4(0, 0, 1, 0);
-        const uint4 cb = cbase[chunk];
-        const uint32_t ll = pe.x, ml = pe.y, ex_t = pe.w;
-        uint32_t off = pe.z;
-        if (off & kOffTag) { // start slot + delta (plan_wave): the chain has delivered the start offsets
+// Step 1, lane = sequence, a chunk of 64 sequences per call.  cbase[k] = {output, literals} before chunk k (plan_wave).
+// Returns false -- and writes nothing -- when the chunk holds an offset that is still symbolic and `rep_known` is not set.
+// bad: an offset of 0 was seen (the copier must give the verdict); maxprev: the largest distance a match reaches before the
+// block start.
+__device__ __forceinline__ bool resolve_build_chunk(uint32_t* map, const uint4* plan, const uint4* cbase, uint32_t chunk, uint32_t nseq, bool rep_known,
+                                                    uint32_t rep0, uint32_t rep1, uint32_t rep2, uint4* plan_wb, int lane, uint32_t& bad, uint32_t& maxprev) {
+    const uint32_t i = chunk * 64 + (uint32_t)lane;
+    const bool valid = i < nseq;
+    const uint4 pe = valid ? plan[i] : make_uint4(0, 0, 1, 0);
+    uint32_t off = pe.z;
+    if (__any(valid && (off & kOffTag) != 0)) { // start slot + delta (plan_wave)
+        if (!rep_known) return false;
+        if (off & kOffTag) {
             off = (uint32_t)sel3((off >> 29) & 3, (int32_t)rep0, (int32_t)rep1, (int32_t)rep2) + (off & 0x1FFFFFFFu) - (uint32_t)kOffBias;
             if (plan_wb && valid) plan_wb[i].z = off;
         }
-        const uint32_t p_l = cb.x + ex_t, p_m = p_l + ll;
-        const uint32_t li = cb.y + (wave_incl_scan(ll, lane) - ll);
-        if (valid && (off == 0 || off >= (1u << 30))) bad = 1;
-        if (valid && ml && off > p_m) { const uint32_t d = off - p_m; maxprev = d > maxprev ? d : maxprev; }
-        // short pieces: every lane its own, four entries per store (16 bytes, 4-byte aligned), as many steps as the longest needs
-        typedef __attribute__((address_space(1))) uint32_t* gmap;
-        auto ent = [&](uint32_t pos) -> uint32_t { const int32_t q = (int32_t)pos - (int32_t)off; return q >= 0 ? (uint32_t)q : (kResPrev | (uint32_t)(-q - 1)); };
-        {
-            const uint32_t n = (valid && ll <= 64) ? ll : 0;
-            gmap const m = (gmap)(map + p_l);
-            for (uint32_t k = 0; __any(k < n); k += 4) {
-                const uint32_t e = kResLit | (li + k);
-                if (k + 4 <= n) { const uint4 v = make_uint4(e, e + 1, e + 2, e + 3); __builtin_memcpy(m + k, &v, 16); }
-                else if (k < n) { m[k] = e; if (k + 1 < n) m[k + 1] = e + 1; if (k + 2 < n) m[k + 2] = e + 2; }
-            }
-        }
-        {
-            const uint32_t n = (valid && ml <= 64) ? ml : 0;
-            gmap const m = (gmap)(map + p_m);
-            for (uint32_t k = 0; __any(k < n); k += 4) {
-                const uint32_t e0 = ent(p_m + k), e1 = ent(p_m + k + 1), e2 = ent(p_m + k + 2), e3 = ent(p_m + k + 3);
-                if (k + 4 <= n) { const uint4 v = make_uint4(e0, e1, e2, e3); __builtin_memcpy(m + k, &v, 16); }
-                else if (k < n) { m[k] = e0; if (k + 1 < n) m[k + 1] = e1; if (k + 2 < n) m[k + 2] = e2; }
-            }
-        }
-        // long pieces: one after the other, by the whole wavefront
-        uint64_t lm = __ballot(valid && ll > 64);
-        while (lm) {
-            const int sl = __builtin_ctzll(lm);
-            const uint32_t n = __builtin_amdgcn_readlane(ll, sl), p = __builtin_amdgcn_readlane(p_l, sl), l0 = __builtin_amdgcn_readlane(li, sl);
-            for (uint32_t k = (uint32_t)lane; k < n; k += 64) map[p + k] = kResLit | (l0 + k);
-            lm &= lm - 1;
-        }
-        uint64_t mm = __ballot(valid && ml > 64);
-        while (mm) {
-            const int sl = __builtin_ctzll(mm);
-            const uint32_t n = __builtin_amdgcn_readlane(ml, sl), p = __builtin_amdgcn_readlane(p_m, sl), o = __builtin_amdgcn_readlane(off, sl);
-            for (uint32_t k = (uint32_t)lane; k < n; k += 64) { const int32_t q = (int32_t)(p + k) - (int32_t)o; map[p + k] = q >= 0 ? (uint32_t)q : (kResPrev | (uint32_t)(-q - 1)); }
-            mm &= mm - 1;
+    }
+    const uint4 cb = cbase[chunk];
+    const uint32_t ll = pe.x, ml = pe.y, ex_t = pe.w;
+    const uint32_t p_l = cb.x + ex_t, p_m = p_l + ll;
+    const uint32_t li = cb.y + (wave_incl_scan(ll, lane) - ll);
+    if (valid && (off == 0 || off >= (1u << 30))) bad = 1;
+    if (valid && ml && off > p_m) { const uint32_t d = off - p_m; maxprev = d > maxprev ? d : maxprev; }
+    // short pieces: every lane its own, four entries per store (16 bytes, 4-byte aligned), as many steps as the longest needs
+    typedef __attribute__((address_space(1))) uint32_t* gmap;
+    auto ent = [&](uint32_t pos) -> uint32_t { const int32_t q = (int32_t)pos - (int32_t)off; return q >= 0 ? (uint32_t)q : (kResPrev | (uint32_t)(-q - 1)); };
+    {
+        const uint32_t n = (valid && ll <= 64) ? ll : 0;
+        gmap const m = (gmap)(map + p_l);
+        for (uint32_t k = 0; __any(k < n); k += 4) {
+            const uint32_t e = kResLit | (li + k);
+            if (k + 4 <= n) { const uint4 v = make_uint4(e, e + 1, e + 2, e + 3); __builtin_memcpy(m + k, &v, 16); }
+            else if (k < n) { m[k] = e; if (k + 1 < n) m[k + 1] = e + 1; if (k + 2 < n) m[k + 2] = e + 2; }
         }
     }
+    {
+        const uint32_t n = (valid && ml <= 64) ? ml : 0;
+        gmap const m = (gmap)(map + p_m);
+        for (uint32_t k = 0; __any(k < n); k += 4) {
+            const uint32_t e0 = ent(p_m + k), e1 = ent(p_m + k + 1), e2 = ent(p_m + k + 2), e3 = ent(p_m + k + 3);
+            if (k + 4 <= n) { const uint4 v = make_uint4(e0, e1, e2, e3); __builtin_memcpy(m + k, &v, 16); }
+            else if (k < n) { m[k] = e0; if (k + 1 < n) m[k + 1] = e1; if (k + 2 < n) m[k + 2] = e2; }
+        }
+    }
+    // long pieces: one after the other, by the whole wavefront
+    uint64_t lm = __ballot(valid && ll > 64);
+    while (lm) {
+        const int sl = __builtin_ctzll(lm);
+        const uint32_t n = __builtin_amdgcn_readlane(ll, sl), p = __builtin_amdgcn_readlane(p_l, sl), l0 = __builtin_amdgcn_readlane(li, sl);
+        for (uint32_t k = (uint32_t)lane; k < n; k += 64) map[p + k] = kResLit | (l0 + k);
+        lm &= lm - 1;
+    }
+    uint64_t mm = __ballot(valid && ml > 64);
+    while (mm) {
+        const int sl = __builtin_ctzll(mm);
+        const uint32_t n = __builtin_amdgcn_readlane(ml, sl), p = __builtin_amdgcn_readlane(p_m, sl), o = __builtin_amdgcn_readlane(off, sl);
+        for (uint32_t k = (uint32_t)lane; k < n; k += 64) { const int32_t q = (int32_t)(p + k) - (int32_t)o; map[p + k] = q >= 0 ? (uint32_t)q : (kResPrev | (uint32_t)(-q - 1)); }
+        mm &= mm - 1;
+    }
+    return true;
+}
+__device__ __forceinline__ void resolve_build_post(uint32_t bad, uint32_t maxprev, int lane) { // a wavefront's findings -> S.res[0], S.res[1]
+    if (__any(bad != 0) && lane == 0) __atomic_fetch_or(&S.res[0], 1u, __ATOMIC_RELAXED);
+    for (int sh = 32; sh; sh >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxprev, sh); maxprev = o > maxprev ? o : maxprev; }
+    if (lane == 0) __atomic_fetch_max(&S.res[1], maxprev, __ATOMIC_RELAXED);
+}
+
+// Step 1 BEHIND THE PLANNER, by the two wavefronts that have nothing to do while the block's chain is walked (the copying
+// and the hashing one; which = 0 / 1): chunk after chunk as the plan is published.  A chunk with a symbolic offset (the
+// block's first sequences, typically) is noted in S.res_sym and left to resolve_build_rest.  Ends when every chunk is
+// built, or the planner has finished without publishing the chunk (it failed or cut the plan: the caller falls back).
+__device__ __noinline__ void resolve_build_follow(uint32_t* map, const uint4* plan, const uint4* cbase, uint32_t nseq_in, uint32_t which, int lane) {
+    const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
+    const uint32_t nchunks = (nseq + 63) / 64;
+    uint32_t bad = 0, maxprev = 0;
+    for (uint32_t chunk = which; chunk < nchunks; chunk += 2) {
+        bool have = false;
+        for (uint32_t it = 0; it < (1u << 24); it++) { // chunk `chunk` is public once the planner has started on chunk + 1 (or has finished)
+            const uint32_t pg = flag_load(&S.c.plan_prog);
+            if ((pg & ~kPlanFin) > chunk) { have = true; break; }
+            if (pg & kPlanFin) { have = (pg & ~kPlanFin) > chunk && !__atomic_load_n(&S.c.err, __ATOMIC_RELAXED) && !__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED); break; }
+            if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!have) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (!resolve_build_chunk(map, plan, cbase, chunk, nseq, false, 0, 0, 0, nullptr, lane, bad, maxprev) && lane == 0) {
+            const uint32_t at = __atomic_fetch_add(&S.res_nsym, 1u, __ATOMIC_RELAXED);
+            if (at < kResSymMax) S.res_sym[at] = chunk;
+        }
+    }
+    resolve_build_post(bad, maxprev, lane);
+}
+// ... and what it left, once the repeat offsets the block starts with are known (all four wavefronts, after a barrier): the
+// noted chunks (all chunks if there were more than the list holds), the literals behind the last sequence, the padding.
+__device__ __noinline__ void resolve_build_rest(uint32_t* map, const uint4* plan, const uint4* cbase, uint32_t nseq_in, uint32_t out_seqs, uint32_t lit_used,
+                                                uint32_t nlit, uint32_t rep0, uint32_t rep1, uint32_t rep2, uint4* plan_wb, int lane, int wave) {
+    const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
+    const uint32_t nchunks = (nseq + 63) / 64;
+    const uint32_t nsym = S.res_nsym;
+    uint32_t bad = 0, maxprev = 0;
+    if (nsym > kResSymMax) { for (uint32_t chunk = (uint32_t)wave; chunk < nchunks; chunk += 4) resolve_build_chunk(map, plan, cbase, chunk, nseq, true, rep0, rep1, rep2, plan_wb, lane, bad, maxprev); }
+    else for (uint32_t k = (uint32_t)wave; k < nsym; k += 4) resolve_build_chunk(map, plan, cbase, S.res_sym[k], nseq, true, rep0, rep1, rep2, plan_wb, lane, bad, maxprev);
     if (wave == 0) { // the literals behind the last sequence, and the padding up to a whole 16 bytes of entries
         const uint32_t rest = nlit - lit_used;
         for (uint32_t k = (uint32_t)lane; k < rest; k += 64) map[out_seqs + k] = kResLit | (lit_used + k);
         if (lane < 4) map[out_seqs + rest + (uint32_t)lane] = kResLit;
     }
-    if (__any(bad != 0) && lane == 0) __atomic_fetch_or(&S.res[0], 1u, __ATOMIC_RELAXED);
-    for (int sh = 32; sh; sh >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxprev, sh); maxprev = o > maxprev ? o : maxprev; }
-    if (lane == 0) __atomic_fetch_max(&S.res[1], maxprev, __ATOMIC_RELAXED);
+    resolve_build_post(bad, maxprev, lane);
 }
 
 // Step 2, all 256 threads (workgroup barriers inside).  true: no entry refers to the block any more.

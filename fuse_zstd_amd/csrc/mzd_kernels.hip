@@ -148,8 +148,8 @@ __device__ __noinline__ bool rep_hop(FileState* fs, uint32_t t, bool frame_first
 }
 
 
-#include "mzd_k_pipeline.h"
 #include "mzd_k_resolve.h"
+#include "mzd_k_pipeline.h"
 
 // ---- driver 1: one workgroup decodes a whole file, block after block.  Used when no file of the launch can have more
 // than one block (every output capacity <= 128 KiB): nothing is forked, nothing is published, the file's state
@@ -490,7 +490,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
             if (resolving && started) {
                 __syncthreads(); // walk, plan and literals are complete (every role has returned); nothing of the block has been written yet
                 TFIN(7); // (diagnostic builds: the resolve timeline reuses the literal-side slots 7, 8, 4 and the copier's 9, 1, 2)
-                if (tid == 0) { S.res[0] = 0; S.res[1] = 0; } // (the planning wavefront has passed the repeat-offset chain on: S.res_rep, S.res[3])
+                // (the planning wavefront has passed the repeat-offset chain on: S.res_rep, S.res[3]; the copying and the hashing wavefront
+                //  have built the map behind the planner, but for the chunks with symbolic offsets: S.res_sym)
                 uint32_t nseq = 0, nlit = 0, pout = 0, lused = 0, too_long = 0, lit_type = 0, r0 = 0, r1 = 0, r2 = 0, hop_ok = 0;
                 uint64_t lit_off = 0;
                 WG_SNAPSHOT(err = c.err; nseq = c.nseq; nlit = c.nlit; pout = c.plan_out; lused = c.plan_lit_used; too_long = c.plan_too_long; lit_type = c.lit_type;
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                 const uint32_t B = pout + (nlit - lused);
                 bool ok = !err && hop_ok && nseq != 0 && !too_long && lused <= nlit && B <= kBlockMax;
                 if (ok) {
-                    resolve_build(map, seqs, walk, nseq, pout, lused, nlit, r0, r1, r2, a.debug ? seqs : nullptr, lane, wave);
+                    resolve_build_rest(map, seqs, walk, nseq, pout, lused, nlit, r0, r1, r2, a.debug ? seqs : nullptr, lane, wave);
                     wg_fence();
                     uint32_t bad = 0;
                     WG_SNAPSHOT(bad = S.res[0]);
