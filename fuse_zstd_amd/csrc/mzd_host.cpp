@@ -250,6 +250,7 @@ struct Plan {
     uint32_t lit_stride = 0;   // literal scratch per small file: largest capacity + 64
     uint32_t big_tasks = 0;    // workgroups worth launching for the files that are not small
     uint64_t blocks = 0;       // block tasks of those files, estimated from their capacities
+    uint32_t nmulti = 0;       // ... how many of them can have more than one block
 };
 // lists: [0, njobs) small list (job indices sorted by dictionary), [njobs, 2 njobs) job list of the general driver
 Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_wg) {
@@ -276,7 +277,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
             maxcap = std::max<size_t>(maxcap, j.dst_cap);
         } else {
             big[p.nbig++] = (uint32_t)i;
-            if (j.dst_cap > kBlockMax) p.multi = true;
+            if (j.dst_cap > kBlockMax) { p.multi = true; p.nmulti++; }
             p.blocks += 1 + j.dst_cap / kBlockMax;
             if (tasks < max_wg) tasks += 1 + j.src_len / 2048;
         }
@@ -313,7 +314,8 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     // few tasks for the lane's workgroups: the in-order copy stage is the critical path -- resolve blocks ahead (mzd_k_resolve.h)
     const int force = g_force_driver.load(std::memory_order_relaxed);
     ka.resolve_map = d.resolve_map;
-    ka.resolve = use_tasks && force != 5 && (force == 4 || p.blocks <= 4ull * l.nwg) ? 1u : 0u; // (measured crossover on cfg4lu: ~5 blocks per workgroup slot)
+    ka.resolve = use_tasks && force != 5 && (force == 4 || p.blocks <= 4ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : 0u; // (measured crossover on cfg4lu: ~5 blocks per
+    // workgroup slot; and a few very big files are chains however many blocks they have)
     HIPCHK(hipMemsetAsync(l.counter, 0, kCounterWords * sizeof(uint32_t), s));
     HIPCHK(hipEventRecord(ev0, s));
     uint32_t grid;
@@ -396,14 +398,63 @@ int run_device_jobs(Device& d, mzd_job* jobs, size_t njobs, hipStream_t s) {
 // ---- the host path ------------------------------------------------------------------------------------------------
 // The staging copies (user buffers <-> pinned memory) are memory-bound host work: split over a few threads (one thread
 // moves ~10 GB/s; the PCIe link ~50).  fn(k) handles piece k of [0, n).
+std::atomic<unsigned> g_copy_threads{8};        // host threads of the staging copies (mzd_debug_host_path 3)
+// A small pool of persistent workers (spawning threads per copy cost more than the copies of a 24 MB chunk and made the
+// host path's time jump from call to call).  One loop at a time; a caller that finds the pool busy -- another call's copy --
+// runs its loop alone.  Pieces are handed out by a counter; the caller works too.
+class CopyPool {
+public:
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_work_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void run(size_t n, unsigned want, const std::function<void(size_t)>& fn) {
+        std::unique_lock<std::mutex> own(run_mu_, std::try_to_lock);
+        if (!own.owns_lock() || want <= 1) { for (size_t k = 0; k < n; k++) fn(k); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while (th_.size() + 1 < want) th_.emplace_back([this] { worker(); });
+            fn_ = &fn; n_ = n; next_.store(0); active_ = 0; helpers_ = std::min<size_t>(want - 1, th_.size()); gen_++;
+        }
+        cv_work_.notify_all();
+        for (size_t k; (k = next_.fetch_add(1)) < n;) fn(k);
+        std::unique_lock<std::mutex> lk(mu_);
+        helpers_ = 0; // (workers that have not started on this loop stay out)
+        cv_done_.wait(lk, [this] { return active_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void worker() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return stop_ || (gen_ != seen && helpers_ > 0); });
+            if (stop_) return;
+            seen = gen_; helpers_--; active_++;
+            const std::function<void(size_t)>* fn = fn_;
+            const size_t n = n_;
+            lk.unlock();
+            for (size_t k; (k = next_.fetch_add(1)) < n;) (*fn)(k);
+            lk.lock();
+            if (--active_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::mutex run_mu_, mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> th_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0, helpers_ = 0, active_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+CopyPool g_pool;
 template <class F>
 void parallel_for(size_t n, size_t total_bytes, F fn) {
-    unsigned want = total_bytes < (4u << 20) ? 1u : std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    unsigned want = total_bytes < (4u << 20) ? 1u : std::min<unsigned>(g_copy_threads.load(std::memory_order_relaxed), std::max(1u, std::thread::hardware_concurrency() / 2));
     if (want <= 1 || n < 2 * want) { for (size_t k = 0; k < n; k++) fn(k); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < want; t++)
-        th.emplace_back([=]() { for (size_t k = n * t / want; k < n * (t + 1) / want; k++) fn(k); });
-    for (auto& x : th) x.join();
+    g_pool.run(n, want, std::function<void(size_t)>(fn));
 }
 // one big copy, split by bytes
 void parallel_memcpy(uint8_t* d, const uint8_t* s, size_t n) {
@@ -763,6 +814,7 @@ int mzd_device_count(void) {
 int mzd_debug_host_path(int device, int what, int value) {
     (void)device;
     if (what == 2) { g_direct_chunks.store(value < 1 ? 1 : value); return MZD_OK; }
+    if (what == 3) { g_copy_threads.store(value < 1 ? 1u : (unsigned)value); return MZD_OK; }
     return MZD_E_PARAM;
 }
 void* mzd_host_alloc(size_t n) {

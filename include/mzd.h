@@ -132,8 +132,8 @@ int mzd_debug_set_driver(int driver);
  * [3] files finished by the block-task driver, [4] small files the lane-per-file kernel handed on to the general driver,
  * [5] groups it took. */
 int mzd_debug_counters(int device, uint32_t* out8);
-/* Host-path diagnostic.  what 2: at most `value` chunks per call when the kernels mirror the outputs into pinned caller
- * memory (default 4). */
+/* Host-path diagnostics.  what 2: at most `value` chunks per call when the kernels mirror the outputs into pinned caller
+ * memory (default 4).  what 3: `value` host threads for the staging copies of pageable buffers (default 8). */
 int mzd_debug_host_path(int device, int what, int value);
 /* Diagnostic builds only (make diag / tfin): per-phase cycle sums of the workgroup that ran job 0; role finish times of
  * every workgroup slot.  In the product build they return zeros. */

@@ -21,6 +21,7 @@ else:
 jobs = api.make_jobs([src.ctypes.data + int(o) for o in cp.comp_offs], cp.comp_sizes,
                      [out.ctypes.data + int(o) for o in cp.raw_offs], cp.raw_sizes)
 L = api.lib()
+if os.environ.get('MZD_COPY_THREADS'): L.mzd_debug_host_path(0, 3, int(os.environ['MZD_COPY_THREADS']))
 if os.environ.get('MZD_DIRECT_CHUNKS'): L.mzd_debug_host_path(0, 2, int(os.environ['MZD_DIRECT_CHUNKS']))
 for rep in range(6):
     if not os.environ.get('MZD_NOZERO'): out[:end] = 0
