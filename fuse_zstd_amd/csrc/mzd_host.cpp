@@ -1089,7 +1089,7 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
 }
 
 // Diagnostic (a build with -DMZD_SMALL_STAMPS): the 8 phase stamps of the small-file kernel's workgroup 0.
-int mzd_debug_small_stamps(int device, uint64_t* out8) { // (9 values)
+int mzd_debug_small_stamps(int device, uint64_t* out8) { // (12 values)
     auto dp = get_device(device);
     if (!dp || !out8) return MZD_E_PARAM;
     WholeGuard g(*dp);

@@ -96,8 +96,13 @@ namespace mzd {
 
 // ---- inter-workgroup hand-over of the block-task driver (agent scope): a task publishes, its successor on another CU acquires
 __device__ __forceinline__ uint32_t g_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifdef MZD_EXP_NOFENCE // (experiment builds only: what the cross-XCD fences cost; results are not valid)
+__device__ __forceinline__ void g_acquire() {}
+__device__ __forceinline__ void g_release() {}
+#else
 __device__ __forceinline__ void g_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 __device__ __forceinline__ void g_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+#endif
 __device__ __forceinline__ void g_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // Agent-scope fences write back / invalidate the XCD's whole L2 (buffer_wbl2 / buffer_inv): they are kept for the one thing
 // that needs them -- the output bytes a successor on another XCD reads -- and everything small (task records, per-file

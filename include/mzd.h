@@ -138,6 +138,8 @@ int mzd_debug_host_path(int device, int what, int value);
 /* Diagnostic builds only (make diag / tfin): per-phase cycle sums of the workgroup that ran job 0; role finish times of
  * every workgroup slot.  In the product build they return zeros. */
 int mzd_debug_stamps(int device, uint64_t* out22);
+/* (a build with -DMZD_SMALL_STAMPS, `make sstamps`) the lane-per-file kernel's phase stamps: 12 values, tools/small_stamps.py */
+int mzd_debug_small_stamps(int device, uint64_t* out12);
 int mzd_debug_tfin_all(int device, uint64_t* out, int max_slots);
 
 /* Milliseconds the decode kernel of the last launch on `device` took (hipEvents on the
