@@ -1,6 +1,8 @@
 """Diagnostic: kernel time per corpus kind (N files of 128 KiB each, product library)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fuse_zstd_amd.api as _api
+if os.environ.get('MZD_AB_SO'): _api._SO = os.path.join(os.path.dirname(_api._SO), os.environ['MZD_AB_SO'])
 import fuse_zstd_amd as mzd, corpus, oracle
 mzd.init()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
