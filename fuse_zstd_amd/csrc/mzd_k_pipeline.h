@@ -15,6 +15,9 @@
 //           table area at version t, rebuilt ones published at t + 1; the copier and the hasher wait for the predecessor
 //           task (FileState::copied == t) for position, repeat offsets and XXH64 state; offsets in the plan stay symbolic.
 #pragma once
+#ifndef MZD_MIRROR_MIN
+#define MZD_MIRROR_MIN 2048 // bytes of finished output before the hashing wavefront turns to the host mirror
+#endif
 
 struct BlockArgs {
     const uint8_t* src; uint64_t n;       // the file
@@ -329,7 +332,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
                     if (upto > xstripes) { xxh_advance(xv, xstripes, upto, fp, lane); did = true; }
                 }
                 if (mirror && !(TASKS && fin)) { // (a task leaves the rest to its completion: its successor must not wait for PCIe)
-                    const uint64_t to = fin ? pos : (pos >= mirrored + 2048 ? mirrored + ((pos - mirrored) & ~1023ull) : mirrored); // >= 2 KiB at a time, whole KiB
+                    const uint64_t to = fin ? pos : (pos >= mirrored + MZD_MIRROR_MIN ? mirrored + ((pos - mirrored) & ~1023ull) : mirrored); // >= MZD_MIRROR_MIN bytes at a time, whole KiB
                     if (to > mirrored) { mirror_wave(dst, b.dst2, mirrored, to, lane); mirrored = to; did = true; }
                 }
                 if (fin) break;

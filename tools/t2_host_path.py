@@ -4,8 +4,10 @@ copy in | decode | copy out on separate streams), i.e. the PCIe-inclusive rate o
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import bench, corpus, fuse_zstd_amd as mzd
+import bench, corpus
 from fuse_zstd_amd import api
+if os.environ.get('MZD_AB_SO'): api._SO = os.path.join(os.path.dirname(api._SO), os.environ['MZD_AB_SO'])  # (another build of the library)
+import fuse_zstd_amd as mzd
 mzd.init()
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else bench.DEFAULT_FILES[wl]
