@@ -105,7 +105,9 @@ constexpr uint32_t kCounterWords = 8;
 struct KernelArgs {
     DevJob* jobs;
     uint32_t njobs;
-    uint32_t* counter;    // see above; zeroed per launch
+    uint32_t* counter;    // see above; all zero when the launch starts ...
+    uint32_t* counter_next; // ... because the launch before it on this lane cleaned it: the last workgroup to finish zeroes the block
+                          // of the NEXT launch (two blocks per lane alternate; launches of a lane run one after the other)
     uint8_t* lit_scratch; // kLitStride bytes per workgroup
     uint4* seq_scratch;   // kSeqStride uint4 per workgroup
     uint4* walk_scratch;  // kSeqStride uint4 per workgroup (state-walk records: LL, ML, OF state offsets, read head - 32)

@@ -56,7 +56,9 @@ std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 
 // them in flight; the device-pointer entry points use all of the device at once (`whole`).
 struct Lane {
     hipStream_t stream = nullptr;
-    uint32_t* counter = nullptr;  // kCounterWords
+    uint32_t* counter = nullptr;  // kCounterWords: the block of the most recent launch (one of `cnt`)
+    uint32_t* cnt[2] = {nullptr, nullptr}; // the lane's two blocks alternate: a launch's last workgroup cleans the other one (mzd_kernels.hip)
+    unsigned flip = 0;
     uint32_t wg0 = 0, nwg = 0;
     uint8_t* small_lit = nullptr;
     size_t small_lit_bytes = 0;
@@ -88,7 +90,7 @@ struct Device {
     uint8_t* small_lit = nullptr;
     uint32_t* resolve_map = nullptr; // kResMapStride words per workgroup slot (mzd_k_resolve.h)
     DebugSlot* debug = nullptr;
-    uint32_t* counters = nullptr; // (kSlots + 1) blocks of kCounterWords
+    uint32_t* counters = nullptr; // 2 x (kSlots + 1) blocks of kCounterWords
     Lane lane[kSlots];
     Lane whole;                   // the whole device (its stream is lane 0's: a whole-device launch runs when no lane is busy)
     hipStream_t copy_in = nullptr, copy_out = nullptr; // the host path's transfers: one stream per direction, shared by all calls
@@ -157,15 +159,15 @@ int init_device(Device& d, int hip_id, int index) {
     HIPCHK(hipMalloc(&d.resolve_map, (size_t)d.max_wg * kResMapStride * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&d.debug, (size_t)d.max_wg * sizeof(DebugSlot)));
     HIPCHK(hipMemset(d.debug, 0, (size_t)d.max_wg * sizeof(DebugSlot)));
-    HIPCHK(hipMalloc(&d.counters, (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
-    HIPCHK(hipMemset(d.counters, 0, (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d.counters, 2 * (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
+    HIPCHK(hipMemset(d.counters, 0, 2 * (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&d.d_dicts, sizeof(DevDict) * kMaxDicts));
     HIPCHK(hipMemset(d.d_dicts, 0, sizeof(DevDict) * kMaxDicts));
     const uint32_t share = d.max_wg / kSlots;
     for (int k = 0; k < kSlots; k++) {
         Lane& l = d.lane[k];
         HIPCHK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-        l.counter = d.counters + (size_t)k * kCounterWords;
+        l.cnt[0] = d.counters + (size_t)(2 * k) * kCounterWords; l.cnt[1] = l.cnt[0] + kCounterWords; l.counter = l.cnt[0];
         l.wg0 = (uint32_t)k * share; l.nwg = share;
         l.small_lit = d.small_lit + (size_t)k * (kSmallLitBytes / kSlots); l.small_lit_bytes = kSmallLitBytes / kSlots;
         HIPCHK(hipEventCreate(&l.ev0));
@@ -175,7 +177,7 @@ int init_device(Device& d, int hip_id, int index) {
     HIPCHK(hipStreamCreateWithFlags(&d.copy_out, hipStreamNonBlocking));
     Lane& w = d.whole;
     w.stream = d.lane[0].stream;
-    w.counter = d.counters + (size_t)kSlots * kCounterWords;
+    w.cnt[0] = d.counters + (size_t)(2 * kSlots) * kCounterWords; w.cnt[1] = w.cnt[0] + kCounterWords; w.counter = w.cnt[0];
     w.wg0 = 0; w.nwg = d.max_wg; w.small_lit = d.small_lit; w.small_lit_bytes = kSmallLitBytes;
     HIPCHK(hipEventCreate(&w.ev0));
     HIPCHK(hipEventCreate(&w.ev1));
@@ -298,7 +300,8 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
 int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, const uint32_t* d_lists, hipEvent_t ev0, hipEvent_t ev1) {
     const uint32_t njobs = p.njobs;
     KernelArgs ka;
-    ka.jobs = d_jobs; ka.njobs = njobs; ka.counter = l.counter;
+    l.counter = l.cnt[l.flip]; l.flip ^= 1u; // (clean: the lane's previous launch zeroed it; this one zeroes l.cnt[l.flip])
+    ka.jobs = d_jobs; ka.njobs = njobs; ka.counter = l.counter; ka.counter_next = l.cnt[l.flip];
     ka.lit_scratch = d.lit_scratch; ka.seq_scratch = d.seq_scratch; ka.walk_scratch = d.walk_scratch;
     ka.dicts = d.d_dicts; ka.ndicts = d.ndicts; ka.debug = d.debug; ka.job_slot0 = l.counter + 1;
     ka.job_list = nullptr; ka.nlist_fixed = 0; ka.wg0 = l.wg0;
@@ -316,7 +319,6 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     ka.resolve_map = d.resolve_map;
     ka.resolve = use_tasks && force != 5 && (force == 4 || p.blocks <= 4ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : 0u; // (measured crossover on cfg4lu: ~5 blocks per
     // workgroup slot; and a few very big files are chains however many blocks they have)
-    HIPCHK(hipMemsetAsync(l.counter, 0, kCounterWords * sizeof(uint32_t), s));
     HIPCHK(hipEventRecord(ev0, s));
     uint32_t grid;
     if (p.nsmall) {
@@ -385,8 +387,8 @@ int run_device_jobs(Device& d, mzd_job* jobs, size_t njobs, hipStream_t s) {
     if (!s) s = d.whole.stream;
     HIPCHK(hipMemcpyAsync(st->d_jobs, st->h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice, s));
     if (p.nsmall) HIPCHK(hipMemcpyAsync(st->d_lists, st->h_lists, njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    d.job0_counter = d.whole.counter;
     rc = enqueue(d, d.whole, s, st->d_jobs, p, st->d_lists, d.whole.ev0, d.whole.ev1);
+    d.job0_counter = d.whole.counter;
     if (rc) { hipStreamSynchronize(s); return rc; }
     HIPCHK(hipMemcpyAsync(st->h_jobs, st->d_jobs, njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -685,10 +687,10 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         if (e == hipSuccess) e = hipEventRecord(k.in, d.copy_in);
         if (e == hipSuccess) { // the kernels
             std::lock_guard<std::mutex> sub(l.submit_mu);
-            if (c == 0) d.job0_counter = l.counter;
             e = hipStreamWaitEvent(l.stream, k.in, 0);
             if (e == hipSuccess && d.whole_used.load(std::memory_order_relaxed)) e = hipStreamWaitEvent(l.stream, d.whole.ev1, 0); // a device-path launch may still run on a caller's stream
             if (e == hipSuccess) erc = enqueue(d, l, l.stream, st->d_jobs + c0, p, st->d_lists + 2 * c0, k.k0, k.k1);
+            if (c == 0) d.job0_counter = l.counter;
         }
         // results and outputs
         if (e == hipSuccess && erc == MZD_OK) e = hipStreamWaitEvent(d.copy_out, k.k1, 0);
@@ -937,9 +939,10 @@ int mzd_batch_launch(mzd_batch* b, void* stream) {
     Device& d = *b->dev;
     HIPCHK(hipSetDevice(d.hip_id));
     WholeGuard g(d); // (launches of one batch follow each other on `stream`; host-path launches wait for their end event)
-    d.job0_counter = d.whole.counter;
     d.whole_used.store(true, std::memory_order_relaxed);
-    return enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists, d.whole.ev0, d.whole.ev1);
+    const int rc = enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists, d.whole.ev0, d.whole.ev1);
+    d.job0_counter = d.whole.counter;
+    return rc;
 }
 
 int mzd_batch_collect(mzd_batch* b, mzd_job* jobs, void* stream) {

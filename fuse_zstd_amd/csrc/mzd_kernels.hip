@@ -156,6 +156,13 @@ __device__ __noinline__ bool rep_hop(FileState* fs, uint32_t t, bool frame_first
 #include "mzd_k_resolve.h"
 #include "mzd_k_pipeline.h"
 
+// The launch's last workgroup to finish zeroes the counter block of the lane's NEXT launch (KernelArgs::counter_next): no
+// memset between launches.  counter[6] counts the workgroups that are done.
+__device__ __forceinline__ void clean_next_counters(const KernelArgs& a, int tid) {
+    if (tid == 0 && a.counter_next && atomicAdd(&a.counter[6], 1u) == gridDim.x - 1)
+        for (uint32_t k = 0; k < kCounterWords; k++) a.counter_next[k] = 0;
+}
+
 // ---- driver 1: one workgroup decodes a whole file, block after block.  Used when no file of the launch can have more
 // than one block (every output capacity <= 128 KiB): nothing is forked, nothing is published, the file's state
 // stays in registers and LDS.
@@ -323,6 +330,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
         TFIN_FLUSH();
         __syncthreads();
     }
+    clean_next_counters(a, tid);
 }
 
 
@@ -656,6 +664,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         TFIN_FLUSH();
         __syncthreads();
     }
+    clean_next_counters(a, tid);
 }
 
 // Dictionary (A.7) -> DevDict: the entropy tables in the exact LDS layout, built once on the
