@@ -133,6 +133,69 @@ __device__ __noinline__ void resolve_build_rest(uint32_t* map, const uint4* plan
     resolve_build_post(bad, maxprev, lane);
 }
 
+// Step 2, all 256 threads (workgroup barriers inside), TILE BY TILE THROUGH LDS.  A round over the whole map in HBM/L2 is bound
+// by the CU's address path (~3 scattered dwords per clock: 45 K cycles per round, ~10 rounds); but entries only ever refer to
+// LOWER positions, so the block can be taken in ascending tiles: entries that refer below the tile take the (final) value of
+// their target with one global load, the rest is pointer jumping inside the tile -- in LDS, where a scattered read costs a
+// few cycles.  The tile lives in the front of the workgroup's LDS image (sequence ring, FSE tables, staging buffers: all
+// dead once the block's walk, plan and literals are complete).  true: no entry refers to the block any more.
+constexpr uint32_t kResTile = 6144; // entries (24 KiB)
+__device__ __noinline__ bool resolve_jump_tiled(uint32_t* map, uint32_t B, int tid) {
+    static_assert(offsetof(Shared, ring) == 0 && offsetof(Shared, ll_base) >= kResTile * 4, "the tile overlays ring, ll, ml, of, stage, hseg2");
+    uint32_t* const tile = reinterpret_cast<uint32_t*>(&S);
+    const uint32_t nall = (B + 3) & ~3u; // (the padding entries behind B are literals)
+    bool good = true;
+    constexpr uint32_t kPer = kResTile / (kWG * 4); // vectors per thread and tile
+    auto load_tile = [&](uint32_t a0, uint4 (&r)[kPer]) { // this thread's vectors of the tile at a0 (literals past the map's end)
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) { const uint32_t i = a0 + (u * kWG + (uint32_t)tid) * 4; r[u] = i < nall ? *reinterpret_cast<const uint4*>(map + i) : make_uint4(kResLit, kResLit, kResLit, kResLit); }
+    };
+    uint4 v[kPer], nx[kPer];
+    load_tile(0, nx);
+    for (uint32_t a0 = 0; a0 < nall; a0 += kResTile) {
+        const uint32_t n = nall - a0 < kResTile ? nall - a0 : kResTile; // a multiple of 4
+        // into LDS; what refers below the tile is final there: one hop (all loads of a thread in flight together; the NEXT tile's
+        // vectors -- nobody writes them before their turn -- are requested before this tile's work and arrive during it)
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) v[u] = nx[u];
+        load_tile(a0 + kResTile, nx);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) { // (positions are < 2^17: flagged entries are never below a0)
+            const uint32_t wx = v[u].x < a0 ? map[v[u].x] : v[u].x, wy = v[u].y < a0 ? map[v[u].y] : v[u].y;
+            const uint32_t wz = v[u].z < a0 ? map[v[u].z] : v[u].z, ww = v[u].w < a0 ? map[v[u].w] : v[u].w;
+            v[u] = make_uint4(wx, wy, wz, ww);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) { const uint32_t i = (u * kWG + (uint32_t)tid) * 4; if (i < n) *reinterpret_cast<uint4*>(tile + i) = v[u]; }
+        __syncthreads();
+        // pointer jumping inside the tile.  A thread keeps its entries in registers and hops each one along its chain until it
+        // is final: every read lands on a lower position or on a final value, so this ends after at most as many steps as the
+        // chain is long, and in about log2 of that since the other threads' entries move on at the same time (they publish every
+        // step; a stale read is still an ancestor).  No barrier, no flag.
+        uint32_t step = 0;
+        for (;; step++) {
+            bool mine = false;
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; u++) mine |= (v[u].x < kResPrev) | (v[u].y < kResPrev) | (v[u].z < kResPrev) | (v[u].w < kResPrev);
+            if (!__any(mine) || step >= 4 * kResRounds) break;
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; u++) { // (entries of vectors past the tile's end are literals)
+                const uint32_t wx = v[u].x < kResPrev ? tile[v[u].x - a0] : v[u].x, wy = v[u].y < kResPrev ? tile[v[u].y - a0] : v[u].y;
+                const uint32_t wz = v[u].z < kResPrev ? tile[v[u].z - a0] : v[u].z, ww = v[u].w < kResPrev ? tile[v[u].w - a0] : v[u].w;
+                v[u] = make_uint4(wx, wy, wz, ww);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; u++) { const uint32_t i = (u * kWG + (uint32_t)tid) * 4; if (i < n) *reinterpret_cast<uint4*>(tile + i) = v[u]; }
+        }
+        good = good && step < 4 * kResRounds;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) { const uint32_t i = (u * kWG + (uint32_t)tid) * 4; if (i < n) *reinterpret_cast<uint4*>(map + a0 + i) = v[u]; }
+        wg_fence(); // the next tile reads these entries
+        __syncthreads(); // (and every wavefront is done with this tile's LDS image)
+    }
+    return good;
+}
+
 // Step 2, all 256 threads (workgroup barriers inside).  true: no entry refers to the block any more.
 __device__ __noinline__ bool resolve_jump(uint32_t* map, uint32_t B, int tid) {
     const uint32_t n4 = (B + 3) / 4;
@@ -216,10 +279,17 @@ __device__ __noinline__ void resolve_gather3(const uint32_t* map, uint32_t B, co
         return (e & kResLit) ? (uint32_t)lit[ix] : (uint32_t)*(hist - ix);
     };
     uint32_t step = 0;
-    for (uint32_t q0 = (uint32_t)gw * 64 + (uint32_t)lane; q0 - ((uint32_t)gw * 64 + (uint32_t)lane) < n4; q0 += kResStepDw, step++) {
-        uint4 v[kResU];
+    const uint32_t qbase = (uint32_t)gw * 64 + (uint32_t)lane;
+    auto load_step = [&](uint32_t q0, uint4 (&r)[kResU]) {
 #pragma unroll
-        for (uint32_t u = 0; u < kResU; u++) { const uint32_t q = q0 + u * 192; v[u] = q < n4 ? m4[q] : make_uint4(kResLit, kResLit, kResLit, kResLit); }
+        for (uint32_t u = 0; u < kResU; u++) { const uint32_t q = q0 + u * 192; r[u] = q < n4 ? m4[q] : make_uint4(kResLit, kResLit, kResLit, kResLit); }
+    };
+    uint4 v[kResU], nx[kResU];
+    load_step(qbase, nx);
+    for (uint32_t q0 = qbase; q0 - qbase < n4; q0 += kResStepDw, step++) {
+#pragma unroll
+        for (uint32_t u = 0; u < kResU; u++) v[u] = nx[u];
+        load_step(q0 + kResStepDw, nx); // (the next step's entries arrive while this step's bytes are fetched)
         uint32_t w[kResU];
 #pragma unroll
         for (uint32_t u = 0; u < kResU; u++) w[u] = byte_of(v[u].x) | (byte_of(v[u].y) << 8) | (byte_of(v[u].z) << 16) | (byte_of(v[u].w) << 24);

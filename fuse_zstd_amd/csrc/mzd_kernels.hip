@@ -518,7 +518,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                     uint32_t bad = 0;
                     WG_SNAPSHOT(bad = S.res[0]);
                     TFIN(8);
-                    ok = !bad && resolve_jump(map, B, tid);
+                    ok = !bad && resolve_jump_tiled(map, B, tid);
                     TFIN(4);
                 }
                 if (ok) { // in task order from here
