@@ -317,8 +317,10 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     // few tasks for the lane's workgroups: the in-order copy stage is the critical path -- resolve blocks ahead (mzd_k_resolve.h)
     const int force = g_force_driver.load(std::memory_order_relaxed);
     ka.resolve_map = d.resolve_map;
-    ka.resolve = use_tasks && force != 5 && (force == 4 || p.blocks <= 4ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : 0u; // (measured crossover on cfg4lu: ~5 blocks per
-    // workgroup slot; and a few very big files are chains however many blocks they have)
+    // 1: every task after a file's first resolves ahead (up to ~8 blocks per workgroup slot -- the measured crossover on cfg4lu --
+    // or a few very big files, which are chains however many blocks they have); 2: only tasks whose predecessor is still
+    // running when they start (launches with more tasks than that)
+    ka.resolve = !use_tasks || force == 5 ? 0u : ((force == 4 || p.blocks <= 8ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : 2u);
     HIPCHK(hipEventRecord(ev0, s));
     uint32_t grid;
     if (p.nsmall) {

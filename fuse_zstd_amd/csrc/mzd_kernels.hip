@@ -435,9 +435,10 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         bool have_block = !err && (in_frame || frame_first);
         uint32_t btype = 0, bsize = 0, last = 0;
         uint64_t pos0 = 0;
+        bool pred_done = false; // the predecessor task had finished when this one read its block header
         if (have_block) {
-            if (tid == 0) parse_block_header(c, src, n);
-            WG_SNAPSHOT(err = c.err; btype = c.btype; bsize = c.bsize; last = c.last; pos0 = c.pos);
+            if (tid == 0) { parse_block_header(c, src, n); S.res[3] = (t != 0 && g_load(&fs->copied) >= t) ? 1u : 0u; } // (is the predecessor done already?)
+            WG_SNAPSHOT(err = c.err; btype = c.btype; bsize = c.bsize; last = c.last; pos0 = c.pos; pred_done = S.res[3] != 0);
             if (err) have_block = false;
         }
         bool is_final = true; // no successor: this task closes the file
@@ -496,7 +497,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         } else if (have_block) {
             // (launch-wide: every task then keeps the repeat-offset chain going.  A file's first block has no predecessor to
             //  wait for: its copier and hasher follow its walker as they always do, and the file's checksum chain starts early)
-            const bool resolving = a.resolve != 0 && t != 0;
+            // resolve == 2 (a launch with many tasks per workgroup slot): only a task whose predecessor is NOT done yet resolves ahead --
+            // one that can copy at once is better off with the streaming copier, which runs beside the walk.
+            const bool resolving = a.resolve != 0 && t != 0 && !(a.resolve == 2 && pred_done);
             BlockArgs ba{src, n, dst, cap, dst2, src + pos0, bsize, pos0, 0, lit_buf, seqs, walk, last, hashing, false, t, frame_first, is_final, fs, ta, j};
             const bool started = compressed_block<true>(a, ba, xv, xstripes, mirrored, tid, lane, wave, resolving);
             bool resolved = false;
