@@ -77,6 +77,7 @@ struct Staging { // device (and pinned host) buffers of one host-path call
     DevJob* d_jobs = nullptr; DevJob* h_jobs = nullptr; // h_jobs pinned
     uint32_t* d_lists = nullptr; uint32_t* h_lists = nullptr; // 2 entries per job: small list | job list
     size_t jobs_cap = 0;
+    hipEvent_t ev[kMaxChunks][4] = {}; // per chunk of a call: inputs there, kernels start / end (timed), results there -- created once
     bool busy = false;
 };
 
@@ -133,6 +134,7 @@ void free_device(Device& d) {
         if (s.h_out) hipHostFree(s.h_out);
         if (s.h_jobs) hipHostFree(s.h_jobs);
         if (s.h_lists) hipHostFree(s.h_lists);
+        for (auto& c : s.ev) for (hipEvent_t e : c) if (e) hipEventDestroy(e);
     }
     for (auto& l : d.lane) free_lane(l, true);
     free_lane(d.whole, false);
@@ -655,11 +657,15 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
     for (size_t c = 0; c < nchunks && result == MZD_OK; c++) {
         const size_t c0 = cut[c], c1 = cut[c + 1];
         Chunk& k = ch[c];
-        hipError_t e = hipEventCreateWithFlags(&k.in, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreate(&k.k0);
-        if (e == hipSuccess) e = hipEventCreate(&k.k1);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&k.done, hipEventDisableTiming);
+        hipError_t e = hipSuccess;
+        if (!st->ev[c][0]) { // (the staging's events are made once: creating and destroying 16 per call cost ~0.1 ms)
+            e = hipEventCreateWithFlags(&st->ev[c][0], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreate(&st->ev[c][1]);
+            if (e == hipSuccess) e = hipEventCreate(&st->ev[c][2]);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev[c][3], hipEventDisableTiming);
+        }
         if (e != hipSuccess) { result = MZD_E_DEVICE; break; }
+        k.in = st->ev[c][0]; k.k0 = st->ev[c][1]; k.k1 = st->ev[c][2]; k.done = st->ev[c][3];
         int ln = kWholeLane;
         if (use_whole) take_whole(d); else ln = lane_begin(d, submitted != 0);
         k.lane = ln;
@@ -721,10 +727,6 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         }
         if (k.lane >= 0) lane_end(d, k.lane);
         else if (k.lane == kWholeLane) give_whole(d);
-        if (k.in) hipEventDestroy(k.in);
-        if (k.k0) hipEventDestroy(k.k0);
-        if (k.k1) hipEventDestroy(k.k1);
-        if (k.done) hipEventDestroy(k.done);
         if (c >= submitted || result != MZD_OK) continue;
         const size_t c0 = cut[c], c1 = cut[c + 1];
         size_t bytes = 0;
