@@ -62,7 +62,7 @@ struct __attribute__((aligned(16))) Shared {
     uint64_t cdiag[8];
 #endif
 #if defined(MZD_STAMPS) || defined(MZD_TFIN)
-    uint64_t ttask, tstart, tfin[12]; // block start; finish of walker / copier / hasher / planner; literals ready; tables ready
+    uint64_t ttask, tstart, tabs, tfin[12]; // block start; finish of walker / copier / hasher / planner; literals ready; tables ready
 #endif
     uint16_t huf[2048]; // sym | len << 8
     int16_t norm[3][64];

@@ -51,8 +51,16 @@ namespace mzd {
 #if defined(MZD_STAMPS) || defined(MZD_TFIN)
 #define TFIN(k) do { if (lane == 0) S.tfin[k] = __builtin_readcyclecounter() - S.tstart; } while (0)
 #define TSTART() do { if (tid == 0) { S.tstart = __builtin_readcyclecounter(); S.tfin[10] = S.tstart - S.ttask; } } while (0)
+#ifdef MZD_TFIN_ABS
+#define TTASK() do { if (tid == 0) { S.ttask = __builtin_readcyclecounter(); S.tabs = (uint64_t)wall_clock64(); } } while (0)
+#else
 #define TTASK() do { if (tid == 0) S.ttask = __builtin_readcyclecounter(); } while (0)
+#endif
+#ifdef MZD_TFIN_ABS // (experiment: absolute clock values -- the spread of workgroup starts and ends over a launch)
+#define TTASK_END() do { if (tid == 0) { S.tfin[11] = (uint64_t)wall_clock64(); S.tfin[10] = S.tabs; } } while (0) /* 100 MHz, the same on every CU */
+#else
 #define TTASK_END() do { if (tid == 0) S.tfin[11] = __builtin_readcyclecounter() - S.ttask; } while (0)
+#endif
 #define TCOUNT(k, v) do { if (lane == 0) atomicAdd((unsigned long long*)&S.tfin[k], (unsigned long long)(v)); } while (0)
 #define TFIN_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 12; k_++) a.debug[a.wg0 + blockIdx.x].tfin[k_] = S.tfin[k_]; } } while (0)
 #else

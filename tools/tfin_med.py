@@ -31,5 +31,9 @@ arr = np.frombuffer(buf, dtype=np.uint64)[: ns * 12].reshape(ns, 12).astype(np.f
 arr = arr[arr[:, 0] > 0]
 names = ["walker", "copier", "hasher", "planner", "lit stream 1", "tables", "headers", "huf weights", "huf table", "copier start", "file start -> block start", "file start -> file end"]
 print("kernel ms", mzd.last_kernel_ms(0), "wgs", len(arr))
+if os.environ.get("MZD_TFIN_ABS"):  # (libmzd_exp.so built with -DMZD_TFIN_ABS: columns 10 / 11 are absolute clock values)
+    st, en = arr[:, 10], arr[:, 11]
+    print("100 MHz clock, microseconds.  starts: spread %.1f (p50 - min %.1f, p99 - min %.1f); ends - first start: min %.1f, p50 %.1f, max %.1f" % ((st.max() - st.min()) / 1e2, (np.median(st) - st.min()) / 1e2, (np.percentile(st, 99) - st.min()) / 1e2, (en.min() - st.min()) / 1e2, (np.median(en) - st.min()) / 1e2, (en.max() - st.min()) / 1e2))
+    sys.exit(0)
 print("median: " + "; ".join("%s %.0fK" % (nm, np.median(arr[:, k]) / 1e3) for k, nm in enumerate(names)))
 print("max:    " + "; ".join("%s %.0fK" % (nm, np.max(arr[:, k]) / 1e3) for k, nm in enumerate(names)))
