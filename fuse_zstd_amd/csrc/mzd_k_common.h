@@ -79,6 +79,7 @@ struct __attribute__((aligned(16))) Shared {
     uint32_t res_rep[3];         // ... the repeat offsets the task starts with (rep_hop)
     uint32_t res_prog[3];        // ... steps the three gathering wavefronts have completed (resolve_gather3)
     uint32_t res_nsym, res_sym[kResSymMax]; // ... chunks left out by the build that follows the planner: they hold offsets still symbolic
+    uint32_t took_first;         // this workgroup has used its first ticket (take_ticket)
     uint32_t pre_job, pre_valid; // the job taken ahead (kNoJob: none) and whether c2 holds its parsed first block
     // driver 1: the small fields of the dictionary the workgroup used last (config 5: every file names the same one --
     // reading them from HBM again for each file costs a round trip per dependent load)

@@ -187,8 +187,14 @@ __device__ __noinline__ void build_tables_wave(int lane) {
 // (the host's part, then what that kernel handed on: KernelArgs::job_list).
 __device__ __forceinline__ uint32_t queue_len(const KernelArgs& a) { return a.job_list ? a.nlist_fixed + __atomic_load_n(&a.counter[4], __ATOMIC_RELAXED) : a.njobs; }
 __device__ __forceinline__ uint32_t queue_job(const KernelArgs& a, uint32_t ticket) { return a.job_list ? a.job_list[ticket] : ticket; }
-__device__ __forceinline__ uint32_t take_job(const KernelArgs& a) { // one lane
-    const uint32_t t = atomicAdd(&a.counter[0], 1u);
+// Tickets: a workgroup's FIRST ticket is its own index -- a thousand workgroups starting at once would otherwise queue up on one
+// atomic counter (~30 K cycles at the median) -- and the later ones come from the counter, which therefore counts from gridDim.x.
+__device__ __forceinline__ uint32_t take_ticket(const KernelArgs& a) { // thread 0
+    if (!S.took_first) { S.took_first = 1; return blockIdx.x; }
+    return gridDim.x + atomicAdd(&a.counter[0], 1u);
+}
+__device__ __forceinline__ uint32_t take_job(const KernelArgs& a) { // thread 0
+    const uint32_t t = take_ticket(a);
     return t < queue_len(a) ? queue_job(a, t) : kDoneJob;
 }
 

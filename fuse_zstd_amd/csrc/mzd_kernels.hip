@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
-    if (tid == 0) { c.lds_dict_fse = 0; c.lds_dict_huf = 0; S.pre_job = kNoJob; S.pre_valid = 0; S.dcache.id = 0; }
+    if (tid == 0) { c.lds_dict_fse = 0; c.lds_dict_huf = 0; S.pre_job = kNoJob; S.pre_valid = 0; S.dcache.id = 0; S.took_first = 0; }
 
     for (;;) {
         TTASK();
@@ -352,13 +352,14 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
+    if (tid == 0) S.took_first = 0;
 
     for (;;) {
         // ---------------- take a task: tickets below njobs are the first blocks of the files, the others the pushed
         // continuations in push order (a ticket may have to wait for its record; it gives up once every file is finished)
         if (tid == 0) {
             c.t_valid = 0;
-            const uint32_t ticket = atomicAdd(&a.counter[0], 1u);
+            const uint32_t ticket = take_ticket(a);
             const uint32_t nq = queue_len(a);
             if (ticket < nq) { c.job = queue_job(a, ticket); c.task = 0; c.pos = 0; c.in_frame = 0; c.with_dict = 0; c.t_valid = 1; }
             else {
