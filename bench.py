@@ -402,11 +402,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # Rehearsal of the N > 1 flow on a box with ONE GPU (tools/, never the driver): every rank on device 0, collectives over gloo
+    # on CPU tensors.  The value of such a run means nothing (the ranks share the card); what it checks is the protocol.
+    rehearsal = world > 1 and os.environ.get("MZD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearsal else dev  # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import corpus
     import fuse_zstd_amd as mzd
@@ -434,10 +443,10 @@ def main():
     my_frac = (w.C + w.U) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(w.U), float(w.C), kernel_ms, my_value, my_frac], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(w.U), float(w.C), kernel_ms, my_value, my_frac], dtype=torch.float64, device=cdev)
         allv = [torch.zeros_like(tot) for _ in range(world)]
         dist.all_gather(allv, tot)
         U_all = sum(float(v[0]) for v in allv)

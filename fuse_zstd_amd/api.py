@@ -39,8 +39,19 @@ def build(force=False):
     src_dir = os.path.join(_HERE, "csrc")
     srcs = [os.path.join(src_dir, f) for f in ("mzd_kernels.hip", "mzd_small.hip", "mzd_host.cpp", "mzd_device.h", "mzd_tables.h") + tuple(f for f in os.listdir(src_dir) if f.startswith("mzd_k_"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mzd.h"))
-    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
-        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    def stale():
+        return force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if stale():
+        # several ranks of one node may get here at once (bench.py under torch.distributed.run): one builds, the others wait and
+        # find the library fresh
+        import fcntl
+        with open(os.path.join(src_dir, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    subprocess.check_call(["make", "-C", src_dir, "-s"])
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return _SO
 
 
