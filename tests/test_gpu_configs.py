@@ -79,14 +79,31 @@ def test_config4_full_size_takes_the_small_file_kernel():
 
 
 @needs_zstd
-def test_config4_log_uniform_mix_of_small_and_multi_block_files():
-    """The log-uniform variant in small (4 KiB .. 1 MiB, 600 files): small files take the lane-per-file kernel, the others
-    block tasks, in ONE launch behind each other."""
+@pytest.mark.parametrize("mode", [0, 3])
+def test_config4_log_uniform_mix_of_small_and_multi_block_files(mode):
+    """The log-uniform variant in small (1 KB .. 1 MiB, 600 files) in ONE launch: block tasks, every block after a file's first
+    resolved ahead of its predecessor (few tasks for the machine).  Mode 0, the library's own choice, gives the few small files
+    to the general driver as well; mode 3 sends them through the lane-per-file kernel first."""
     rng = np.random.RandomState(1234)
     sizes = [int(x) for x in np.exp(rng.uniform(np.log(1000), np.log(1 << 20), size=600)).astype(np.int64)]
     cp = corpus.build_corpus("json", 4, sizes)
-    res, got, end = _device_resident(cp)
+    mzd.set_driver(mode)
+    try:
+        res, got, end = _device_resident(cp)
+    finally:
+        mzd.set_driver(0)
     _check_corpus(cp, res, got, end, sample=60)
+
+
+@needs_zstd
+def test_many_multi_block_files_resolve_only_where_the_predecessor_is_still_running():
+    """6 000 files of 1 KB .. 512 KiB: more than 8 block tasks per workgroup slot, so a task resolves its block ahead only when
+    its predecessor is still running as it starts (KernelArgs::resolve = 2); both kinds of task hand over to each other."""
+    rng = np.random.RandomState(4321)
+    sizes = [int(x) for x in np.exp(rng.uniform(np.log(1000), np.log(1 << 19), size=6000)).astype(np.int64)]
+    cp = corpus.build_corpus("json", 14, sizes)
+    res, got, end = _device_resident(cp)
+    _check_corpus(cp, res, got, end, sample=80)
 
 
 @needs_zstd
