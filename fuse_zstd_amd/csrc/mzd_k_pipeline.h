@@ -286,9 +286,6 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
             CopyCtx cx{b.seqs, dst, fstart, c.dict_content, c.dict_content_len, r.lit_in_place() ? r.place : r.lit, nlit, b.cap, lit_type >= 2 ? streams : 0u,
                        {r0, r1, r2}, (TASKS && a.debug) ? b.seqs : nullptr};
             TFIN(9);
-#ifdef MZD_EXP_COPY_DELAY // (experiment: how much of a later copier start shows in the launch's duration)
-            { const uint64_t t0_ = __builtin_readcyclecounter(); while (__builtin_readcyclecounter() - t0_ < (uint64_t)MZD_EXP_COPY_DELAY) __builtin_amdgcn_s_sleep(16); }
-#endif
             __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); // second on the critical path, behind the walker
             rc = copy_wave(r.nseq, cx, &opos, lane);
             __builtin_amdgcn_s_setprio(0);
