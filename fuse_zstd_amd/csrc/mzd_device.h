@@ -77,9 +77,16 @@ struct FileState { // zeroed per launch
     // of their own, as soon as a task's plan is complete -- rep_e = the offsets after task rep_ver - 1
     uint32_t rep_ver;
     uint32_t rep_e[3];
-    uint64_t pad[1];
+    // The checksum chain (XXH64: strictly serial through a frame, 46 cycles per 32-byte stripe) is published separately from the
+    // bytes: hashed = t + 1 means xstripes / xxh[] hold the state after task t.  Most tasks publish both together; a task that
+    // resolved its block ahead hands `copied` over as soon as its bytes are gathered and `hashed` when its hash is done, so the
+    // successor's gather does not wait for it.  A checksum failure found that way is posted here (first one wins): by then the
+    // bytes' chain has moved on with err = 0.
+    uint32_t hashed;
+    int32_t herr;
+    uint64_t herr_out;      // `out` before the task that found it
 };
-static_assert(sizeof(FileState) == 128, "FileState layout");
+static_assert(sizeof(FileState) == 136, "FileState layout");
 
 struct TableArea { // the entropy tables in force after the file's most recently published task (LDS layout)
     uint64_t ll[512];

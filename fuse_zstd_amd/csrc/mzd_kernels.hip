@@ -128,19 +128,38 @@ __device__ __noinline__ bool g_wait_ge(const uint32_t* p, uint32_t want) {
     return false;
 }
 // lane 0: what the predecessor of task t left behind -> S.c.pred_*.  false: the launch is broken (timeout).
-__device__ __noinline__ bool load_pred(const FileState* fs, uint32_t t) {
+// load_pred_copy: position, repeat offsets, first error (FileState::copied); load_pred_hash: the checksum chain
+// (FileState::hashed), and a checksum failure posted on it, which outranks whatever the bytes' chain says (it is earlier in
+// the stream); load_pred: both.
+__device__ __noinline__ bool load_pred_copy(const FileState* fs, uint32_t t) {
     Ctl& c = S.c;
     if (t == 0) {
-        c.pred_err = 0; c.pred_out = 0; c.pred_frame_out0 = 0; c.pred_xstripes = 0;
+        c.pred_err = 0; c.pred_out = 0; c.pred_frame_out0 = 0;
         c.pred_rep[0] = 1; c.pred_rep[1] = 4; c.pred_rep[2] = 8;
-        for (int k = 0; k < 4; k++) c.pred_xxh[k] = 0;
     } else {
-        if (!g_wait_ge(&fs->copied, t)) { c.pred_err = MZD_E_DEVICE; c.pred_out = 0; c.pred_frame_out0 = 0; c.pred_xstripes = 0; return false; }
-        c.pred_err = g_ld(&fs->err); c.pred_out = g_ld(&fs->out); c.pred_frame_out0 = g_ld(&fs->frame_out0); c.pred_xstripes = g_ld(&fs->xstripes);
+        if (!g_wait_ge(&fs->copied, t)) { c.pred_err = MZD_E_DEVICE; c.pred_out = 0; c.pred_frame_out0 = 0; return false; }
+        c.pred_err = g_ld(&fs->err); c.pred_out = g_ld(&fs->out); c.pred_frame_out0 = g_ld(&fs->frame_out0);
         c.pred_rep[0] = g_ld(&fs->rep[0]); c.pred_rep[1] = g_ld(&fs->rep[1]); c.pred_rep[2] = g_ld(&fs->rep[2]);
-        for (int k = 0; k < 4; k++) c.pred_xxh[k] = g_ld(&fs->xxh[k]);
     }
     return true;
+}
+__device__ __noinline__ bool load_pred_hash(const FileState* fs, uint32_t t) {
+    Ctl& c = S.c;
+    if (t == 0) {
+        c.pred_xstripes = 0;
+        for (int k = 0; k < 4; k++) c.pred_xxh[k] = 0;
+    } else {
+        if (!g_wait_ge(&fs->hashed, t)) { c.pred_err = MZD_E_DEVICE; c.pred_xstripes = 0; return false; }
+        c.pred_xstripes = g_ld(&fs->xstripes);
+        for (int k = 0; k < 4; k++) c.pred_xxh[k] = g_ld(&fs->xxh[k]);
+        const int32_t he = g_ld(&fs->herr);
+        if (he) { c.pred_err = he; c.pred_out = g_ld(&fs->herr_out); }
+    }
+    return true;
+}
+__device__ __noinline__ bool load_pred(const FileState* fs, uint32_t t) {
+    const bool a_ = load_pred_copy(fs, t);
+    return a_ && load_pred_hash(fs, t);
 }
 
 // One lane.  The repeat-offset chain: wait for the predecessor's, apply this task's transform (identity unless it planned
@@ -395,6 +414,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         uint64_t mirrored = 0;                // wave 2: how far this task's block has been mirrored
         bool have_mirrored = false;           // ... `mirrored` is valid (a compressed block whose copier ran)
         bool rep_hopped = false;              // resolving launches: this task has passed the repeat-offset chain on
+        bool early_done = false;              // ... and has published both of its hand-overs already (bytes early, checksum state behind)
         FileState* const fs = &a.fstate[j];
         TableArea* const ta = &a.tables[j];
         if (tid == 0) {
@@ -534,7 +554,12 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                     TFIN(4);
                 }
                 if (ok) { // in task order from here
-                    if (tid == 0) load_pred(fs, t);
+                    // A block of a frame with a checksum, not the file's last task, hands its BYTES over as soon as they are gathered
+                    // and its checksum state when the hash is done (FileState::hashed): the successor's gather does not wait for it.
+                    uint32_t tpub = 0;
+                    WG_SNAPSHOT(tpub = c.tables_published);
+                    const bool early = hashing && !is_final && tpub != 0;
+                    if (tid == 0) { if (early) load_pred_copy(fs, t); else load_pred(fs, t); }
                     int perr = 0;
                     uint64_t fstart0 = 0;
                     uint32_t reach = 0;
@@ -549,15 +574,64 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                         if (hashing) { // K7 beside the gather: wavefront 2 hashes behind the other three (the state travels from task to task)
                             if (tid < 3) S.res_prog[tid] = 0;
                             __syncthreads();
+                            const uint64_t out_end = out0 + B;
+                            // (the frame's trailer checks that need no hash: content size, room for the checksum)
+                            const int err_c = !last ? 0 : ((c.has_fcs && out_end - fstart0 != c.fcs) ? MZD_E_CORRUPT : (n - (pos0 + bsize) < 4 ? MZD_E_TRUNCATED : 0));
                             if (wave == 2) {
+                                bool chain_ok = true;
+                                if (early) { // the checksum chain has its own hand-over
+                                    int ok_ = 1;
+                                    if (lane == 0) ok_ = load_pred_hash(fs, t) ? 1 : 0;
+                                    chain_ok = __builtin_amdgcn_readfirstlane(ok_) != 0;
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                }
+                                const bool dead = early && (!chain_ok || __atomic_load_n(&c.pred_err, __ATOMIC_RELAXED) != 0); // a checksum failed earlier in the file
                                 xv = frame_first ? xxh_init(lane) : c.pred_xxh[lane & 3];
                                 xstripes = frame_first ? 0 : c.pred_xstripes;
-                                if (!resolve_hash_behind(xv, xstripes, dst + fstart0, out0 - fstart0, B, lane) && lane == 0) post_err(&c.err, MZD_E_DEVICE);
+                                if (!dead && !resolve_hash_behind(xv, xstripes, dst + fstart0, out0 - fstart0, B, lane) && lane == 0) post_err(&c.err, MZD_E_DEVICE);
+                                if (early) {
+                                    int herr_now = 0;
+                                    if (!dead && last && !err_c) { // close the digest
+                                        xxh_advance(xv, xstripes, (out_end - fstart0) / 32, dst + fstart0, lane);
+                                        const uint64_t h = xxh_finish(xv, dst + fstart0, out_end - fstart0, lane);
+#ifndef MZD_EXP_NOHASH
+                                        if ((uint32_t)h != ld32(src + pos0 + bsize)) herr_now = MZD_E_CHECKSUM;
+#endif
+                                    }
+                                    if (lane < 4) g_st(&fs->xxh[lane], xv);
+                                    if (lane == 0) {
+                                        g_st(&fs->xstripes, xstripes);
+                                        if (herr_now) { g_st(&fs->herr_out, out0); g_st(&fs->herr, (int32_t)herr_now); }
+                                    }
+                                    g_settle();
+                                    if (lane == 0) g_store(&fs->hashed, t + 1);
+                                }
                                 TFIN(2);
                             } else {
                                 resolve_gather3(map, B, lits, dst, out0, wave == 3 ? 2 : wave, lane);
                                 if (wave == 0) TFIN(1);
+                                if (early && wave == 0) { // the bytes' hand-over: when the other two gathering wavefronts are through as well
+                                    const uint32_t nsteps = ((B + 3) / 4 + kResStepDw - 1) / kResStepDw;
+                                    if (lane == 0) {
+                                        for (uint32_t it = 0; it < (1u << 24); it++) {
+                                            if (flag_load(&S.res_prog[1]) >= nsteps && flag_load(&S.res_prog[2]) >= nsteps) break;
+                                            __builtin_amdgcn_s_sleep(4);
+                                        }
+                                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                        RepOp Rf; Rf.s = c.rep_op[0]; Rf.v0 = (int32_t)c.rep_op[1]; Rf.v1 = (int32_t)c.rep_op[2]; Rf.v2 = (int32_t)c.rep_op[3];
+                                        const uint32_t ri0 = frame_first ? c.rep[0] : S.res_rep[0], ri1 = frame_first ? c.rep[1] : S.res_rep[1], ri2 = frame_first ? c.rep[2] : S.res_rep[2];
+                                        g_st(&fs->rep[0], rep_eval(Rf, 0, ri0, ri1, ri2)); g_st(&fs->rep[1], rep_eval(Rf, 1, ri0, ri1, ri2)); g_st(&fs->rep[2], rep_eval(Rf, 2, ri0, ri1, ri2));
+                                        g_st(&fs->err, (int32_t)err_c);
+                                        g_st(&fs->out, err_c ? out0 : out_end);
+                                        g_st(&fs->frame_out0, fstart0);
+                                        g_settle();
+                                        g_release(); // (every gathering wavefront has waited for its stores: resolve_gather3)
+                                        g_store(&fs->copied, t + 1);
+                                    }
+                                }
                             }
+                            if (early) { early_done = true; if (tid == 0 && err_c) c.err = err_c; }
                         } else {
                             resolve_gather(map, B, lits, dst, out0, tid);
                             wg_fence();
@@ -572,8 +646,12 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                         }
                         resolved = true;
                     } else if (perr) { // the file has already failed: nothing to execute (the error travels on)
+                        if (early && tid == 0) load_pred_hash(fs, t); // (this task publishes both chains together, below: the checksum chain's turn must have come)
                         if (tid == 0) { c.out = out0; c.pos = pos0 + bsize; }
                         resolved = true;
+                    } else if (early) { // (falls back to the copying wavefront, which starts from the complete predecessor state)
+                        if (tid == 0) load_pred_hash(fs, t);
+                        __syncthreads();
                     }
                 }
             }
@@ -600,7 +678,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
         int final_err = perr ? perr : err;
         const bool mirror_rest = dst2 && !final_err && out_now > pred_out; // this task's bytes the host mirror has not seen yet (all of a raw / RLE block)
         const uint64_t mirror_from = (have_mirrored && mirrored >= pred_out && mirrored <= out_now) ? mirrored : pred_out;
-        if (!final_err && have_block && last) { // frame trailer: content size and checksum
+        if (!final_err && have_block && last && !early_done) { // frame trailer: content size and checksum
             if (tid == 0) {
                 if (c.has_fcs && out_now - fstart != c.fcs) c.err = MZD_E_CORRUPT;
                 else if (has_ck && n - pos_now < 4) c.err = MZD_E_TRUNCATED;
@@ -622,7 +700,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
             final_err = err;
         }
         // the state for the successor (or the file's result), published in task order
-        if (!is_final) {
+        if (early_done) {} // (done: mzd_k_resolve.h path above)
+        else if (!is_final) {
             if (wave == 2) { // K7 state lives in this wavefront's registers
                 if (lane < 4) g_st(&fs->xxh[lane], xv);
                 if (lane == 0) g_st(&fs->xstripes, xstripes);
@@ -663,7 +742,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
             // writes the XCD's L2 back
             g_settle();
             __syncthreads();
-            if (tid == 0) { g_release(); g_store(&fs->copied, t + 1); }
+            if (tid == 0) { g_release(); g_store(&fs->hashed, t + 1); g_store(&fs->copied, t + 1); }
         } else if (tid == 0) { // the file is finished: its result, and one file less to wait for
             a.jobs[j].out_len = final_err ? pred_out : out_now;
             a.jobs[j].status = final_err;

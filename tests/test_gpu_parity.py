@@ -298,6 +298,31 @@ def test_corrupted_multi_block_files_report_the_oracles_error(driver, force_driv
 
 @needs_zstd
 @pytest.mark.parametrize("driver", DRIVERS)
+def test_checksum_failures_inside_multi_frame_files_of_multi_block_frames(driver, force_driver):
+    """Three multi-block frames in one file; the checksum of the first, second or third frame is wrong (or a byte of a block's
+    content is).  With blocks resolved ahead the bytes' chain runs ahead of the checksum chain, so the failure is found when
+    later frames have long been handed over: status and length must still be the oracle's (the first error in stream order)."""
+    force_driver(driver)
+    frames = [corpus.build_corpus(kind, 91 + k, [size]).comp_file(0).tobytes() for k, (kind, size) in enumerate((("json", 300000), ("text", 280000), ("json", 400000)))]
+    total = 300000 + 280000 + 400000
+    ends = np.cumsum([len(f) for f in frames])
+    good = b"".join(frames)
+    cases = [(good, total)]
+    rng = np.random.RandomState(5)
+    for k in range(3):
+        b = bytearray(good); b[int(ends[k]) - 2] ^= 0x5A; cases.append((bytes(b), total))          # the stored checksum of frame k
+        b = bytearray(good); pos = int(ends[k]) - 2000 - int(rng.randint(0, 50000)); b[pos] ^= 0x11; cases.append((bytes(b), total))  # content of frame k
+    cases.append((good, 300000 + 280000 + 10))   # the destination ends inside the third frame
+    res = mzd.decode_batch([c for c, _ in cases], [cap for _, cap in cases])
+    for i, ((comp, cap), (st, out)) in enumerate(zip(cases, res)):
+        rc, want = oracle.decode(comp, cap=cap)
+        assert st == rc, (i, st, rc)
+        assert st != 0 or out == want, i
+    assert res[0][0] == 0 and res[1][0] == mzd.E_CHECKSUM
+
+
+@needs_zstd
+@pytest.mark.parametrize("driver", DRIVERS)
 def test_multi_block_corpus_both_drivers(driver, force_driver):
     """Seeded files of 4 KiB .. 1 MiB (up to 8 blocks, treeless literals and repeat tables between them) in one batch."""
     force_driver(driver)
