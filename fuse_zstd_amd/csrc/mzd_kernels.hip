@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
                     // and its checksum state when the hash is done (FileState::hashed): the successor's gather does not wait for it.
                     uint32_t tpub = 0;
                     WG_SNAPSHOT(tpub = c.tables_published);
-                    const bool early = hashing && !is_final && tpub != 0;
+                    const bool early = hashing && !is_final && tpub != 0 && a.resolve == 1; // (launches with many tasks per slot are not chain-bound)
                     if (tid == 0) { if (early) load_pred_copy(fs, t); else load_pred(fs, t); }
                     int perr = 0;
                     uint64_t fstart0 = 0;
