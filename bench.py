@@ -71,6 +71,28 @@ def file_sizes(workload, nfiles, rank, world):
     return [int(x) for x in allsz[rank::world]]
 
 
+def silesia_chunks(nfiles, rank, world):
+    """Pieces of 128 KiB of the files under $SILESIA_DIR (sorted by name), piece i -> rank i mod world, at most nfiles per rank;
+    None when the variable is not set or the directory holds nothing (then the generator's Silesia-proxy mix is used)."""
+    d = os.environ.get("SILESIA_DIR")
+    if not d or not os.path.isdir(d):
+        return None
+    out, i = [], 0
+    for fn in sorted(os.listdir(d)):
+        path = os.path.join(d, fn)
+        if not os.path.isfile(path):
+            continue
+        with open(path, "rb") as f:
+            while True:
+                piece = f.read(131072)
+                if not piece:
+                    break
+                if i % world == rank and len(out) < nfiles:
+                    out.append(piece)
+                i += 1
+    return out or None
+
+
 def cpu_baseline(cp, budget_s=10.0):
     """The reference's CPU path on this host: libzstd (dlopen).  B2 = all cores, one file per task,
     one-shot decode with a reused DCtx per thread; B1 = one thread, streaming through an 8 KiB
@@ -218,7 +240,13 @@ class Workload:
             tr = np.random.RandomState(55).randint(300, 3001, size=4000)
             self.dictionary = corpus.train_dict(kind, cfg_id, [int(x) for x in tr], cap=112640)
             self.dict_id = mzd.load_dict(self.dictionary)
-        self.cp = cp = corpus.build_corpus(kind, cfg_id, sizes, first_index=rank, stride=world, level=level, kind_mod=kind_mod, dictionary=self.dictionary)
+        chunks = silesia_chunks(nfiles, rank, world) if name == "cfg3" else None
+        if chunks:  # the real Silesia files when the box has them (SILESIA_DIR), each 128 KiB piece its own frame
+            self.cp = cp = corpus.build_corpus_from_chunks(chunks, level=level)
+            self.nfiles = len(chunks)
+            self.desc = "Silesia (SILESIA_DIR) as 128 KiB single-block frames, level %d (BASELINE configs[2])" % level
+        else:
+            self.cp = cp = corpus.build_corpus(kind, cfg_id, sizes, first_index=rank, stride=world, level=level, kind_mod=kind_mod, dictionary=self.dictionary)
         self.C = int(cp.comp_sizes.sum()); self.U = int(cp.raw_sizes.sum())
         self.end = int(cp.raw_offs[-1] + cp.raw_sizes[-1])
         self.nsets = max(1, min(8, -(-(MALL_BYTES + (64 << 20)) // (self.C + self.U))))

@@ -83,7 +83,13 @@ class Corpus:
         return self.comp[o:o + n]
 
 
-def build_corpus(kind, cfg_id, sizes, first_index=0, stride=1, level=3, checksum=True, kind_mod=0, nthreads=None, align=16, dictionary=None):
+def build_corpus_from_chunks(chunks, level=3, checksum=True, nthreads=None, align=16):
+    """Compress given byte strings (real data, e.g. 128 KiB pieces of the Silesia files: SURVEY.md 8d config 3), each as ONE frame written
+    like the reference's writer.  Same Corpus layout as build_corpus."""
+    return build_corpus(-1, 0, [len(c) for c in chunks], level=level, checksum=checksum, nthreads=nthreads, align=align, _raw_chunks=chunks)
+
+
+def build_corpus(kind, cfg_id, sizes, first_index=0, stride=1, level=3, checksum=True, kind_mod=0, nthreads=None, align=16, dictionary=None, _raw_chunks=None):
     """Generate + compress len(sizes) files with indices first_index + i*stride.  kind_mod>0 cycles kinds kind..kind+kind_mod-1 by index
     (the Silesia-proxy mix).  Compressed frames are packed at `align`-byte boundaries."""
     L = lib()
@@ -97,6 +103,9 @@ def build_corpus(kind, cfg_id, sizes, first_index=0, stride=1, level=3, checksum
         raw_offs[1:] = np.cumsum((sizes[:-1] + np.uint64(15)) & ~np.uint64(15))
     raw_total = int(raw_offs[-1] + sizes[-1]) if n else 0
     raw = np.zeros(raw_total + 64, dtype=np.uint8)
+    if _raw_chunks is not None:
+        for o, c in zip(raw_offs, _raw_chunks):
+            raw[int(o):int(o) + len(c)] = np.frombuffer(c, dtype=np.uint8)
     bounds = np.array([L.corpus_bound(int(s)) for s in np.unique(sizes)], dtype=np.uint64)
     bmap = dict(zip([int(s) for s in np.unique(sizes)], [int(b) for b in bounds]))
     slot = np.array([bmap[int(s)] for s in sizes], dtype=np.uint64)

@@ -228,7 +228,7 @@ static void* build_worker(void* v) {
         uint64_t idx = a->first_index + (uint64_t)i * a->stride;
         int kind = a->kind_base + (a->kind_mod ? (int)(idx % (uint64_t)a->kind_mod) : 0);
         uint8_t* raw = a->raw + a->raw_offs[i];
-        corpus_gen(kind, a->cfg_id, idx, raw, (size_t)a->raw_sizes[i]);
+        if (a->kind_base >= 0) corpus_gen(kind, a->cfg_id, idx, raw, (size_t)a->raw_sizes[i]); /* (< 0: the caller has filled `raw` -- real files) */
         p_CCtx_setParameter(c, 100, a->level);
         p_CCtx_setParameter(c, 201, a->checksum);
         size_t cap = p_compressBound((size_t)a->raw_sizes[i]);

@@ -161,3 +161,24 @@ def test_golden_accept_reject_against_libzstd_1_5_when_loadable():
     if r.stdout.strip() == "SKIP":
         pytest.skip("no libzstd 1.5.x on this machine")
     assert r.stdout.startswith("OK"), r.stdout
+
+
+def test_corpus_from_real_chunks_and_the_silesia_directory_hook(tmp_path, monkeypatch):
+    """when SILESIA_DIR names a directory, bench.py cuts its files into 128 KiB pieces (piece i -> rank
+    i mod N) and compresses each as its own frame; the frames decode to the pieces."""
+    import corpus
+    if not corpus.have_zstd():
+        pytest.skip("no libzstd shared object to compress with")
+    import bench
+    (tmp_path / "a.txt").write_bytes(b"the quick brown fox jumps over the lazy dog. " * 9000)
+    (tmp_path / "b.bin").write_bytes(bytes(range(256)) * 700)
+    monkeypatch.setenv("SILESIA_DIR", str(tmp_path))
+    all_pieces = bench.silesia_chunks(1000, 0, 1)
+    assert [len(p) for p in all_pieces] == [131072, 131072, 131072, 405000 - 3 * 131072, 131072, 179200 - 131072]
+    assert bench.silesia_chunks(1000, 1, 2) == all_pieces[1::2] and bench.silesia_chunks(2, 0, 2) == all_pieces[0::2][:2]
+    cp = corpus.build_corpus_from_chunks(all_pieces)
+    for i, piece in enumerate(all_pieces):
+        rc, out = oracle.decode(cp.comp_file(i).tobytes(), cap=len(piece))
+        assert rc == 0 and out == piece
+    monkeypatch.delenv("SILESIA_DIR")
+    assert bench.silesia_chunks(10, 0, 1) is None
