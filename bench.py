@@ -244,6 +244,7 @@ class Workload:
         if chunks:  # the real Silesia files when the box has them (SILESIA_DIR), each 128 KiB piece its own frame
             self.cp = cp = corpus.build_corpus_from_chunks(chunks, level=level)
             self.nfiles = len(chunks)
+            self.real_data = True
             self.desc = "Silesia (SILESIA_DIR) as 128 KiB single-block frames, level %d (BASELINE configs[2])" % level
         else:
             self.cp = cp = corpus.build_corpus(kind, cfg_id, sizes, first_index=rank, stride=world, level=level, kind_mod=kind_mod, dictionary=self.dictionary)
@@ -490,9 +491,9 @@ def main():
             "metric": "decompressed GiB/s through FUSE read path; byte-exact vs libzstd",
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic" if not getattr(w, "real_data", False) else "files of SILESIA_DIR",
             "value_is": "T1: the decode of open() (reference src/main.rs:463-467) with compressed files resident in HBM when the timed region starts and decoded files left in HBM; the host-to-host rate of the same path is t2_end_to_end",
-            "config": {"workload": "%s: %s" % (args.workload, w.desc), "files_per_gpu": nfiles, "files_total": nfiles * world,
+            "config": {"workload": "%s: %s" % (args.workload, w.desc), "files_per_gpu": w.nfiles, "files_total": w.nfiles * world,
                        "decompressed_bytes_per_gpu": w.U, "compressed_bytes_per_gpu": w.C, "zstd_level": args.level,
                        "sharding": "file i -> GPU i mod N, no collective", "compressor": "libzstd " + corpus.zstd_version(),
                        "buffer_sets_rotated": w.nsets, "working_set_bytes": w.nsets * (w.C + w.U)},
