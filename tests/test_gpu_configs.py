@@ -4,6 +4,7 @@ threads), dictionary unloading, and -- where the box has two GPUs -- the multi-G
 
 Every case goes through the C ABI (include/mzd.h); expected bytes come from the seeded generator (what was
 compressed), and a sample of every corpus is decoded by the oracle as well."""
+import os
 import threading
 
 import numpy as np
@@ -329,3 +330,29 @@ def test_lazy_open_decodes_only_what_reads_need():
     assert e.value.errno == errno.EFAULT
     fs.release(fh)
     fs.close()
+
+
+@needs_zstd
+def test_bench_line_keeps_the_contract():
+    """`python bench.py` prints ONE JSON line with the fields the driver parses (a short run: 2 steps, the headline workload alone),
+    plus the `roofline` object; its value is a plausible rate and the output was verified byte-exact."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mzd.shutdown()  # (the child initialises the device itself; this process comes back afterwards)
+    try:
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-others", "--no-t2", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=600, cwd=root)
+    finally:
+        mzd.init()
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"].startswith("decompressed GiB/s") and d["unit"] == "GiB/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "u8"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["verified_byte_exact"] is True
+    assert d["config"]["workload"].startswith("cfg2") and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert 10.0 < d["value"] < 1000.0 and r["kernel"] == "mzd_decode_kernel_files"
