@@ -161,6 +161,24 @@ struct SmallArgs {
 void launch_small(const SmallArgs& a, uint32_t grid, int g, uint32_t lds_at_least, void* stream);
 uint32_t small_lds_bytes(int g, int with_dict);
 
+// ---- the small-file kernel with the whole file in LDS (mzd_lds.hip): G files per wavefront, 64 / G lanes per file; a file's
+// slot = [tables | ring | compressed input | output window], sized by the host for the launch's largest file
+struct LdsArgs {
+    DevJob* jobs;
+    const uint32_t* list;       // job indices, sorted by dictionary
+    uint32_t n;
+    uint32_t* counter;          // the launch's counter block (words 4 and 5)
+    uint32_t* redo_list;        // = job_list + nlist_fixed
+    const DevDict* dicts;
+    uint32_t ndicts;
+    uint32_t tab_bytes;         // per file: Huffman table, then the three FSE tables (0: files use the dictionary's tables only)
+    uint32_t comp_bytes;        // per file: >= the largest src_len of the launch + 16, a multiple of 16
+    uint32_t out_bytes;         // per file: >= the largest dst_cap of the launch + 16, a multiple of 16, >= 1024
+    uint64_t* stamps;           // diagnostic build (-DMZD_SMALL_STAMPS), else unused
+};
+void launch_lds(const LdsArgs& a, uint32_t grid, int g, int with_dict, void* stream);
+uint32_t lds_kernel_bytes(int g, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes);
+
 
 void launch_decode(const KernelArgs& a, uint32_t grid, void* stream);
 int kernel_lds_bytes();

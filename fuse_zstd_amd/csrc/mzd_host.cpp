@@ -251,7 +251,10 @@ struct Plan {
     uint32_t njobs = 0, nsmall = 0, nbig = 0;
     int small_g = 16;
     bool with_dict = false, multi = false;
-    uint32_t lit_stride = 0;   // literal scratch per small file: largest capacity + 64
+    uint32_t lit_stride = 0;   // literal scratch per small file: largest capacity + 64 (the lane-per-file kernel, debug mode 6)
+    bool lds_kernel = true;    // small files take mzd_lds.hip (the whole file in LDS); false: mzd_small.hip (debug mode 6)
+    int lds_g = 4;             // files per wavefront of that kernel
+    uint32_t lds_tab = 0, lds_comp = 0, lds_out = 0; // its slot geometry (LdsArgs)
     uint32_t big_tasks = 0;    // workgroups worth launching for the files that are not small
     uint64_t blocks = 0;       // block tasks of those files, estimated from their capacities
     uint32_t nmulti = 0;       // ... how many of them can have more than one block
@@ -269,9 +272,9 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
     // The lane-per-file kernel pays off from a few thousand small files on (its launch lasts ~0.6 ms however few they are,
     // and runs before the general driver); fewer of them fill the general driver's idle workgroup slots for less
     // (measured on the log-uniform mix cfg4lu, 13 % small files: 12.8 ms without it against 14.1 ms with it)
-    size_t eligible = 0;
+    size_t eligible = 0, maxsrc = 0;
     for (size_t i = 0; i < njobs; i++) eligible += jobs[i].dst_cap <= kSmallCap && jobs[i].src_len <= kSmallSrcMax;
-    const bool small_ok = force == 3 || (force == 0 && eligible >= 8ull * max_wg); // (3: whenever a file is eligible -- tests)
+    const bool small_ok = force == 3 || force == 6 || (force == 0 && eligible >= 8ull * max_wg); // (3, 6: whenever a file is eligible -- tests)
     for (size_t i = 0; i < njobs; i++) {
         const DevJob& j = jobs[i];
         const bool is_small = small_ok && j.dst_cap <= kSmallCap && j.src_len <= kSmallSrcMax;
@@ -279,6 +282,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
             small[p.nsmall++] = (uint32_t)i;
             if (j.dict) p.with_dict = true; else all_dict = false;
             maxcap = std::max<size_t>(maxcap, j.dst_cap);
+            maxsrc = std::max<size_t>(maxsrc, j.src_len);
         } else {
             big[p.nbig++] = (uint32_t)i;
             if (j.dst_cap > kBlockMax) { p.multi = true; p.nmulti++; }
@@ -289,6 +293,22 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
     if (p.nsmall) {
         p.small_g = (p.with_dict && all_dict) ? 64 : 16;
         p.lit_stride = (uint32_t)align_up(maxcap + 64, 64);
+        p.lds_kernel = force != 6;
+        // the LDS kernel's slots: sized for the launch's largest file.  Files that all name a dictionary bring no tables of their
+        // own in the plain case (a file that does is handed on); else 2 KiB hold a 10-bit Huffman table, later 256 FSE entries
+        // (three tables of <= 512 sequences), 4 KiB twice that
+        p.lds_tab = (p.with_dict && all_dict) ? 0u : (maxcap <= 5120 ? 2048u : 4096u);
+        p.lds_comp = (uint32_t)align_up(maxsrc + 16, 16);
+        p.lds_out = (uint32_t)std::max<size_t>(1024, align_up(maxcap + 16, 16));
+        {   // files per wavefront: more files per wavefront make better use of the lanes in the serial phases, fewer give a
+            // CU more wavefronts to overlap -- the largest G that still leaves four wavefronts on a CU, else 4
+            static const int env_g = getenv("MZD_LDS_G") ? atoi(getenv("MZD_LDS_G")) : 0;
+            p.lds_g = 4;
+            for (int g : {16, 8})
+                if (160u * 1024u / lds_kernel_bytes(g, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out) >= 4) { p.lds_g = g; break; }
+            if (env_g == 4 || env_g == 8 || env_g == 16) p.lds_g = env_g;
+            while (p.lds_g > 4 && lds_kernel_bytes(p.lds_g, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out) > 160u * 1024u) p.lds_g /= 2;
+        }
         if (p.with_dict) // groups share one dictionary's tables: sort by dictionary (stable)
             std::stable_sort(small, small + p.nsmall, [&](uint32_t x, uint32_t y) { return jobs[x].dict < jobs[y].dict; });
     }
@@ -325,7 +345,22 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     ka.resolve = !use_tasks || force == 5 ? 0u : ((force == 4 || p.blocks <= 8ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : 2u);
     HIPCHK(hipEventRecord(ev0, s));
     uint32_t grid;
-    if (p.nsmall) {
+    if (p.nsmall && p.lds_kernel) {
+        LdsArgs la;
+        la.jobs = d_jobs; la.list = d_lists; la.n = p.nsmall; la.counter = l.counter;
+        la.redo_list = const_cast<uint32_t*>(d_lists) + njobs + p.nbig;
+        la.dicts = d.d_dicts; la.ndicts = d.ndicts;
+        la.tab_bytes = p.lds_tab; la.comp_bytes = p.lds_comp; la.out_bytes = p.lds_out;
+        la.stamps = reinterpret_cast<uint64_t*>(d.debug); // (diagnostic builds: the first debug slot's first bytes; unused otherwise)
+        const uint32_t ngroups = (p.nsmall + (uint32_t)p.lds_g - 1) / (uint32_t)p.lds_g;
+        const uint32_t lds = lds_kernel_bytes(p.lds_g, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out);
+        uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(8u, (160u * 1024u) / lds)); // one wavefront per workgroup
+        resident = std::max<uint32_t>(1u, resident * l.nwg / d.max_wg);
+        launch_lds(la, std::min(ngroups, resident), p.lds_g, p.with_dict ? 1 : 0, s);
+        HIPCHK(hipGetLastError());
+        ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig;
+        grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
+    } else if (p.nsmall) {
         SmallArgs sa;
         sa.jobs = d_jobs; sa.small_list = d_lists; sa.nsmall = p.nsmall; sa.counter = l.counter;
         sa.redo_list = const_cast<uint32_t*>(d_lists) + njobs + p.nbig;
@@ -991,10 +1026,10 @@ int mzd_load_dict(const uint8_t* dict, size_t n, uint32_t* dict_id) {
         HIPCHK(hipSetDevice(d.hip_id));
         uint8_t* buf = nullptr;
         int32_t* st = nullptr;
-        HIPCHK(hipMalloc(&buf, align_up(n + MZD_SRC_PADDING, kAlign)));
+        HIPCHK(hipMalloc(&buf, align_up(n + 64, kAlign))); // (readable 32 bytes past the content: mzd_lds.hip fetches dictionary matches in two 16-byte pieces)
         hipFree(d.dict_bufs[slot]);
         d.dict_bufs[slot] = buf;
-        HIPCHK(hipMemset(buf, 0, align_up(n + MZD_SRC_PADDING, kAlign)));
+        HIPCHK(hipMemset(buf, 0, align_up(n + 64, kAlign)));
         HIPCHK(hipMemcpy(buf, dict, n, hipMemcpyHostToDevice));
         HIPCHK(hipMalloc(&st, 64));
         HIPCHK(hipMemset(st, 0xFF, 64));
@@ -1096,12 +1131,12 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
 }
 
 // Diagnostic (a build with -DMZD_SMALL_STAMPS): the 8 phase stamps of the small-file kernel's workgroup 0.
-int mzd_debug_small_stamps(int device, uint64_t* out8) { // (12 values)
+int mzd_debug_small_stamps(int device, uint64_t* out8) { // (24 values)
     auto dp = get_device(device);
     if (!dp || !out8) return MZD_E_PARAM;
     WholeGuard g(*dp);
     HIPCHK(hipSetDevice(dp->hip_id));
-    HIPCHK(hipMemcpy(out8, dp->debug, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out8, dp->debug, 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MZD_OK;
 }
 

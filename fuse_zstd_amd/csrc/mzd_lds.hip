@@ -1,0 +1,1084 @@
+// mzd_lds.hip -- the small-file kernel: a file's whole decode inside LDS.
+//
+// Same arithmetic as mzd_kernels.hip (the frame decoder behind `zstd::stream::copy_decode`, reference
+// src/main.rs:463-467; format: RFC 8878 / SURVEY.md Appendix A), for the corpus the reference's own benchmark reads
+// (benchmarks/parallel-files.fio:3-7: thousands of files of a few KiB).  A wavefront takes a GROUP of G files and gives
+// each LPF = 64 / G lanes; everything a file needs lives in its LDS slot from the first byte to the last:
+//
+//     slot = [ tables | ring | compressed input | output window ]
+//
+//   * the compressed file is copied into the slot once, 16 bytes per lane (coalesced); every parser and bit reader
+//     works on LDS bytes;
+//   * Huffman literals are decoded into the TAIL of the output window (cap - nlit ..): the write head of the execution
+//     never passes the literal read head (what is still to be written is at least the literals still to be read), so
+//     literals and output share the window;
+//   * the FSE state walk does only what the chain needs (three table reads, one bitstream window, the three state
+//     updates: mzd_k_walk.h's step, with per-lane tables) and records its state per sequence in the ring; field
+//     extraction is done by LPF lanes at once, a lane per sequence, from those records;
+//   * sequences are executed in order by the file's LPF lanes, a byte per lane, LDS -> LDS: a match is a read and a
+//     write of the output window, never an HBM round trip;
+//   * XXH64 reads the window; the finished file leaves LDS with whole-wavefront 16-byte stores (to the destination and,
+//     when the caller's buffer is pinned host memory, to its mirror: DevJob::dst2).
+// Chains that are serial by construction (Huffman weights, normalized counts, the state walk) run on one lane per file,
+// the files of a group in lockstep.  Only the plain case is decoded here: ONE frame of ONE block without an error of any
+// kind.  Anything else -- several frames or blocks, skippable frames, tables that do not fit the slot, every malformed
+// input -- is handed on untouched (nothing has left LDS by then): the job index is appended to the launch's redo list and
+// the general driver behind this kernel decodes it, so error classes and their order stay those of the block pipeline.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+#include <type_traits>
+
+#include "../../include/mzd.h"
+#include "mzd_device.h"
+#include "mzd_tables.h"
+
+namespace mzd {
+namespace lw {
+
+#define DI __device__ __forceinline__
+
+typedef const __attribute__((address_space(1))) uint8_t* gcp;
+typedef __attribute__((address_space(1))) uint8_t* gp;
+struct V16 { uint64_t a, b; }; // 16 bytes, any alignment
+DI V16 gv16(const uint8_t* p) { V16 v; __builtin_memcpy(&v, (gcp)p, 16); return v; }
+DI void gsv16(uint8_t* p, const V16& v) { __builtin_memcpy((gp)p, &v, 16); }
+DI uint32_t gu32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, (gcp)p, 4); return v; }
+DI uint32_t gu8(const uint8_t* p) { return *(gcp)p; }
+DI void gs8(uint8_t* p, uint32_t v) { *(gp)p = (uint8_t)v; }
+DI int hibit32(uint32_t v) { return 31 - __builtin_clz(v); }
+DI uint32_t bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); } // (offset and width: low 5 bits)
+
+// ------------------------------------------------------------------------------------ LDS image (dynamic)
+extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+DI uint32_t& L32(uint32_t off) { return *reinterpret_cast<uint32_t*>(lds + off); }
+DI uint16_t& L16(uint32_t off) { return *reinterpret_cast<uint16_t*>(lds + off); }
+DI int16_t& L16s(uint32_t off) { return *reinterpret_cast<int16_t*>(lds + off); }
+DI uint8_t& L8(uint32_t off) { return lds[off]; }
+DI uint64_t& L64(uint32_t off) { return *reinterpret_cast<uint64_t*>(lds + off); } // 8-byte aligned
+DI uint64_t lds_u64(uint32_t off) { uint64_t v; __builtin_memcpy(&v, lds + off, 8); return v; } // any alignment
+DI uint32_t lds_u32(uint32_t off) { uint32_t v; __builtin_memcpy(&v, lds + off, 4); return v; }
+DI V16 lds_v16(uint32_t off) { return *reinterpret_cast<const V16*>(lds + off); } // 16-byte aligned
+DI void lds_sv16(uint32_t off, const V16& v) { *reinterpret_cast<V16*>(lds + off) = v; }
+
+DI void lds_s64(uint32_t off, uint64_t v) { __builtin_memcpy(lds + off, &v, 8); } // any alignment
+DI void lds_s32(uint32_t off, uint32_t v) { __builtin_memcpy(lds + off, &v, 4); }
+DI void lds_s16(uint32_t off, uint32_t v) { const uint16_t w = (uint16_t)v; __builtin_memcpy(lds + off, &w, 2); }
+
+// The lanes of a wavefront talk through LDS without a barrier: a wavefront's LDS operations execute in issue order, so a
+// read issued after another lane's write sees it.  What has to be kept is the ORDER OF ISSUE: no memory operation moves
+// across this point.
+DI void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("" ::: "memory");
+}
+
+// shared by the wavefront: code tables; the dictionary's image (DICT)
+constexpr uint32_t kShLL = 0;     // uint32 [36]: baseline | extra bits << 24
+constexpr uint32_t kShML = 144;   // uint32 [53]
+constexpr uint32_t kShDump = 384;  // 8 bytes per lane: where the stores of idle lanes go (select-style code: no branch around a store)
+constexpr uint32_t kShBytes = 896;
+constexpr uint32_t kDLL = 0, kDML = 4096, kDOF = 8192, kDHuf = 10240, kDictImg = 14336; // FSE entries of 8 bytes, Huffman entries of 2
+constexpr uint32_t kAux = 256;    // per file: the normalized counts of the three sequence tables, later the walk records / the plan
+// scratch of the Huffman weights, in the (still empty) output window: weights [256] | their FSE table [64 x 8] | its counts | rank counters
+constexpr uint32_t kWts = 0, kWTab = 256, kWNorm = 768, kWRank = 800, kWScratch = 832;
+
+// ---- the file's LPF lanes (LPF = 16, 8 or 4: inside one DPP row of 16 lanes)
+// the value of the lane N below, 0 for the file's first N lanes
+template <int N, int LPF> DI uint32_t seg_shr(uint32_t v, uint32_t sub) {
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xF, 0xF, false); // row_shr:N
+    return (LPF == 16 || sub >= (uint32_t)N) ? t : 0u;
+}
+// the value of the file's lane K, in all its lanes
+template <int K, int LPF> DI uint32_t bcast(uint32_t v) {
+    if (LPF == 16) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 + K, 0xF, 0xF, false); // row_newbcast:K
+    if (LPF == 8) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x150 + (K & 7), 0xF, 0x3, false);
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x150 + 8 + (K & 7), 0xF, 0xC, false);
+    }
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, (K & 3) * 0x55, 0xF, 0xF, false); // quad_perm: [K, K, K, K]
+}
+// Lane masks and selects that stay selects: left to itself the compiler turns a chain of `c == k ? a : b` into exec-mask
+// branch regions (two or three scalar instructions and a branch each; on a lone wavefront every one of them costs an issue slot)
+typedef uint64_t lmask;
+DI lmask m_eq(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32); }
+DI lmask m_ne(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 33); }
+DI lmask m_gt(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 34); }
+DI lmask m_ge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35); }
+DI lmask m_lt(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 36); }
+DI lmask m_le(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 37); }
+DI uint32_t sel(lmask m, uint32_t t, uint32_t f) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m)); return r; }
+// ---- repeat offsets (A.5) as a scan.  The state before a sequence is three REFERENCES: to one of the three offsets the step
+// started with (0, 1, 2) or to the offset value a sequence of the step brought along (0x10 | its lane in the file).  A sequence is
+// a transform of that triple -- a new offset: (own, s0, s1); "repeat 0": identity; 1: (s1, s0, s2); 2: (s2, s0, s1) -- kept as
+// three bytes, and composing two of them is one byte permute: the later one's bytes select among the earlier one's, except where
+// they are constants.  ("repeat 0 minus one" makes a new VALUE out of a reference: steps that hold one take the serial form.)
+constexpr uint32_t kRepId = 0x03020100u;
+DI uint32_t rep_compose(uint32_t later, uint32_t earlier) {
+    const uint32_t p = __builtin_amdgcn_perm(0u, earlier, later);
+    const uint32_t mask = ((later & 0x00101010u) >> 4) * 0xFFu;
+    return (later & mask) | (p & ~mask);
+}
+template <int N, int LPF> DI uint32_t rep_shr(uint32_t v, uint32_t sub) { // the transform of the lane N below, the identity for the file's first N lanes
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)kRepId, (int)v, 0x110 + N, 0xF, 0xF, false);
+    return (LPF == 16 || sub >= (uint32_t)N) ? t : kRepId;
+}
+
+// n (<= 31) bytes, held in d[0..7], to LDS offset `at`: exact pieces of 16 / 8 / 4 / 2 / 1; a lane without a piece stores to `dump`
+DI void store_exact31(uint32_t at, uint32_t n, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t d4, uint32_t d5, uint32_t d6, uint32_t d7, uint32_t dump) {
+    const lmask m16 = m_ne(n & 16, 0), m8 = m_ne(n & 8, 0), m4 = m_ne(n & 4, 0), m2 = m_ne(n & 2, 0), m1 = m_ne(n & 1, 0);
+    const uint32_t a16 = sel(m16, at, dump);
+    lds_s64(a16, (uint64_t)d0 | ((uint64_t)d1 << 32)); lds_s64(sel(m16, at + 8, dump), (uint64_t)d2 | ((uint64_t)d3 << 32));
+    d0 = sel(m16, d4, d0); d1 = sel(m16, d5, d1); d2 = sel(m16, d6, d2); d3 = sel(m16, d7, d3); at += n & 16;
+    lds_s64(sel(m8, at, dump), (uint64_t)d0 | ((uint64_t)d1 << 32));
+    d0 = sel(m8, d2, d0); d1 = sel(m8, d3, d1); at += n & 8;
+    lds_s32(sel(m4, at, dump), d0);
+    d0 = sel(m4, d1, d0); at += n & 4;
+    lds_s16(sel(m2, at, dump), d0);
+    d0 = sel(m2, d0 >> 16, d0); at += n & 2;
+    L8(sel(m1, at, dump)) = (uint8_t)d0;
+}
+template <int N, class F> DI void static_for(F&& f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
+// FSE decode entry, 8 bytes (mzd_k_tables.h: pack_entry): low word = LDS address of the entry of next-state base (so that
+// the new state's address is low + 8 * bits); high word = nbBits | (extra + nbBits) << 8 | symbol << 16 | extra << 24
+DI uint64_t fse_entry(uint32_t tab_off, uint32_t nbase, uint32_t nb, uint32_t sym, uint32_t extra) {
+    return (uint64_t)(tab_off + nbase * 8u) | ((uint64_t)(nb | ((extra + nb) << 8) | (sym << 16) | (extra << 24)) << 32);
+}
+
+// ------------------------------------------------------------------------------------ bit readers over LDS bytes
+struct LBack { // backward (the Huffman weights' stream: <= 128 bytes), zero below the start
+    uint32_t base;
+    int32_t h;
+    uint64_t cur;
+    int32_t avail;
+    DI bool init(uint32_t off, uint32_t sl) {
+        base = off; cur = 0; avail = 0; h = 0;
+        if (sl == 0) return false;
+        const uint32_t last = lds[off + sl - 1];
+        if (last == 0) return false;
+        h = (int32_t)((sl - 1) * 8) + hibit32(last);
+        return true;
+    }
+    DI void refill() {
+        if (h <= 0) { cur = 0; avail = 64; return; }
+        const int32_t b = (h - 1) >> 3;
+        uint64_t W = b >= 7 ? lds_u64(base + (uint32_t)(b - 7)) : lds_u64(base) << (8 * (7 - b)); // (bytes before the stream are not its own)
+        const int32_t sh = 8 * (b + 1) - h;
+        cur = W << sh;
+        avail = 64 - sh;
+        if (h < avail) cur &= ~0ull << (64 - h);
+    }
+    DI uint32_t read(uint32_t n) { // n <= 32
+        if ((int32_t)n > avail) refill();
+        const uint32_t v = n ? (uint32_t)(cur >> (64 - n)) : 0u;
+        cur <<= n; avail -= (int32_t)n; h -= (int32_t)n;
+        return v;
+    }
+};
+
+// Normalized counts (A.3) from LDS bytes (>= 8 readable bytes behind them) -> int16 norm[] in LDS at `norm_off`.  Returns bytes
+// used or 0 (give up).  sym_cap: symbols the caller has room for (<= max_sym + 1).  Every field (<= 10 bits) is one unaligned
+// 4-byte read at its bit position.  Bits past the description's end need no masking: a read that touches them either leaves
+// `bit` past the limit (rejected), or it is the short form of a value whose dropped bit was the only one outside.
+DI uint32_t read_ncount_lane(uint32_t src_off, uint32_t n, int max_log, int max_sym, int sym_cap, uint32_t norm_off, uint32_t& nsym_out, uint32_t& log_out) {
+    if (n < 1) return 0;
+    const int32_t limit = (int32_t)(n > 4096 ? 4096 : n) * 8;
+    auto bits = [&](int32_t bit) -> uint32_t { return lds_u32(src_off + ((uint32_t)bit >> 3)) >> (bit & 7); }; // >= 25 bits
+    int32_t bit = 4;
+    const int al = 5 + (int)(bits(0) & 15);
+    if (al > max_log) return 0;
+    int remaining = 1 << al, sym = 0;
+    bool bad = false;
+    while (remaining > 0 && sym <= max_sym && !bad) {
+        const int nb = hibit32((uint32_t)(remaining + 1)) + 1;
+        bad |= bit >= limit;
+        const int val = (int)(bits(bit) & ((1u << nb) - 1));
+        const int lower = (1 << (nb - 1)) - 1;
+        const int thr = (1 << nb) - 1 - (remaining + 1);
+        const bool small = (val & lower) < thr;
+        const int v2 = small ? (val & lower) : (val > lower ? val - thr : val);
+        bit += small ? nb - 1 : nb;
+        const int pr = v2 - 1;
+        remaining -= (pr < 0) ? 1 : pr;
+        bad |= (remaining < 0) | (sym >= sym_cap);
+        if (bad) break;
+        L16s(norm_off + 2 * (uint32_t)sym) = (int16_t)pr;
+        sym++;
+        if (pr == 0) { // runs of zero-probability symbols: 2 bits each, 3 = "and more"
+            for (;;) {
+                if (bit >= limit) { bad = true; break; }
+                const int r = (int)(bits(bit) & 3);
+                bit += 2;
+                if (sym + r > max_sym + 1 || sym + r > sym_cap) { bad = true; break; }
+                for (int i = 0; i < r; i++) L16s(norm_off + 2 * (uint32_t)(sym + i)) = 0;
+                sym += r;
+                if (r != 3) break;
+            }
+        }
+    }
+    if (bad || remaining != 0 || sym > max_sym + 1 || bit > limit) return 0;
+    nsym_out = (uint32_t)sym;
+    log_out = (uint32_t)al;
+    return (uint32_t)((bit + 7) >> 3);
+}
+
+// FSE decode table (A.3) by ONE lane: `tab_off` LDS offset of the 8-byte entries, norm[] in LDS.  kind 0 LL, 1 OF, 2 ML,
+// 3 Huffman weights (no extra bits).  Nothing is read back from LDS: a symbol's positions (the spread of A.3 visits them in
+// stride order) are collected as a bit mask in registers -- W words of 64 positions -- and numbered in ascending position
+// order straight from the mask (a lone lane pays a round trip per dependent LDS read: the textbook form, which re-reads the
+// spread symbols and keeps the state counters in memory, costs two per entry).
+template <int W>
+DI bool build_fse_mask(uint32_t tab_off, uint32_t norm_off, uint32_t nsym, uint32_t log, int kind) {
+    const uint32_t size = 1u << log, mask = size - 1;
+    const uint32_t step = (size >> 1) + (size >> 3) + 3;
+    auto extra_of = [&](uint32_t s) -> uint32_t { return kind == 0 ? L32(kShLL + 4 * s) >> 24 : (kind == 1 ? s : (kind == 2 ? L32(kShML + 4 * s) >> 24 : 0u)); };
+    uint32_t high = size;
+    for (uint32_t s = 0; s < nsym; s++) // "less than one": a single state at the top, numbered 1 -> nbBits = log, next-state base 0
+        if (L16s(norm_off + 2 * s) == -1) { high--; L64(tab_off + 8 * high) = fse_entry(tab_off, 0, log, s, extra_of(s)); }
+    uint32_t pos = 0;
+    for (uint32_t s = 0; s < nsym; s++) {
+        const int c = L16s(norm_off + 2 * s);
+        if (c <= 0) continue;
+        uint64_t m[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) m[w] = 0;
+        for (int i = 0; i < c; i++) {
+#pragma unroll
+            for (int w = 0; w < W; w++) m[w] |= (W == 1 || (pos >> 6) == (uint32_t)w) ? 1ull << (pos & 63) : 0ull;
+            do { pos = (pos + step) & mask; } while (pos >= high);
+        }
+        const uint32_t extra = extra_of(s);
+        uint32_t d = (uint32_t)c;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            uint64_t mm = m[w];
+            while (mm) {
+                const uint32_t p = (uint32_t)__builtin_ctzll(mm) + 64u * (uint32_t)w;
+                mm &= mm - 1;
+                const uint32_t nb = log - (uint32_t)hibit32(d);
+                L64(tab_off + 8 * p) = fse_entry(tab_off, (d << nb) - size, nb, s, extra);
+                d++;
+            }
+        }
+    }
+    return pos == 0;
+}
+DI bool build_fse_lane(uint32_t tab_off, uint32_t norm_off, uint32_t nsym, uint32_t log, int kind) {
+    if (log <= 6) return build_fse_mask<1>(tab_off, norm_off, nsym, log, kind);
+    if (log == 7) return build_fse_mask<2>(tab_off, norm_off, nsym, log, kind);
+    if (log == 8) return build_fse_mask<4>(tab_off, norm_off, nsym, log, kind);
+    return build_fse_mask<8>(tab_off, norm_off, nsym, log, kind);
+}
+
+// ------------------------------------------------------------------------------------ XXH64 pieces (A.6), over LDS bytes
+DI uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+DI uint64_t xround(uint64_t acc, uint64_t in) { acc += in * XP2; acc = rotl64(acc, 31); return acc * XP1; }
+DI uint64_t xmerge(uint64_t hh, uint64_t v) { v = xround(0, v); hh ^= v; return hh * XP1 + XP4; }
+DI uint64_t xxh_tail(uint64_t hh, uint32_t q, uint32_t end) {
+    while (q + 8 <= end) { hh ^= xround(0, lds_u64(q)); hh = rotl64(hh, 27) * XP1 + XP4; q += 8; }
+    if (q + 4 <= end) { hh ^= (uint64_t)lds_u32(q) * XP1; hh = rotl64(hh, 23) * XP2 + XP3; q += 4; }
+    while (q < end) { hh ^= (uint64_t)L8(q) * XP5; hh = rotl64(hh, 11) * XP1; q++; }
+    hh ^= hh >> 33; hh *= XP2; hh ^= hh >> 29; hh *= XP3; hh ^= hh >> 32;
+    return hh;
+}
+
+// Diagnostic build only (-DMZD_SMALL_STAMPS): cycle counter of workgroup 0 at every phase boundary of its first group.
+#ifdef MZD_SMALL_STAMPS
+#define SSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) a.stamps[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SSTAMP(k)
+#endif
+
+// A match the in-order step's one-byte-per-lane form does not cover: longer than LPF, overlapping its own output, or
+// starting in the dictionary content (logically just before the frame).  The file's lanes, a byte each per round.
+template <int LPF, bool DICT>
+__device__ __noinline__ void rare_match(uint32_t outo, uint32_t mp, uint32_t off, uint32_t m, uint32_t sub, const uint8_t* dict_end, uint32_t dict_len) {
+    if (off - 1 >= mp + dict_len) return; // (a wrong offset: the file is handed on)
+    if (DICT && off > mp) {
+        const uint32_t back = off - mp;
+        const uint32_t n1 = m < back ? m : back;
+        for (uint32_t q = sub; q < n1; q += LPF) L8(outo + mp + q) = (uint8_t)gu8(dict_end - back + q);
+        mp += n1; m -= n1;
+        if (!m) return;
+    }
+    asm volatile("" ::: "memory");
+    if (off >= LPF || off >= m) { // a round never reads what it writes
+        for (uint32_t q = sub; q < m; q += LPF) { const uint32_t v = L8(outo + mp - off + q); asm volatile("" ::: "memory"); L8(outo + mp + q) = (uint8_t)v; asm volatile("" ::: "memory"); }
+    } else { // period < LPF: every lane repeats one byte of the pattern
+        uint32_t rr = sub; // sub mod off
+        if (rr >= 8 * off) rr -= 8 * off;
+        if (rr >= 4 * off) rr -= 4 * off;
+        if (rr >= 2 * off) rr -= 2 * off;
+        if (rr >= off) rr -= off;
+        uint32_t per = off; // the largest multiple of the period <= LPF
+        while (per + off <= LPF) per += off;
+        const uint32_t v = L8(outo + mp - off + rr);
+        asm volatile("" ::: "memory");
+        if (sub < per) for (uint32_t q = sub; q < m; q += per) L8(outo + mp + q) = (uint8_t)v;
+    }
+    asm volatile("" ::: "memory");
+}
+
+struct DictInfo { // the dictionary whose image sits in LDS (wave-uniform)
+    uint32_t handle, formatted, dict_id, content_len, huf_log;
+    uint32_t al[3], rep[3];
+    const uint8_t* content;
+};
+
+// ------------------------------------------------------------------------------------ the kernel
+// One wavefront per workgroup; a persistent loop over groups of G files.
+template <int G, bool DICT>
+__global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
+    constexpr uint32_t LPF = 64 / G; // lanes per file = sequences per plan step
+    static_assert(LPF >= 4, "four Huffman streams, four XXH64 accumulators");
+    const uint32_t lane = threadIdx.x;
+    const uint32_t f = lane / LPF, sub = lane % LPF;
+    const bool leader = sub == 0;
+    const uint32_t dict_off = kShBytes;
+    const uint32_t stride = a.tab_bytes + kAux + a.comp_bytes + a.out_bytes;
+    const uint32_t tabo = kShBytes + (DICT ? kDictImg : 0u) + f * stride; // the file's slot
+    const uint32_t ringo = tabo + a.tab_bytes, cmp = ringo + kAux, outo = cmp + a.comp_bytes;
+
+    if (lane < 36) L32(kShLL + 4 * lane) = LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24);
+    if (lane < 53) L32(kShML + 4 * lane) = ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24);
+    wsync();
+    DictInfo di;
+    di.handle = 0; di.formatted = 0; di.dict_id = 0; di.content_len = 0; di.huf_log = 0; di.content = nullptr;
+    for (int t = 0; t < 3; t++) { di.al[t] = 0; di.rep[t] = 0; }
+
+    const uint32_t ngroups = (a.n + G - 1) / G;
+    bool first_group = true;
+    (void)first_group;
+    for (;;) {
+        uint32_t g = 0;
+        SSTAMP(0);
+        if (lane == 0) g = atomicAdd(&a.counter[5], 1u);
+        g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+        if (g >= ngroups) break;
+
+        // =============================== the group's files: job entries, then the compressed bytes -> LDS
+        const uint32_t fidx = g * G + f;
+        const bool have = fidx < a.n;
+        uint32_t job = 0;
+        const uint8_t* src = nullptr; uint8_t* dst = nullptr; uint8_t* dst2 = nullptr;
+        uint32_t n = 0, cap = 0, jdict = 0;
+        bool fits = false;
+        if (have) {
+            job = a.list[fidx];
+            const DevJob& dj = a.jobs[job];
+            src = dj.src; dst = dj.dst; dst2 = dj.dst2; jdict = dj.dict;
+            fits = dj.src_len + 16 <= a.comp_bytes && dj.dst_cap + 16 <= a.out_bytes; // (the host sized the slots for the launch's largest file)
+            n = fits ? (uint32_t)dj.src_len : 0u; cap = fits ? (uint32_t)dj.dst_cap : 0u;
+        }
+        if (fits) { // 16 bytes per lane, four loads in flight (inputs are readable MZD_SRC_PADDING bytes past their end)
+            uint32_t k = sub * 16;
+            for (; k + 3 * LPF * 16 < n; k += 4 * LPF * 16) {
+                const V16 v0 = gv16(src + k), v1 = gv16(src + k + LPF * 16), v2 = gv16(src + k + 2 * LPF * 16), v3 = gv16(src + k + 3 * LPF * 16);
+                lds_sv16(cmp + k, v0); lds_sv16(cmp + k + LPF * 16, v1); lds_sv16(cmp + k + 2 * LPF * 16, v2); lds_sv16(cmp + k + 3 * LPF * 16, v3);
+            }
+            for (; k < n; k += LPF * 16) lds_sv16(cmp + k, gv16(src + k));
+        }
+        // the group's dictionary: the first one named (the host sorts the list by dictionary)
+        if (DICT) {
+            const uint64_t named = __ballot(have && jdict != 0 && jdict <= a.ndicts);
+            if (named) {
+                const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)jdict, __builtin_ctzll(named));
+                if (want != di.handle) {
+                    const DevDict* dd = &a.dicts[want - 1];
+                    di.handle = want; di.formatted = dd->formatted; di.dict_id = dd->dict_id; di.content_len = dd->content_len;
+                    di.huf_log = dd->huf_log; di.content = dd->content;
+                    for (int t = 0; t < 3; t++) { di.al[t] = dd->al[t]; di.rep[t] = dd->rep[t]; }
+                    if (di.formatted) { // (entries as the block pipeline keeps them: next-state offsets relative to the table -> LDS addresses)
+                        for (uint32_t i = lane; i < 512; i += 64) { L64(dict_off + kDLL + 8 * i) = dd->ll[i] + (dict_off + kDLL); L64(dict_off + kDML + 8 * i) = dd->ml[i] + (dict_off + kDML); }
+                        for (uint32_t i = lane; i < 256; i += 64) L64(dict_off + kDOF + 8 * i) = dd->of[i] + (dict_off + kDOF);
+                        for (uint32_t i = lane; i < 1024; i += 64) L32(dict_off + kDHuf + 4 * i) = reinterpret_cast<const uint32_t*>(dd->huf)[i];
+                    }
+                }
+            }
+        }
+        wsync();
+        SSTAMP(1);
+
+        // =============================== headers: frame, block, literals section (every lane of the file, from LDS)
+        bool ok = have && fits; // still on the fast path
+        bool done = false;      // finished without a block to decode (empty file, raw / RLE block)
+        uint32_t out_len = 0, res_off = outo; // the decoded file: out_len bytes at LDS offset res_off
+        uint32_t has_fcs = 0, has_ck = 0, fcs = 0, btype = 0, bsize = 0, b0 = 0;
+        uint32_t lit_type = 0, nlit = 0, streams = 0, lit_off = 0, tree_off = 0, tree_len = 0;
+        uint32_t s_len0 = 0, s_len1 = 0, s_len2 = 0, s_len3 = 0, s_base = 0;
+        uint32_t seq_off = 0, seq_len = 0;
+        const bool with_d = DICT && ok && jdict != 0;
+        if (ok && n == 0) { done = true; } // no frame at all: nothing to decode
+        else if (ok) {
+            ok = false;
+            do {
+                if (jdict > a.ndicts || (jdict && (!DICT || jdict != di.handle))) break;
+                if (n < 9) break;
+                if (lds_u32(cmp) != 0xFD2FB528u) break;
+                const uint32_t fhd = L8(cmp + 4);
+                const uint32_t fcsf = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+                if (fhd & 8) break;
+                const uint32_t did_sz = did == 3 ? 4u : did, fcs_sz = fcsf == 0 ? single : (1u << fcsf);
+                const uint32_t hs = 5 + (single ? 0u : 1u) + did_sz + fcs_sz;
+                if (n < hs + 3) break;
+                uint32_t q = 5;
+                uint64_t window = 0;
+                if (!single) { const uint32_t b = L8(cmp + q); q++; const uint32_t wl = 10 + (b >> 3); window = (1ull << wl) + ((1ull << wl) >> 3) * (b & 7); }
+                uint32_t frame_dict = 0;
+                if (did_sz) { frame_dict = lds_u32(cmp + q) & (did_sz == 4 ? 0xFFFFFFFFu : ((1u << (8 * did_sz)) - 1)); q += did_sz; }
+                has_fcs = 1;
+                uint64_t fcs64 = 0;
+                if (fcsf == 0) { if (single) fcs64 = L8(cmp + q); else has_fcs = 0; }
+                else if (fcsf == 1) fcs64 = (lds_u32(cmp + q) & 0xFFFF) + 256;
+                else if (fcsf == 2) fcs64 = lds_u32(cmp + q);
+                else fcs64 = lds_u64(cmp + q);
+                if (single) window = fcs64;
+                if (window > (1ull << 27) + 1) break;
+                const uint32_t block_max = (uint32_t)(window < kBlockMax ? window : kBlockMax);
+                has_ck = (fhd >> 2) & 1;
+                if (frame_dict && frame_dict != (with_d && di.formatted ? di.dict_id : 0u)) break;
+                if (has_fcs && fcs64 > cap) break;
+                fcs = (uint32_t)fcs64;
+                const uint32_t bh = lds_u32(cmp + hs) & 0xFFFFFF;
+                const uint32_t last = bh & 1;
+                btype = (bh >> 1) & 3; bsize = bh >> 3;
+                if (!last || btype == 3 || bsize > block_max) break;
+                const uint32_t body = btype == 1 ? 1u : bsize;
+                if ((uint64_t)hs + 3 + body + (has_ck ? 4u : 0u) != n) break; // exactly one frame of one block, nothing behind it
+                b0 = hs + 3;
+                if (btype < 2) {
+                    if (bsize > cap || (has_fcs && fcs != bsize)) break;
+                    out_len = bsize; done = true; ok = true;
+                    break;
+                }
+                if (bsize < 2) break;
+                // ---- literals section header (A.4)
+                const uint64_t lb = lds_u64(cmp + b0);
+                const uint32_t c0 = (uint32_t)lb & 0xFF, c1 = (uint32_t)(lb >> 8) & 0xFF, c2 = (uint32_t)(lb >> 16) & 0xFF;
+                const uint32_t sf = (c0 >> 2) & 3;
+                lit_type = c0 & 3;
+                uint32_t hl, regen, comp = 0;
+                if (lit_type < 2) {
+                    if (sf == 0 || sf == 2) { hl = 1; regen = c0 >> 3; }
+                    else if (sf == 1) { hl = 2; regen = (c0 >> 4) + (c1 << 4); }
+                    else { if (bsize < 3) break; hl = 3; regen = (c0 >> 4) + (c1 << 4) + (c2 << 12); }
+                    if (regen > block_max || regen > cap) break;
+                    const uint32_t lbody = lit_type == 0 ? regen : 1u;
+                    if (hl + lbody >= bsize) break; // (the sequences section needs at least one byte)
+                    nlit = regen; streams = 0;
+                    lit_off = b0 + hl;
+                    seq_off = b0 + hl + lbody; seq_len = bsize - hl - lbody;
+                } else {
+                    if (bsize < 3) break;
+                    if (sf < 2) { hl = 3; const uint32_t v = (uint32_t)lb & 0xFFFFFF; regen = (v >> 4) & 0x3FF; comp = v >> 14; streams = sf ? 4 : 1; }
+                    else if (sf == 2) { if (bsize < 4) break; hl = 4; const uint32_t v = (uint32_t)lb; regen = (v >> 4) & 0x3FFF; comp = v >> 18; streams = 4; }
+                    else { if (bsize < 5) break; hl = 5; const uint64_t v = lb & 0xFFFFFFFFFFull; regen = (uint32_t)(v >> 4) & 0x3FFFF; comp = (uint32_t)(v >> 22); streams = 4; }
+                    if (regen > block_max || regen > cap || regen == 0 || (streams == 4 && regen < 6) || hl + comp >= bsize) break;
+                    uint32_t p_off = b0 + hl, rem = comp;
+                    if (lit_type == 2) {
+                        if (a.tab_bytes == 0) break; // no room for a private Huffman table in this launch's slots
+                        if (rem < 1) break;
+                        const uint32_t hb = L8(cmp + p_off);
+                        const uint32_t tl = hb >= 128 ? 1 + ((hb - 127) + 1) / 2 : 1 + hb;
+                        if (tl > rem || (hb < 128 && hb < 1)) break;
+                        tree_off = p_off; tree_len = tl;
+                        p_off += tl; rem -= tl;
+                    } else if (!(with_d && di.formatted)) break; // treeless without a table to reuse
+                    if (streams == 1) { s_base = p_off; s_len0 = rem; if (rem == 0) break; }
+                    else {
+                        if (rem < 10) break;
+                        const uint64_t jt = lds_u64(cmp + p_off);
+                        const uint32_t l1 = (uint32_t)jt & 0xFFFF, l2 = (uint32_t)(jt >> 16) & 0xFFFF, l3 = (uint32_t)(jt >> 32) & 0xFFFF;
+                        if (6 + l1 + l2 + l3 > rem) break;
+                        const uint32_t l4 = rem - 6 - l1 - l2 - l3;
+                        const uint32_t seg = (regen + 3) / 4;
+                        if (3 * seg > regen || !l1 || !l2 || !l3 || !l4) break;
+                        s_base = p_off + 6; s_len0 = l1; s_len1 = l2; s_len2 = l3; s_len3 = l4;
+                    }
+                    nlit = regen;
+                    seq_off = b0 + hl + comp; seq_len = bsize - hl - comp;
+                }
+                ok = true;
+            } while (false);
+        }
+        (void)tree_len;
+        bool live = ok && !done; // a compressed block to decode
+        // raw / RLE blocks: the content is the block's bytes where they lie / the window filled with the byte
+        if (ok && done && n != 0) {
+            if (btype == 0) res_off = cmp + b0;
+            else { const uint32_t v = L8(cmp + b0); for (uint32_t k = sub; k < bsize; k += LPF) L8(outo + k) = (uint8_t)v; }
+        }
+        const uint32_t lit_base = lit_type == 0 ? cmp + lit_off : outo + cap - nlit; // the literals: raw where they lie, else the window's tail
+        SSTAMP(2);
+
+        // =============================== Huffman weights and decode table (one lane per file)
+        uint32_t huf_log = di.huf_log, huf_off = dict_off + kDHuf; // treeless: the dictionary's table
+        if (live && lit_type == 2) {
+            uint32_t good = 0, maxbits_l = 0;
+            if (leader) {
+                const uint32_t wts = outo + kWts, wtab = outo + kWTab, wnorm = outo + kWNorm, so = outo + kWRank;
+                uint32_t nw = 0;
+                do {
+                    const uint32_t tp = cmp + tree_off; // the tree description
+                    const uint32_t hb = L8(tp);
+                    if (hb >= 128) { // direct: 4 bits per weight, high nibble first
+                        nw = hb - 127;
+                        for (uint32_t i = 0; i < nw; i++) {
+                            const uint32_t by = L8(tp + 1 + i / 2);
+                            L8(wts + i) = (uint8_t)((i & 1) ? (by & 15) : (by >> 4));
+                        }
+                    } else {
+                        uint32_t nsym = 0, log = 0;
+                        const uint32_t hdr = read_ncount_lane(tp + 1, hb, 6, 255, 16, wnorm, nsym, log);
+                        if (hdr == 0 || hdr >= hb) break;
+                        SSTAMP(13);
+                        if (!build_fse_lane(wtab, wnorm, nsym, log, 3)) break;
+                        SSTAMP(14);
+                        LBack rd;
+                        if (!rd.init(tp + 1 + hdr, hb - hdr)) break;
+                        rd.refill();
+                        uint32_t s1 = wtab + 8 * rd.read(log), s2 = wtab + 8 * rd.read(log);
+                        bool fin = false;
+                        for (;;) { // two interleaved states; the stream's over-read ends it (A.4)
+                            if (nw > 253) break;
+                            uint64_t e = L64(s1);
+                            uint32_t eh = (uint32_t)(e >> 32);
+                            L8(wts + nw) = (uint8_t)(eh >> 16); nw++;
+                            s1 = (uint32_t)e + 8 * rd.read(eh & 31);
+                            if (rd.h < 0) { L8(wts + nw) = (uint8_t)(L32(s2 + 4) >> 16); nw++; fin = true; break; }
+                            if (nw > 253) break;
+                            e = L64(s2);
+                            eh = (uint32_t)(e >> 32);
+                            L8(wts + nw) = (uint8_t)(eh >> 16); nw++;
+                            s2 = (uint32_t)e + 8 * rd.read(eh & 31);
+                            if (rd.h < 0) { L8(wts + nw) = (uint8_t)(L32(s1 + 4) >> 16); nw++; fin = true; break; }
+                        }
+                        if (!fin) break;
+                    }
+                    // ---- validation, implied last weight, canonical table (A.4)
+                    SSTAMP(15);
+                    if (nw < 1 || nw > 255) break;
+                    for (uint32_t r = 0; r < 16; r++) L16(so + 2 * r) = 0; // rank counters
+                    uint32_t total = 0;
+                    bool wbad = false;
+                    for (uint32_t i = 0; i < nw; i++) {
+                        const uint32_t w = L8(wts + i);
+                        if (w > 12) { wbad = true; break; }
+                        L16(so + 2 * w) = (uint16_t)(L16(so + 2 * w) + 1);
+                        total += w ? 1u << (w - 1) : 0u;
+                    }
+                    if (wbad || total == 0) break;
+                    const uint32_t maxbits = (uint32_t)hibit32(total) + 1;
+                    if (maxbits > 11 || (2u << maxbits) > a.tab_bytes) break; // (a table that does not fit the slot: the general path takes the file)
+                    const uint32_t left = (1u << maxbits) - total;
+                    if (left & (left - 1)) break;
+                    const uint32_t wl = (uint32_t)hibit32(left) + 1;
+                    L8(wts + nw) = (uint8_t)wl; nw++;
+                    L16(so + 2 * wl) = (uint16_t)(L16(so + 2 * wl) + 1);
+                    const uint32_t r1 = L16(so + 2);
+                    if (r1 < 2 || (r1 & 1)) break;
+                    uint32_t pos = 0; // rank counters -> start positions (weight 1 = longest codes first)
+                    for (uint32_t r = 1; r <= maxbits; r++) { const uint32_t c = L16(so + 2 * r); L16(so + 2 * r) = (uint16_t)pos; pos += c << (r - 1); }
+                    if (pos != (1u << maxbits)) break; // also catches weights above maxbits
+                    SSTAMP(16);
+                    for (uint32_t s = 0; s < nw; s++) {
+                        const uint32_t w = L8(wts + s);
+                        if (!w) continue;
+                        const uint32_t cnt = 1u << (w - 1), at = L16(so + 2 * w);
+                        L16(so + 2 * w) = (uint16_t)(at + cnt);
+                        const uint32_t e = s | ((maxbits + 1 - w) << 8);
+                        if (cnt == 1) L16(tabo + 2 * at) = (uint16_t)e;
+                        else for (uint32_t i = 0; i < cnt; i += 2) L32(tabo + 2 * (at + i)) = e | (e << 16);
+                    }
+                    maxbits_l = maxbits;
+                    good = 1;
+                } while (false);
+            }
+            good = (uint32_t)__shfl((int)good, (int)(f * LPF));
+            maxbits_l = (uint32_t)__shfl((int)maxbits_l, (int)(f * LPF));
+            huf_log = maxbits_l; huf_off = tabo;
+            if (!good) { ok = false; live = false; }
+        }
+        wsync();
+        SSTAMP(3);
+
+        // =============================== Huffman streams -> the window's tail (lane = (file, stream))
+        {
+            uint32_t lit_bad = 0;
+            if (live && lit_type >= 2 && sub < streams) {
+                const uint32_t st = sub;
+                const uint32_t seg = (nlit + 3) / 4;
+                const uint32_t sl = streams == 1 ? s_len0 : (st == 0 ? s_len0 : (st == 1 ? s_len1 : (st == 2 ? s_len2 : s_len3)));
+                const uint32_t rel = streams == 1 ? 0u : (st == 0 ? 0u : (st == 1 ? s_len0 : (st == 2 ? s_len0 + s_len1 : s_len0 + s_len1 + s_len2)));
+                const uint32_t lbase = cmp + s_base + rel;
+                const uint32_t nsym = streams == 1 ? nlit : (st < 3 ? seg : nlit - 3 * seg);
+                const uint32_t out = lit_base + (streams == 1 ? 0u : st * seg);
+                const uint32_t Lg = huf_log, tab = huf_off;
+                bool good = sl != 0;
+                const uint32_t last = good ? L8(lbase + sl - 1) : 1u;
+                good = good && last != 0;
+                if (good) {
+                    int32_t h = (int32_t)((sl - 1) * 8) + hibit32(last); // unread bits
+                    // the 64 bits below the read head, MSB-aligned; bits below the stream's start read as zero (A.4: the last symbols
+                    // may peek past it).  Every stream is preceded by >= 8 bytes of its file.
+                    auto window = [&](int32_t hh, int32_t& av) -> uint64_t {
+                        int32_t b = (hh - 1) >> 3;
+                        b = b < -1 ? -1 : b;
+                        uint64_t w = lds_u64(lbase + (uint32_t)(b + 9) - 16);
+                        const uint32_t sh = (uint32_t)(8 * (b + 1) - hh) & 63;
+                        w <<= sh;
+                        av = 64 - (int32_t)sh;
+                        const uint64_t keep = hh >= 64 ? ~0ull : (hh <= 0 ? 0ull : ~0ull << (64 - hh));
+                        return w & keep;
+                    };
+                    int32_t av;
+                    uint64_t cur = window(h, av);
+                    uint32_t k = 0;
+                    const uint32_t shL = 64 - Lg;
+                    for (; k + 2 <= nsym; k += 2) { // two symbols (<= 22 bits) per step
+                        const uint32_t e0 = L16(tab + 2 * (uint32_t)(cur >> shL));
+                        cur <<= (e0 >> 8);
+                        const uint32_t e1 = L16(tab + 2 * (uint32_t)(cur >> shL));
+                        cur <<= (e1 >> 8);
+                        const int32_t used = (int32_t)((e0 >> 8) + (e1 >> 8));
+                        av -= used; h -= used;
+                        L8(out + k) = (uint8_t)e0; L8(out + k + 1) = (uint8_t)e1;
+                        if (av < 22) cur = window(h, av);
+                    }
+                    if (k < nsym) {
+                        const uint32_t e0 = L16(tab + 2 * (uint32_t)(cur >> shL));
+                        L8(out + k) = (uint8_t)e0;
+                        h -= (int32_t)(e0 >> 8);
+                    }
+                    good = h == 0; // consumed exactly
+                }
+                if (!good) lit_bad = 1;
+            }
+            const uint64_t badm = __ballot(lit_bad != 0); // a failed stream condemns its file
+            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) { ok = false; live = false; }
+            // RLE literals: the tail is filled with the byte
+            if (live && lit_type == 1) { const uint32_t v = L8(cmp + lit_off); for (uint32_t k = sub; k < nlit; k += LPF) L8(lit_base + k) = (uint8_t)v; }
+        }
+        wsync();
+        SSTAMP(4);
+
+        // =============================== sequences section header (one lane per file): nbSeq, modes, normalized counts
+        uint32_t nseq = 0, bs_off = 0, bs_len = 0;
+        uint32_t tabL = 0, tabO = 0, tabM = 0, alL = 0, alO = 0, alM = 0; // LDS offset of each table, its log
+        uint32_t modes3 = 0, rle_syms = 0, nsyms = 0;
+        if (live) {
+            uint32_t good = 0;
+            if (leader) {
+                do {
+                    const uint32_t sp = cmp + seq_off;
+                    const uint64_t w = lds_u64(sp);
+                    uint32_t p = 1;
+                    nseq = (uint32_t)w & 0xFF;
+                    if (nseq > 0x7F) {
+                        if (nseq == 0xFF) { if (p + 2 > seq_len) break; nseq = ((uint32_t)(w >> 8) & 0xFFFF) + 0x7F00; p = 3; }
+                        else { if (p + 1 > seq_len) break; nseq = ((nseq - 0x80) << 8) + ((uint32_t)(w >> 8) & 0xFF); p = 2; }
+                    }
+                    if (nseq == 0) { good = p == seq_len; break; }
+                    if (nseq > cap / 3 + 1 || p + 1 > seq_len) break; // (every match is >= 3 bytes)
+                    const uint32_t modes = (uint32_t)(w >> (8 * p)) & 0xFF;
+                    p++;
+                    if (modes & 3) break;
+                    bool tbad = false;
+                    uint32_t used_entries = 0;
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        const uint32_t m = (modes >> (6 - 2 * t)) & 3;
+                        const int max_log = t == 1 ? 8 : 9, max_sym = t == 0 ? 35 : (t == 1 ? 31 : 52);
+                        const uint32_t noff = ringo + (t == 0 ? 0u : (t == 1 ? 72u : 136u));
+                        uint32_t tab = 0, al = 0, rs = 0, ns = 0;
+                        if (m == 0) { // predefined distribution: built like a described one
+                            ns = t == 0 ? 36u : (t == 1 ? 29u : 53u); al = t == 1 ? 5u : 6u;
+                            for (uint32_t s = 0; s < ns; s++) L16s(noff + 2 * s) = t == 0 ? LL_DEF[s] : (t == 1 ? OF_DEF[s] : ML_DEF[s]);
+                            tab = tabo + 8 * used_entries; used_entries += 1u << al;
+                        } else if (m == 1) {
+                            if (p + 1 > seq_len) { tbad = true; break; }
+                            rs = L8(sp + p); p++;
+                            if (rs > (uint32_t)max_sym) { tbad = true; break; }
+                            tab = tabo + 8 * used_entries; used_entries += 1; al = 0;
+                        } else if (m == 2) {
+                            if (p >= seq_len) { tbad = true; break; }
+                            const uint32_t used = read_ncount_lane(sp + p, seq_len - p, max_log, max_sym, max_sym + 1, noff, ns, al);
+                            if (used == 0) { tbad = true; break; }
+                            p += used;
+                            tab = tabo + 8 * used_entries; used_entries += 1u << al;
+                        } else {
+                            if (!(with_d && di.formatted)) { tbad = true; break; }
+                            tab = dict_off + (t == 0 ? kDLL : (t == 1 ? kDOF : kDML)); al = t == 0 ? di.al[0] : (t == 1 ? di.al[1] : di.al[2]);
+                        }
+                        if (t == 0) { tabL = tab; alL = al; } else if (t == 1) { tabO = tab; alO = al; } else { tabM = tab; alM = al; }
+                        modes3 |= m << (2 * t); rle_syms |= rs << (8 * t); nsyms |= ns << (8 * t);
+                    }
+                    if (tbad || used_entries * 8 > a.tab_bytes) break;
+                    if (p >= seq_len) break; // the bitstream needs at least one byte
+                    bs_off = seq_off + p; bs_len = seq_len - p;
+                    good = 1;
+                } while (false);
+            }
+            const int ld = (int)(f * LPF);
+            good = (uint32_t)__shfl((int)good, ld);
+            nseq = (uint32_t)__shfl((int)nseq, ld); bs_off = (uint32_t)__shfl((int)bs_off, ld); bs_len = (uint32_t)__shfl((int)bs_len, ld);
+            tabL = (uint32_t)__shfl((int)tabL, ld); tabO = (uint32_t)__shfl((int)tabO, ld); tabM = (uint32_t)__shfl((int)tabM, ld);
+            alL = (uint32_t)__shfl((int)alL, ld); alO = (uint32_t)__shfl((int)alO, ld); alM = (uint32_t)__shfl((int)alM, ld);
+            modes3 = (uint32_t)__shfl((int)modes3, ld); rle_syms = (uint32_t)__shfl((int)rle_syms, ld); nsyms = (uint32_t)__shfl((int)nsyms, ld);
+            if (!good) { ok = false; live = false; nseq = 0; }
+        }
+        wsync();
+        SSTAMP(5);
+
+        // =============================== FSE decode tables (lane = (file, table))
+        {
+            uint32_t tb_bad = 0;
+            if (live && nseq && sub < 3) {
+                const int t = (int)sub;
+                const uint32_t m = (modes3 >> (2 * t)) & 3;
+                const uint32_t tab = t == 0 ? tabL : (t == 1 ? tabO : tabM), al = t == 0 ? alL : (t == 1 ? alO : alM);
+                if (m == 1) {
+                    const uint32_t s = (rle_syms >> (8 * t)) & 0xFF;
+                    const uint32_t extra = t == 0 ? L32(kShLL + 4 * s) >> 24 : (t == 1 ? s : L32(kShML + 4 * s) >> 24);
+                    L64(tab) = fse_entry(tab, 0, 0, s, extra);
+                } else if (m == 0 || m == 2) {
+                    const uint32_t noff = ringo + (t == 0 ? 0u : (t == 1 ? 72u : 136u));
+                    if (!build_fse_lane(tab, noff, (nsyms >> (8 * t)) & 0xFF, al, t)) tb_bad = 1;
+                }
+            }
+            const uint64_t badm = __ballot(tb_bad != 0);
+            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) { ok = false; live = false; nseq = 0; }
+        }
+        wsync();
+        SSTAMP(6);
+
+        // =============================== FSE state walk -> field extraction -> execution, LPF sequences at a time
+        // Bit positions are LDS bit addresses (8 * byte offset + bit): G = the read head, bits below it are unread.
+        // Per step of LPF sequences: (1) the walk, one lane per file, branch-free: the state as it stands is the record of a
+        // sequence; (2) lane = sequence: fields from the records, positions by scans over the file's lanes, what can be checked
+        // without the offsets, and the literals -- they depend on nothing: every lane copies its own (reads of the whole step
+        // before its writes: the literals may sit in the window's tail); (3) in order, the file's lanes in step: repeat offsets
+        // and the match, a byte per lane, its fields broadcast from the sequence's lane (DPP).
+        {
+            const uint32_t G0 = 8 * (cmp + bs_off); // the stream's bit 0
+            uint32_t Gh = G0, aL = 0, aM = 0, aO = 0;
+            bool bad = false;
+            if (live && nseq) {
+                const uint32_t lastb = L8(cmp + bs_off + bs_len - 1);
+                bad = lastb == 0;
+                Gh = G0 + (bs_len - 1) * 8 + (uint32_t)hibit32(lastb | 1u);
+                const uint32_t need = alL + alO + alM; // <= 26
+                bad |= Gh - G0 < need;
+                const uint32_t e = (Gh + 7) >> 3;
+                const uint64_t X = lds_u64(e - 8);
+                const uint32_t Y = (uint32_t)(X >> ((Gh - 8 * e + 64 - need) & 63)); // the three initial states: LL, OF, ML from the top
+                aM = tabM + 8 * bfe(Y, 0, alM); aO = tabO + 8 * bfe(Y, alM, alO); aL = tabL + 8 * bfe(Y, alM + alO, alL);
+                Gh -= need;
+            }
+            const uint32_t dict_len = with_d ? di.content_len : 0u;
+            const uint8_t* const dict_end = with_d ? di.content + di.content_len : nullptr;
+            uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+            if (with_d && di.formatted) { rep0 = di.rep[0]; rep1 = di.rep[1]; rep2 = di.rep[2]; }
+            uint32_t lpos = 0, opos = 0;
+            const uint32_t nrun = (live && !bad) ? nseq : 0u;
+            const uint32_t dump = kShDump + 8 * lane; // where the stores of lanes that have nothing to store go
+#ifdef MZD_SMALL_STAMPS
+            uint64_t tw_ = 0, tp_ = 0, te_ = 0, t0_ = __builtin_readcyclecounter(), t1_ = 0;
+#define GSTAMP(acc) do { t1_ = __builtin_readcyclecounter(); acc += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define GSTAMP(acc)
+#endif
+            for (uint32_t c0 = 0; __any(c0 < nrun && !bad); c0 += LPF) {
+                const bool act = c0 < nrun && !bad;
+                GSTAMP(te_);
+                // ---- (1) the walk
+                uint32_t wbad = 0;
+                if (act && leader) {
+                    auto record = [&](uint32_t k) { *reinterpret_cast<uint4*>(lds + ringo + 16 * k) = make_uint4(aL, aM, aO, Gh); };
+                    auto step = [&]() {
+                        const uint32_t e = (Gh + 7) >> 3;
+                        const uint64_t X = lds_u64(e - 8); // the 57..64 bits below the read head
+                        const uint64_t EL = L64(aL), EM = L64(aM), EO = L64(aO);
+                        const uint32_t hL = (uint32_t)(EL >> 32), hM = (uint32_t)(EM >> 32), hO = (uint32_t)(EO >> 32);
+                        const uint32_t tot = ((hL + hM + hO) >> 8) & 0xFF; // every bit this sequence consumes
+                        const int32_t s = (int32_t)(Gh - 8 * e + 64) - (int32_t)tot;
+                        wbad |= (uint32_t)s >> 31; // wider than the window: handed on
+                        const uint32_t Y = (uint32_t)(X >> (s & 63));
+                        // fresh state bits sit at the bottom of what the sequence consumes: OF lowest, then ML, then LL
+                        aO = (uint32_t)EO + 8 * bfe(Y, 0, hO);
+                        aM = (uint32_t)EM + 8 * bfe(Y, hO, hM);
+                        aL = (uint32_t)EL + 8 * bfe(Y, hO + hM, hL);
+                        Gh -= tot;
+                    };
+                    if (c0 + LPF < nrun) { // every sequence of the step is followed by a state update
+#pragma unroll
+                        for (uint32_t k = 0; k < LPF; k++) { record(k); step(); }
+                    } else { // the file's last step
+                        const uint32_t cnt = nrun - c0;
+                        for (uint32_t k = 0; k < cnt; k++) { record(k); if (k + 1 < cnt) step(); }
+                    }
+                    wbad |= (uint32_t)(Gh - G0) >> 31; // over-read (bounded: <= LPF * 89 bits below the stream, inside the slot)
+                }
+                wsync();
+                GSTAMP(tw_);
+                // ---- (2) lane = sequence c0 + sub
+                uint32_t ll = 0, ml = 0, w0 = 0; // w0: repeat code (0..3; 4 = a new offset) | (offset value - 3) << 3
+                uint32_t pbad = wbad;
+                if (act && c0 + sub < nrun) {
+                    const uint4 r = *reinterpret_cast<const uint4*>(lds + ringo + 16 * sub);
+                    const uint32_t hL = L32(r.x + 4), hM = L32(r.y + 4), hO = L32(r.z + 4);
+                    const uint32_t xL = hL >> 24, xM = hM >> 24, xO = hO >> 24;
+                    const uint32_t cL = (hL >> 16) & 0xFF, cM = (hM >> 16) & 0xFF, cO = (hO >> 16) & 0xFF;
+                    const uint32_t xs = xL + xM + xO;
+                    const uint32_t tL = r.w - xs; // bottom of the LL field
+                    if ((int32_t)(tL - G0) < 0 || xs + (tL & 7) > 64) pbad = 1;
+                    uint64_t W = lds_u64(tL >> 3) >> (tL & 7);
+                    const uint32_t vL = (uint32_t)W & (uint32_t)((1ull << xL) - 1); W >>= xL;
+                    const uint32_t vM = (uint32_t)W & (uint32_t)((1ull << xM) - 1); W >>= xM;
+                    const uint32_t vO = (uint32_t)(W & ((1ull << xO) - 1));
+                    const uint32_t ofv = (1u << cO) + vO;
+                    ml = (L32(kShML + 4 * cM) & 0xFFFFFF) + vM;
+                    ll = (L32(kShLL + 4 * cL) & 0xFFFFFF) + vL;
+                    if (c0 + sub + 1 == nrun && tL != G0) pbad = 1; // the bitstream must be consumed exactly
+                    if (((ll | ml) >> 14) | (cO > 18)) pbad = 1;     // (cannot be right for a window of <= 8 KiB and a dictionary of <= 128 KiB; keeps the packed fields and the sums below in range)
+                    w0 = ofv > 3 ? 4u | ((ofv - 3) << 3) : ofv - 1 + (ll == 0 ? 1u : 0u);
+                }
+                // positions: inclusive scans over the file's lanes
+                uint32_t il = ll, it = ll + ml;
+                il += seg_shr<1, LPF>(il, sub); it += seg_shr<1, LPF>(it, sub);
+                il += seg_shr<2, LPF>(il, sub); it += seg_shr<2, LPF>(it, sub);
+                if (LPF > 4) { il += seg_shr<4, LPF>(il, sub); it += seg_shr<4, LPF>(it, sub); }
+                if (LPF > 8) { il += seg_shr<8, LPF>(il, sub); it += seg_shr<8, LPF>(it, sub); }
+                const uint32_t lp = lpos + il - ll, op = opos + it - ll - ml; // this sequence's literals / its output
+                if ((lp + ll > nlit) | (op + ll + ml > cap)) pbad = 1;       // literals left, room in the destination (A.5)
+                {
+                    const uint64_t pm = __ballot(pbad != 0);
+                    if ((pm >> (f * LPF)) & ((1ull << LPF) - 1)) { bad = true; ll = 0; ml = 0; w0 = 0; } // (nothing of this step is executed)
+                }
+                // ---- repeat offsets (A.5): every lane its sequence's offset
+                const uint32_t c = w0 & 7, pushv = w0 >> 3;
+                uint32_t off;
+                if (__ballot(c == 3) == 0) { // the scan over references
+                    const uint32_t T = sel(m_eq(c, 4), 0x03010010u | sub, sel(m_eq(c, 0), kRepId, sel(m_eq(c, 1), 0x03020001u, 0x03010002u)));
+                    uint32_t P = T;
+                    P = rep_compose(P, rep_shr<1, LPF>(P, sub));
+                    P = rep_compose(P, rep_shr<2, LPF>(P, sub));
+                    if (LPF > 4) P = rep_compose(P, rep_shr<4, LPF>(P, sub));
+                    if (LPF > 8) P = rep_compose(P, rep_shr<8, LPF>(P, sub));
+                    const uint32_t Ex = rep_shr<1, LPF>(P, sub); // the state before this sequence
+                    const uint32_t PL = bcast<LPF - 1, LPF>(P);  // ... and behind the step's last
+                    auto resolve = [&](uint32_t ref) -> uint32_t {
+                        const uint32_t vc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~(LPF - 1)) | (ref & (LPF - 1))) * 4), (int)pushv);
+                        const uint32_t vi = sel(m_eq(ref, 0), rep0, sel(m_eq(ref, 1), rep1, rep2));
+                        return sel(m_ne(ref & 0x10, 0), vc, vi);
+                    };
+                    const uint32_t mine = resolve((Ex >> (8 * (c & 3))) & 0xFF);
+                    off = sel(m_eq(c, 4), pushv, mine);
+                    const uint32_t n0 = resolve(PL & 0xFF), n1 = resolve((PL >> 8) & 0xFF), n2 = resolve((PL >> 16) & 0xFF);
+                    rep0 = n0; rep1 = n1; rep2 = n2;
+                } else { // in order
+                    off = 0;
+                    static_for<LPF>([&](auto kc) {
+                        constexpr int K = decltype(kc)::value;
+                        const uint32_t a0 = bcast<K, LPF>(w0);
+                        const uint32_t ck = a0 & 7, pk = a0 >> 3;
+                        const lmask e0 = m_eq(ck, 0), e1 = m_eq(ck, 1), e2 = m_eq(ck, 2), e3 = m_eq(ck, 3);
+                        const uint32_t X = sel(e2, rep2, sel(e3, rep0 - 1, pk));
+                        const uint32_t o = sel(e0, rep0, sel(e1, rep1, X));
+                        rep2 = sel(e0 | e1, rep2, rep1); rep1 = sel(e0, rep1, rep0); rep0 = o;
+                        off = sel(m_eq(sub, K), o, off);
+                    });
+                }
+                const uint32_t mp = op + ll; // where the match goes
+                {   // offset within the history, and not zero ("rep0 - 1")
+                    const uint64_t om = __ballot(ml != 0 && off - 1 >= mp + dict_len);
+                    if ((om >> (f * LPF)) & ((1ull << LPF) - 1)) { bad = true; ll = 0; ml = 0; }
+                }
+                // ---- the literals: up to 31 bytes per lane in exact pieces; longer runs by the whole wavefront, one after the other.
+                // The window's tail is their source: what a sequence writes ends at or below its own literals' end, so the order is --
+                // every short run is read; the long runs are copied, ascending (none of them reaches the source of a later run);
+                // the short runs are written.  Matches that lie wholly in the dictionary depend on nothing either: requested first.
+                {
+                    bool dfull = false;
+                    V16 D0 = {0, 0}, D1 = {0, 0};
+                    if (DICT) {
+                        dfull = ml != 0 && ml < 32 && off > mp && off - mp >= ml;
+                        const uint8_t* dp = dfull ? dict_end - (off - mp) : dict_end; // (dictionary buffers are readable 32 bytes past their end)
+                        D0 = gv16(dp); D1 = gv16(dp + 16);
+                    }
+                    const uint32_t sa = lit_base + lp;
+                    const uint64_t A = lds_u64(sa), B = lds_u64(sa + 8), C = lds_u64(sa + 16), D = lds_u64(sa + 24);
+                    asm volatile("" ::: "memory");
+                    uint64_t big = __ballot(ll >= 32);
+                    while (big) {
+                        const int bl = __builtin_ctzll(big);
+                        big &= big - 1;
+                        const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)ll, bl), s2 = (uint32_t)__builtin_amdgcn_readlane((int)sa, bl), d2 = (uint32_t)__builtin_amdgcn_readlane((int)(outo + op), bl);
+                        for (uint32_t q = 0; q < n2; q += 64) { // (destination at or below the source: ascending pieces, each read before it is written)
+                            const uint32_t v = L8(s2 + q + lane);
+                            asm volatile("" ::: "memory");
+                            if (q + lane < n2) L8(d2 + q + lane) = (uint8_t)v;
+                            asm volatile("" ::: "memory");
+                        }
+                    }
+                    store_exact31(outo + op, ll < 32 ? ll : 0u, (uint32_t)A, (uint32_t)(A >> 32), (uint32_t)B, (uint32_t)(B >> 32), (uint32_t)C, (uint32_t)(C >> 32), (uint32_t)D, (uint32_t)(D >> 32), dump);
+                    if (DICT) {
+                        store_exact31(outo + mp, dfull ? ml : 0u, (uint32_t)D0.a, (uint32_t)(D0.a >> 32), (uint32_t)D0.b, (uint32_t)(D0.b >> 32), (uint32_t)D1.a, (uint32_t)(D1.a >> 32), (uint32_t)D1.b, (uint32_t)(D1.b >> 32), dump);
+                        if (dfull) ml = 0; // done
+                    }
+                }
+                const uint32_t chunk_l = bcast<LPF - 1, LPF>(il), chunk_t = bcast<LPF - 1, LPF>(it);
+                wsync();
+                GSTAMP(tp_);
+                // ---- (3) the matches inside the window, in rounds: a lane copies its own match (<= 31 bytes, not overlapping itself) once
+                // everything below its source's end is final, i.e. once that end is at or below the match of the file's first sequence still
+                // waiting; a first sequence of any other kind -- longer, overlapping, starting in the dictionary -- is executed by the
+                // file's lanes together (its source is complete by then).  The first waiting sequence never waits, so every round ends one.
+                {
+                    const uint32_t m = ml;
+                    const bool simple = (m < 32) & (off >= m) & (off <= mp);
+                    bool pending = m != 0;
+                    const uint32_t send = mp - off + m; // end of the source
+                    const uint32_t rowbase = lane & ~(LPF - 1);
+                    for (;;) {
+                        const uint64_t pm = __ballot(pending);
+                        if (!pm) break;
+                        const uint32_t seg = (uint32_t)(pm >> (f * LPF)) & ((1u << LPF) - 1);
+                        const uint32_t first = seg ? (uint32_t)__builtin_ctz(seg) : 0u;
+                        const uint32_t fl4 = (rowbase + first) * 4;
+                        const uint32_t F = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)mp);
+                        const bool ready = pending & simple & (send <= F);
+                        {
+                            const uint32_t ra = ready ? outo + mp - off : dump;
+                            const uint64_t A = lds_u64(ra), B = lds_u64(ra + 8), C = lds_u64(ra + 16), D = lds_u64(ra + 24);
+                            asm volatile("" ::: "memory");
+                            store_exact31(outo + mp, ready ? m : 0u, (uint32_t)A, (uint32_t)(A >> 32), (uint32_t)B, (uint32_t)(B >> 32), (uint32_t)C, (uint32_t)(C >> 32), (uint32_t)D, (uint32_t)(D >> 32), dump);
+                            asm volatile("" ::: "memory");
+                        }
+                        pending = pending & !ready;
+                        const bool fc = pending & !simple & (sub == first); // the first one waiting, and not of the simple kind
+                        const uint64_t cm = __ballot(fc);
+                        if (cm) {
+                            const uint32_t fmp = F, foff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)off), fm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)m);
+                            if ((cm >> (f * LPF)) & ((1ull << LPF) - 1)) rare_match<LPF, DICT>(outo, fmp, foff, fm, sub, dict_end, dict_len);
+                            pending = pending & !fc;
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                lpos += chunk_l; opos += chunk_t;
+                wsync();
+            }
+#ifdef MZD_SMALL_STAMPS
+            if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[10] = tw_; a.stamps[11] = tp_; a.stamps[12] = te_; }
+#endif
+            if (live) {
+                bool good = !bad;
+                if (good) {
+                    const uint32_t rest = nlit - lpos;
+                    good = rest <= cap - opos;
+                    if (good) {
+                        for (uint32_t q = sub; q < rest; q += LPF) { const uint32_t v = L8(lit_base + lpos + q); asm volatile("" ::: "memory"); L8(outo + opos + q) = (uint8_t)v; asm volatile("" ::: "memory"); }
+                        opos += rest;
+                        good = !(has_fcs && opos != fcs);
+                        out_len = opos;
+                    }
+                }
+                if (!good) { ok = false; live = false; }
+            }
+        }
+        wsync();
+        SSTAMP(7);
+        // =============================== XXH64 over the window (lane = (file, accumulator))
+        {
+            uint32_t ck_bad = 0;
+            const bool hashing = ok && has_ck && n != 0;
+            const uint32_t nstripes = hashing ? out_len / 32 : 0u;
+            if (sub < 4) {
+                const uint32_t acc_i = sub;
+                uint64_t v = acc_i == 0 ? XP1 + XP2 : (acc_i == 1 ? XP2 : (acc_i == 2 ? 0ull : 0ull - XP1));
+                uint32_t q = res_off + 8 * acc_i;
+                uint32_t s = 0;
+                for (; s + 4 <= nstripes; s += 4) {
+                    const uint64_t i0 = lds_u64(q), i1 = lds_u64(q + 32), i2 = lds_u64(q + 64), i3 = lds_u64(q + 96);
+                    v = xround(v, i0); v = xround(v, i1); v = xround(v, i2); v = xround(v, i3);
+                    q += 128;
+                }
+                for (; s < nstripes; s++) { v = xround(v, lds_u64(q)); q += 32; }
+                const int base = (int)(lane & ~3u);
+                const uint64_t v1 = __shfl(v, base), v2 = __shfl(v, base + 1), v3 = __shfl(v, base + 2), v4 = __shfl(v, base + 3);
+                if (hashing && acc_i == 0) {
+                    uint64_t hh;
+                    if (out_len >= 32) {
+                        hh = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+                        hh = xmerge(hh, v1); hh = xmerge(hh, v2); hh = xmerge(hh, v3); hh = xmerge(hh, v4);
+                    } else hh = XP5;
+                    hh += out_len;
+                    hh = xxh_tail(hh, res_off + (out_len / 32) * 32, res_off + out_len);
+                    if ((uint32_t)hh != lds_u32(cmp + n - 4)) ck_bad = 1;
+                }
+            }
+            const uint64_t badm = __ballot(ck_bad != 0);
+            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) ok = false;
+        }
+        SSTAMP(8);
+
+        // =============================== the finished files leave LDS: all 64 lanes per file, 16 bytes per lane, to the destination
+        // and to its mirror in the caller's pinned memory (DevJob::dst2)
+        {
+            uint64_t m = __ballot(leader && have && ok && out_len != 0);
+            while (m) {
+                const int fl_ = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)out_len, fl_);
+                const uint32_t from = (uint32_t)__builtin_amdgcn_readlane((int)res_off, fl_);
+                const uint64_t d1 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)dst, fl_) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uintptr_t)dst >> 32), fl_) << 32);
+                const uint64_t d2 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)dst2, fl_) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uintptr_t)dst2 >> 32), fl_) << 32);
+                uint8_t* const to = (uint8_t*)(uintptr_t)d1;
+                uint8_t* const to2 = (uint8_t*)(uintptr_t)d2;
+                const bool aligned = (from & 15) == 0; // (a raw block lies where the input put it)
+                for (uint32_t o = lane * 16; o + 16 <= len; o += 1024) {
+                    V16 v;
+                    if (aligned) v = lds_v16(from + o); else { v.a = lds_u64(from + o); v.b = lds_u64(from + o + 8); }
+                    gsv16(to + o, v);
+                    if (to2) gsv16(to2 + o, v);
+                }
+                const uint32_t tail = len & ~15u;
+                if (tail + lane < len) { const uint32_t v = L8(from + tail + lane); gs8(to + tail + lane, v); if (to2) gs8(to2 + tail + lane, v); }
+            }
+        }
+
+        // =============================== results: done here, or handed to the general driver
+        if (have && leader) {
+            if (ok) { a.jobs[job].out_len = out_len; a.jobs[job].status = MZD_OK; }
+            else { const uint32_t k = atomicAdd(&a.counter[4], 1u); a.redo_list[k] = job; }
+        }
+        SSTAMP(9);
+        first_group = false;
+        wsync(); // the slots are rewritten by the next group
+    }
+}
+
+} // namespace lw
+
+uint32_t lds_kernel_bytes(int g, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes) {
+    return lw::kShBytes + (with_dict ? lw::kDictImg : 0u) + (uint32_t)g * (tab_bytes + lw::kAux + comp_bytes + out_bytes);
+}
+
+void launch_lds(const LdsArgs& a, uint32_t grid, int g, int with_dict, void* stream) {
+    const uint32_t bytes = lds_kernel_bytes(g, with_dict, a.tab_bytes, a.comp_bytes, a.out_bytes);
+    hipStream_t s = (hipStream_t)stream;
+#define MZD_LDS_LAUNCH(GG, DD) do { \
+        static bool attr_set = false; \
+        if (!attr_set) { hipFuncSetAttribute((const void*)lw::mzd_lds_kernel<GG, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        hipLaunchKernelGGL((lw::mzd_lds_kernel<GG, DD>), dim3(grid), dim3(64), bytes, s, a); } while (0)
+    if (with_dict) { if (g == 4) MZD_LDS_LAUNCH(4, true); else if (g == 8) MZD_LDS_LAUNCH(8, true); else MZD_LDS_LAUNCH(16, true); }
+    else { if (g == 4) MZD_LDS_LAUNCH(4, false); else if (g == 8) MZD_LDS_LAUNCH(8, false); else MZD_LDS_LAUNCH(16, false); }
+#undef MZD_LDS_LAUNCH
+}
+
+} // namespace mzd

@@ -1,0 +1,44 @@
+"""Diagnostic: phase times of the LDS small-file kernel (mzd_lds.hip), from a library built with `make sstamps`:
+cycles between the phase boundaries of workgroup 0's first group, and the kernel time of the launch.
+  python tools/lds_stamps.py [cfg4|cfg5] [files]      (MZD_LDS_G=4|8|16 picks the files per wavefront)"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import fuse_zstd_amd.api as api
+api._SO = os.path.join(os.path.dirname(api._SO), os.environ.get("MZD_SO", "libmzd_sstamps.so"))
+import bench, corpus, fuse_zstd_amd as mzd
+mzd.init()
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else bench.DEFAULT_FILES[wl]
+kind, cfg, km, _ = bench.WORKLOADS[wl]
+sizes = bench.file_sizes(wl, n, 0, 1)
+d, did = None, 0
+if wl == "cfg5":
+    tr = np.random.RandomState(55).randint(300, 3001, size=4000)
+    d = corpus.train_dict(kind, cfg, [int(x) for x in tr], cap=112640)
+    did = mzd.load_dict(d)
+cp = corpus.build_corpus(kind, cfg, sizes, kind_mod=km, dictionary=d)
+import torch
+dev = torch.device("cuda:0")
+comp = torch.from_numpy(cp.comp).to(dev)
+end = int(cp.raw_offs[-1] + cp.raw_sizes[-1])
+out = torch.zeros(end + 64, dtype=torch.uint8, device=dev)
+jobs = api.make_jobs([comp.data_ptr() + int(o) for o in cp.comp_offs], cp.comp_sizes, [out.data_ptr() + int(o) for o in cp.raw_offs], cp.raw_sizes,
+                     [did] * n if did else None)
+torch.cuda.synchronize()
+names = ["take group, job entries, input -> LDS", "headers", "Huffman weights + table", "Huffman streams", "sequence header, counts",
+         "FSE tables", "walk + extract + execute", "XXH64", "flush + results"]
+mzd.set_driver(3)
+for rep in range(3):
+    res = mzd.decode_batch_device(0, jobs)
+    assert all(st == 0 for st, _ in res)
+    st = (C.c_uint64 * 24)()
+    api.lib().mzd_debug_small_stamps.argtypes = [C.c_int, C.c_void_p]
+    api.lib().mzd_debug_small_stamps(0, st)
+    t = list(st)
+    if rep == 2:
+        print("%s G=%s: kernel %.3f ms; workgroup 0, first group: total %d cycles" % (wl, os.environ.get("MZD_LDS_G", "auto"), mzd.last_kernel_ms(0), t[9] - t[0]))
+        print("    inside: walk %d, extract %d, execute %d cycles" % (t[10], t[11], t[12]))
+        print("    Huffman: counts %d, weights' FSE table %d, weights %d, ranks %d, table fill %d" % (t[13] - t[2], t[14] - t[13], t[15] - t[14], t[16] - t[15], t[3] - t[16]))
+        for k in range(9):
+            print("    %-46s %8d cycles" % (names[k], t[k + 1] - t[k]))
