@@ -173,11 +173,15 @@ struct LdsArgs {
     uint32_t ndicts;
     uint32_t tab_bytes;         // per file: Huffman table, then the three FSE tables (0: files use the dictionary's tables only)
     uint32_t comp_bytes;        // per file: >= the largest src_len of the launch + 16, a multiple of 16
-    uint32_t out_bytes;         // per file: >= the largest dst_cap of the launch + 16, a multiple of 16, >= 1024
+    uint32_t out_bytes;         // per file: >= the largest dst_cap of the launch + 16, a multiple of 16 (the window lies over the other three)
+    uint8_t* scratch;           // HBM: per resident file (gridDim.x * G of them) lit_stride bytes of literals + 8 * seq_cap bytes of sequences
+    uint32_t lit_stride;        // >= the largest dst_cap of the launch + 64
+    uint32_t seq_cap;           // >= the largest dst_cap of the launch / 3 + 2 (every match is >= 3 bytes)
     uint64_t* stamps;           // diagnostic build (-DMZD_SMALL_STAMPS), else unused
 };
 void launch_lds(const LdsArgs& a, uint32_t grid, int g, int with_dict, void* stream);
 uint32_t lds_kernel_bytes(int g, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes);
+size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap);
 
 
 void launch_decode(const KernelArgs& a, uint32_t grid, void* stream);

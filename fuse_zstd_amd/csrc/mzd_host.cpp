@@ -294,23 +294,37 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
         p.small_g = (p.with_dict && all_dict) ? 64 : 16;
         p.lit_stride = (uint32_t)align_up(maxcap + 64, 64);
         p.lds_kernel = force != 6;
+        // The files of a group run in lockstep, so a group takes as long as its largest file: the list is sorted by size (a
+        // counting sort: capacity in steps of 32 bytes), and by dictionary first -- a group shares one dictionary's tables.
+        {
+            constexpr uint32_t kBuckets = kSmallCap / 32 + 1;
+            static thread_local std::vector<uint32_t> cnt, tmp;
+            const uint32_t nd = p.with_dict ? kMaxDicts + 2 : 1;
+            cnt.assign((size_t)nd * kBuckets + 1, 0);
+            auto key = [&](uint32_t i) -> uint32_t {
+                const uint32_t dk = p.with_dict ? std::min<uint32_t>(jobs[i].dict, kMaxDicts + 1) : 0u;
+                return dk * kBuckets + (uint32_t)(jobs[i].dst_cap / 32);
+            };
+            for (uint32_t k = 0; k < p.nsmall; k++) cnt[key(small[k]) + 1]++;
+            for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+            tmp.resize(p.nsmall);
+            for (uint32_t k = 0; k < p.nsmall; k++) tmp[cnt[key(small[k])]++] = small[k];
+            std::copy(tmp.begin(), tmp.end(), small);
+        }
         // the LDS kernel's slots: sized for the launch's largest file.  Files that all name a dictionary bring no tables of their
         // own in the plain case (a file that does is handed on); else 2 KiB hold a 10-bit Huffman table, later 256 FSE entries
         // (three tables of <= 512 sequences), 4 KiB twice that
         p.lds_tab = (p.with_dict && all_dict) ? 0u : (maxcap <= 5120 ? 2048u : 4096u);
         p.lds_comp = (uint32_t)align_up(maxsrc + 16, 16);
-        p.lds_out = (uint32_t)std::max<size_t>(1024, align_up(maxcap + 16, 16));
-        {   // files per wavefront: more files per wavefront make better use of the lanes in the serial phases, fewer give a
-            // CU more wavefronts to overlap -- the largest G that still leaves four wavefronts on a CU, else 4
+        p.lds_out = (uint32_t)align_up(maxcap + 16, 16);
+        {   // files per wavefront: residency is set by LDS (and by registers: two wavefronts per SIMD), whatever G is; fewer files
+            // per wavefront spread a launch's tail better and cost nothing but lane efficiency in the serial phases, which the
+            // SIMDs have to spare (measured, cfg4: G = 4 0.52 ms, G = 8 0.64 ms)
             static const int env_g = getenv("MZD_LDS_G") ? atoi(getenv("MZD_LDS_G")) : 0;
-            p.lds_g = 4;
-            for (int g : {16, 8})
-                if (160u * 1024u / lds_kernel_bytes(g, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out) >= 4) { p.lds_g = g; break; }
+            p.lds_g = (p.with_dict && all_dict) ? 8 : 4; // (one dictionary image per wavefront: worth more files per image; cfg5: G = 4 1.03 ms, 8 0.94, 16 1.25)
             if (env_g == 4 || env_g == 8 || env_g == 16) p.lds_g = env_g;
             while (p.lds_g > 4 && lds_kernel_bytes(p.lds_g, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out) > 160u * 1024u) p.lds_g /= 2;
         }
-        if (p.with_dict) // groups share one dictionary's tables: sort by dictionary (stable)
-            std::stable_sort(small, small + p.nsmall, [&](uint32_t x, uint32_t y) { return jobs[x].dict < jobs[y].dict; });
     }
     if (force == 1) p.multi = false;
     if (force == 2 || force == 4 || force == 5) p.multi = true;
@@ -354,9 +368,13 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         la.stamps = reinterpret_cast<uint64_t*>(d.debug); // (diagnostic builds: the first debug slot's first bytes; unused otherwise)
         const uint32_t ngroups = (p.nsmall + (uint32_t)p.lds_g - 1) / (uint32_t)p.lds_g;
         const uint32_t lds = lds_kernel_bytes(p.lds_g, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out);
-        uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(8u, (160u * 1024u) / lds)); // one wavefront per workgroup
+        uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(12u, (160u * 1024u) / lds)); // one wavefront per workgroup
         resident = std::max<uint32_t>(1u, resident * l.nwg / d.max_wg);
-        launch_lds(la, std::min(ngroups, resident), p.lds_g, p.with_dict ? 1 : 0, s);
+        la.lit_stride = p.lit_stride; la.seq_cap = (p.lit_stride - 64) / 3 + 2;
+        la.scratch = l.small_lit;
+        const size_t per_wave = (size_t)p.lds_g * lds_scratch_per_file(la.lit_stride, la.seq_cap);
+        const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / per_wave);
+        launch_lds(la, std::min(ngroups, std::min(resident, by_scratch)), p.lds_g, p.with_dict ? 1 : 0, s);
         HIPCHK(hipGetLastError());
         ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig;
         grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
@@ -1131,12 +1149,13 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
 }
 
 // Diagnostic (a build with -DMZD_SMALL_STAMPS): the 8 phase stamps of the small-file kernel's workgroup 0.
-int mzd_debug_small_stamps(int device, uint64_t* out8) { // (24 values)
+int mzd_debug_small_stamps(int device, uint64_t* out8) { // (64 values; 32..47: files that left the fast path, by reason)
     auto dp = get_device(device);
     if (!dp || !out8) return MZD_E_PARAM;
     WholeGuard g(*dp);
     HIPCHK(hipSetDevice(dp->hip_id));
-    HIPCHK(hipMemcpy(out8, dp->debug, 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out8, dp->debug, 1032 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset((uint8_t*)dp->debug + 32 * sizeof(uint64_t), 0, 1000 * sizeof(uint64_t)));
     return MZD_OK;
 }
 

@@ -3,20 +3,21 @@
 // Same arithmetic as mzd_kernels.hip (the frame decoder behind `zstd::stream::copy_decode`, reference
 // src/main.rs:463-467; format: RFC 8878 / SURVEY.md Appendix A), for the corpus the reference's own benchmark reads
 // (benchmarks/parallel-files.fio:3-7: thousands of files of a few KiB).  A wavefront takes a GROUP of G files and gives
-// each LPF = 64 / G lanes; everything a file needs lives in its LDS slot from the first byte to the last:
+// each LPF = 64 / G lanes.  A file's LDS slot is used twice:
 //
-//     slot = [ tables | ring | compressed input | output window ]
+//     entropy phase:   [ tables | ring | compressed input ]        execute phase:   [ output window ]
 //
 //   * the compressed file is copied into the slot once, 16 bytes per lane (coalesced); every parser and bit reader
 //     works on LDS bytes;
-//   * Huffman literals are decoded into the TAIL of the output window (cap - nlit ..): the write head of the execution
-//     never passes the literal read head (what is still to be written is at least the literals still to be read), so
-//     literals and output share the window;
+//   * Huffman literals go to a scratch in HBM (L2-resident: written and read by the same wavefront);
 //   * the FSE state walk does only what the chain needs (three table reads, one bitstream window, the three state
 //     updates: mzd_k_walk.h's step, with per-lane tables) and records its state per sequence in the ring; field
-//     extraction is done by LPF lanes at once, a lane per sequence, from those records;
-//   * sequences are executed in order by the file's LPF lanes, a byte per lane, LDS -> LDS: a match is a read and a
-//     write of the output window, never an HBM round trip;
+//     extraction is done by LPF lanes at once, a lane per sequence, from those records; the sequences -- 8 bytes each:
+//     literal length, match length, offset value -- follow the literals into the scratch;
+//   * then the slot becomes the file's OUTPUT WINDOW (what the entropy phase kept there is dead; residency is set by
+//     max(entropy image, window), not by their sum): LPF sequences at a time, a lane per sequence -- positions by scans,
+//     repeat offsets by a scan over references, every lane copies its own literals, matches are resolved LDS -> LDS in
+//     rounds (never an HBM round trip);
 //   * XXH64 reads the window; the finished file leaves LDS with whole-wavefront 16-byte stores (to the destination and,
 //     when the caller's buffer is pinned host memory, to its mirror: DevJob::dst2).
 // Chains that are serial by construction (Huffman weights, normalized counts, the state walk) run on one lane per file,
@@ -46,6 +47,9 @@ DI V16 gv16(const uint8_t* p) { V16 v; __builtin_memcpy(&v, (gcp)p, 16); return 
 DI void gsv16(uint8_t* p, const V16& v) { __builtin_memcpy((gp)p, &v, 16); }
 DI uint32_t gu32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, (gcp)p, 4); return v; }
 DI uint32_t gu8(const uint8_t* p) { return *(gcp)p; }
+DI uint64_t gu64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, (gcp)p, 8); return v; }
+DI void gs32(uint8_t* p, uint32_t v) { __builtin_memcpy((gp)p, &v, 4); }
+DI void gs64(uint8_t* p, uint64_t v) { __builtin_memcpy((gp)p, &v, 8); }
 DI void gs8(uint8_t* p, uint32_t v) { *(gp)p = (uint8_t)v; }
 DI int hibit32(uint32_t v) { return 31 - __builtin_clz(v); }
 DI uint32_t bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); } // (offset and width: low 5 bits)
@@ -81,8 +85,8 @@ constexpr uint32_t kShDump = 384;  // 8 bytes per lane: where the stores of idle
 constexpr uint32_t kShBytes = 896;
 constexpr uint32_t kDLL = 0, kDML = 4096, kDOF = 8192, kDHuf = 10240, kDictImg = 14336; // FSE entries of 8 bytes, Huffman entries of 2
 constexpr uint32_t kAux = 256;    // per file: the normalized counts of the three sequence tables, later the walk records / the plan
-// scratch of the Huffman weights, in the (still empty) output window: weights [256] | their FSE table [64 x 8] | its counts | rank counters
-constexpr uint32_t kWts = 0, kWTab = 256, kWNorm = 768, kWRank = 800, kWScratch = 832;
+// scratch of the Huffman weights: their FSE table [64 x 8] | its counts
+constexpr uint32_t kWTab = 0, kWNorm = 512; // in the table area, which the Huffman table takes over once the weights are decoded; the weights themselves: the ring
 
 // ---- the file's LPF lanes (LPF = 16, 8 or 4: inside one DPP row of 16 lanes)
 // the value of the lane N below, 0 for the file's first N lanes
@@ -181,13 +185,20 @@ struct LBack { // backward (the Huffman weights' stream: <= 128 bytes), zero bel
 };
 
 // Normalized counts (A.3) from LDS bytes (>= 8 readable bytes behind them) -> int16 norm[] in LDS at `norm_off`.  Returns bytes
-// used or 0 (give up).  sym_cap: symbols the caller has room for (<= max_sym + 1).  Every field (<= 10 bits) is one unaligned
-// 4-byte read at its bit position.  Bits past the description's end need no masking: a read that touches them either leaves
-// `bit` past the limit (rejected), or it is the short form of a value whose dropped bit was the only one outside.
+// used or 0 (give up).  sym_cap: symbols the caller has room for (<= max_sym + 1).  The description is read upwards through a
+// 64-bit register window, re-read from LDS when fewer than 16 of its bits are left (a lone lane pays a round trip per LDS read:
+// one per five or six symbols instead of one per symbol).  Bits past the description's end need no masking: a field that
+// touches them either leaves `bit` past the limit (rejected), or it is the short form of a value whose dropped bit was the only
+// one outside.
 DI uint32_t read_ncount_lane(uint32_t src_off, uint32_t n, int max_log, int max_sym, int sym_cap, uint32_t norm_off, uint32_t& nsym_out, uint32_t& log_out) {
     if (n < 1) return 0;
     const int32_t limit = (int32_t)(n > 4096 ? 4096 : n) * 8;
-    auto bits = [&](int32_t bit) -> uint32_t { return lds_u32(src_off + ((uint32_t)bit >> 3)) >> (bit & 7); }; // >= 25 bits
+    uint64_t win = lds_u64(src_off);
+    int32_t wbase = 0; // win = description bits [wbase, wbase + 64)
+    auto bits = [&](int32_t bit) -> uint32_t { // >= 16 bits at `bit`
+        if (bit - wbase > 48) { wbase = bit & ~7; win = lds_u64(src_off + ((uint32_t)wbase >> 3)); }
+        return (uint32_t)(win >> (bit - wbase));
+    };
     int32_t bit = 4;
     const int al = 5 + (int)(bits(0) & 15);
     if (al > max_log) return 0;
@@ -226,52 +237,61 @@ DI uint32_t read_ncount_lane(uint32_t src_off, uint32_t n, int max_log, int max_
     return (uint32_t)((bit + 7) >> 3);
 }
 
-// FSE decode table (A.3) by ONE lane: `tab_off` LDS offset of the 8-byte entries, norm[] in LDS.  kind 0 LL, 1 OF, 2 ML,
-// 3 Huffman weights (no extra bits).  Nothing is read back from LDS: a symbol's positions (the spread of A.3 visits them in
-// stride order) are collected as a bit mask in registers -- W words of 64 positions -- and numbered in ascending position
-// order straight from the mask (a lone lane pays a round trip per dependent LDS read: the textbook form, which re-reads the
-// spread symbols and keeps the state counters in memory, costs two per entry).
-template <int W>
-DI bool build_fse_mask(uint32_t tab_off, uint32_t norm_off, uint32_t nsym, uint32_t log, int kind) {
+// FSE decode table (A.3) by ONE lane: `tab_off` LDS offset of the 8-byte entries, norm[] in LDS (turned into the per-symbol
+// state counters on the way).  kind 0 LL, 1 OF, 2 ML, 3 Huffman weights (no extra bits).  Several tables are built side by side
+// in different lanes, so both passes are loops over TABLE POSITIONS -- the same trip count for every lane with the same table
+// log -- and never over a symbol's count (a loop whose trip count differs from lane to lane runs as long as its longest
+// instance, once per symbol: measured six times the cost of one table):
+//   pass 1, the spread: position after position in stride order takes the current symbol (its code | extra bits << 8);
+//   pass 2, the numbering: position after position in ascending order, four at a time -- the symbol is read back and its
+//           state counter is bumped by an LDS atomic that returns the old value (two 16-bit counters share a word: counts
+//           stay below 2^16, so an add to one half never carries into the other), both round trips shared by the four.
+DI bool build_fse_lane(uint32_t tab_off, uint32_t norm_off, uint32_t nsym, uint32_t log, int kind) {
     const uint32_t size = 1u << log, mask = size - 1;
     const uint32_t step = (size >> 1) + (size >> 3) + 3;
     auto extra_of = [&](uint32_t s) -> uint32_t { return kind == 0 ? L32(kShLL + 4 * s) >> 24 : (kind == 1 ? s : (kind == 2 ? L32(kShML + 4 * s) >> 24 : 0u)); };
     uint32_t high = size;
     for (uint32_t s = 0; s < nsym; s++) // "less than one": a single state at the top, numbered 1 -> nbBits = log, next-state base 0
         if (L16s(norm_off + 2 * s) == -1) { high--; L64(tab_off + 8 * high) = fse_entry(tab_off, 0, log, s, extra_of(s)); }
-    uint32_t pos = 0;
-    for (uint32_t s = 0; s < nsym; s++) {
-        const int c = L16s(norm_off + 2 * s);
-        if (c <= 0) continue;
-        uint64_t m[W];
-#pragma unroll
-        for (int w = 0; w < W; w++) m[w] = 0;
-        for (int i = 0; i < c; i++) {
-#pragma unroll
-            for (int w = 0; w < W; w++) m[w] |= (W == 1 || (pos >> 6) == (uint32_t)w) ? 1ull << (pos & 63) : 0ull;
+    // pass 1
+    {
+        uint32_t pos = 0, s = 0xFFFFFFFFu, val = 0;
+        int32_t left = 0;
+        bool over = false;
+        for (uint32_t j = 0; j < high; j++) {
+            while (left <= 0 && !over) { // the next symbol that has states (at most nsym steps in all)
+                s++;
+                over = s >= nsym;
+                left = over ? 1 : (int32_t)L16s(norm_off + 2 * s);
+                val = over ? 0u : (s | (extra_of(s) << 8));
+            }
+            L32(tab_off + 8 * pos) = val;
+            left--;
             do { pos = (pos + step) & mask; } while (pos >= high);
         }
-        const uint32_t extra = extra_of(s);
-        uint32_t d = (uint32_t)c;
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-            uint64_t mm = m[w];
-            while (mm) {
-                const uint32_t p = (uint32_t)__builtin_ctzll(mm) + 64u * (uint32_t)w;
-                mm &= mm - 1;
-                const uint32_t nb = log - (uint32_t)hibit32(d);
-                L64(tab_off + 8 * p) = fse_entry(tab_off, (d << nb) - size, nb, s, extra);
-                d++;
-            }
-        }
+        // every count is used up exactly when the positions are: the counts of the symbols with states sum to `high`
+        if (over || left != 0 || pos != 0) return false;
+        for (s++; s < nsym; s++) if (L16s(norm_off + 2 * s) > 0) return false;
     }
-    return pos == 0;
-}
-DI bool build_fse_lane(uint32_t tab_off, uint32_t norm_off, uint32_t nsym, uint32_t log, int kind) {
-    if (log <= 6) return build_fse_mask<1>(tab_off, norm_off, nsym, log, kind);
-    if (log == 7) return build_fse_mask<2>(tab_off, norm_off, nsym, log, kind);
-    if (log == 8) return build_fse_mask<4>(tab_off, norm_off, nsym, log, kind);
-    return build_fse_mask<8>(tab_off, norm_off, nsym, log, kind);
+    // pass 2
+    auto number = [&](uint32_t i, uint32_t v, uint32_t old) {
+        const uint32_t s = v & 0xFF, extra = v >> 8;
+        const uint32_t d = (old >> (16 * (s & 1))) & 0xFFFF;
+        const uint32_t nb = log - (uint32_t)hibit32(d | 1u);
+        L64(tab_off + 8 * i) = fse_entry(tab_off, (d << nb) - size, nb, s, extra);
+    };
+    auto bump = [&](uint32_t v) -> uint32_t {
+        const uint32_t s = v & 0xFF;
+        return __hip_atomic_fetch_add(static_cast<uint32_t*>(__builtin_assume_aligned(lds + norm_off + 2 * (s & ~1u), 4)), 1u << (16 * (s & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    uint32_t i = 0;
+    for (; i + 4 <= high; i += 4) {
+        const uint32_t v0 = L32(tab_off + 8 * i), v1 = L32(tab_off + 8 * i + 8), v2 = L32(tab_off + 8 * i + 16), v3 = L32(tab_off + 8 * i + 24);
+        const uint32_t o0 = bump(v0), o1 = bump(v1), o2 = bump(v2), o3 = bump(v3);
+        number(i, v0, o0); number(i + 1, v1, o1); number(i + 2, v2, o2); number(i + 3, v3, o3);
+    }
+    for (; i < high; i++) { const uint32_t v = L32(tab_off + 8 * i); number(i, v, bump(v)); }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------ XXH64 pieces (A.6), over LDS bytes
@@ -339,9 +359,13 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
     const uint32_t f = lane / LPF, sub = lane % LPF;
     const bool leader = sub == 0;
     const uint32_t dict_off = kShBytes;
-    const uint32_t stride = a.tab_bytes + kAux + a.comp_bytes + a.out_bytes;
-    const uint32_t tabo = kShBytes + (DICT ? kDictImg : 0u) + f * stride; // the file's slot
-    const uint32_t ringo = tabo + a.tab_bytes, cmp = ringo + kAux, outo = cmp + a.comp_bytes;
+    const uint32_t ent = a.tab_bytes + kAux + a.comp_bytes;                // the entropy phase's image of a file ...
+    const uint32_t stride = ent > a.out_bytes ? ent : a.out_bytes;         // ... and its output window share the slot
+    const uint32_t tabo = kShBytes + (DICT ? kDictImg : 0u) + f * stride;  // the file's slot
+    const uint32_t ringo = tabo + a.tab_bytes, cmp = ringo + kAux, outo = tabo;
+    // the file's share of the scratch in HBM: literals, then the sequences (8 bytes each)
+    uint8_t* const lit_g = a.scratch + (size_t)(blockIdx.x * G + f) * ((size_t)a.lit_stride + 8u * (size_t)a.seq_cap);
+    uint8_t* const seq_g = lit_g + a.lit_stride;
 
     if (lane < 36) L32(kShLL + 4 * lane) = LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24);
     if (lane < 53) L32(kShML + 4 * lane) = ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24);
@@ -353,35 +377,53 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
     const uint32_t ngroups = (a.n + G - 1) / G;
     bool first_group = true;
     (void)first_group;
+    // The way to a group's input is four dependent trips to HBM (ticket -> list entry -> job entry -> bytes).  They are made for the
+    // NEXT group while this one is decoded, one trip per phase: by the time a group starts, its first kPF x 16 bytes per lane sit in registers.
+    constexpr int kPF = 6;
+    struct JobRegs { bool have, fits; uint32_t job, n, cap, jdict; const uint8_t* src; uint8_t* dst; uint8_t* dst2; };
+    auto ticket = [&]() -> uint32_t { uint32_t t = 0; if (lane == 0) t = atomicAdd(&a.counter[5], 1u); return (uint32_t)__builtin_amdgcn_readfirstlane((int)t); };
+    auto list_entry = [&](uint32_t gg) -> uint32_t { const uint32_t fi = gg * G + f; return (gg < ngroups && fi < a.n) ? a.list[fi] : 0xFFFFFFFFu; };
+    auto job_entry = [&](uint32_t jb) -> JobRegs {
+        JobRegs J; J.have = jb != 0xFFFFFFFFu; J.fits = false; J.job = jb; J.n = 0; J.cap = 0; J.jdict = 0; J.src = nullptr; J.dst = nullptr; J.dst2 = nullptr;
+        if (J.have) {
+            const DevJob& dj = a.jobs[jb];
+            J.src = dj.src; J.dst = dj.dst; J.dst2 = dj.dst2; J.jdict = dj.dict;
+            J.fits = dj.src_len + 16 <= a.comp_bytes && dj.dst_cap + 16 <= a.out_bytes; // (the host sized the slots for the launch's largest file)
+            J.n = J.fits ? (uint32_t)dj.src_len : 0u; J.cap = J.fits ? (uint32_t)dj.dst_cap : 0u;
+        }
+        return J;
+    };
+    auto prefetch = [&](const JobRegs& J, V16 (&pf)[kPF]) { // (inputs are readable MZD_SRC_PADDING bytes past their end)
+#pragma unroll
+        for (int k = 0; k < kPF; k++) { const uint32_t o = 16 * (sub + LPF * (uint32_t)k); pf[k] = o < J.n ? gv16(J.src + o) : V16{0, 0}; }
+    };
+    uint32_t g = ticket();
+    JobRegs J = job_entry(list_entry(g));
+    V16 pf[kPF];
+    prefetch(J, pf);
     for (;;) {
-        uint32_t g = 0;
         SSTAMP(0);
-        if (lane == 0) g = atomicAdd(&a.counter[5], 1u);
-        g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
         if (g >= ngroups) break;
 
-        // =============================== the group's files: job entries, then the compressed bytes -> LDS
+        // =============================== the group's files: the compressed bytes -> LDS
         const uint32_t fidx = g * G + f;
-        const bool have = fidx < a.n;
-        uint32_t job = 0;
-        const uint8_t* src = nullptr; uint8_t* dst = nullptr; uint8_t* dst2 = nullptr;
-        uint32_t n = 0, cap = 0, jdict = 0;
-        bool fits = false;
-        if (have) {
-            job = a.list[fidx];
-            const DevJob& dj = a.jobs[job];
-            src = dj.src; dst = dj.dst; dst2 = dj.dst2; jdict = dj.dict;
-            fits = dj.src_len + 16 <= a.comp_bytes && dj.dst_cap + 16 <= a.out_bytes; // (the host sized the slots for the launch's largest file)
-            n = fits ? (uint32_t)dj.src_len : 0u; cap = fits ? (uint32_t)dj.dst_cap : 0u;
-        }
-        if (fits) { // 16 bytes per lane, four loads in flight (inputs are readable MZD_SRC_PADDING bytes past their end)
-            uint32_t k = sub * 16;
+        const bool have = J.have, fits = J.fits;
+        const uint32_t job = J.job, n = J.n, cap = J.cap, jdict = J.jdict;
+        const uint8_t* const src = J.src; uint8_t* const dst = J.dst; uint8_t* const dst2 = J.dst2;
+        if (fits) { // 16 bytes per lane: what came ahead, then the rest, four loads in flight
+#pragma unroll
+            for (int k = 0; k < kPF; k++) { const uint32_t o = 16 * (sub + LPF * (uint32_t)k); if (o < n) lds_sv16(cmp + o, pf[k]); }
+            uint32_t k = (sub + LPF * kPF) * 16;
             for (; k + 3 * LPF * 16 < n; k += 4 * LPF * 16) {
                 const V16 v0 = gv16(src + k), v1 = gv16(src + k + LPF * 16), v2 = gv16(src + k + 2 * LPF * 16), v3 = gv16(src + k + 3 * LPF * 16);
                 lds_sv16(cmp + k, v0); lds_sv16(cmp + k + LPF * 16, v1); lds_sv16(cmp + k + 2 * LPF * 16, v2); lds_sv16(cmp + k + 3 * LPF * 16, v3);
             }
             for (; k < n; k += LPF * 16) lds_sv16(cmp + k, gv16(src + k));
         }
+        // (trip 1 for the next group -- only while at least a grid's worth of groups is left behind this one: a wavefront that books its
+        //  next group early takes it from one that would have been free sooner, which matters when a launch has about a group per wavefront)
+        const bool early = g + gridDim.x < ngroups;
+        uint32_t g_next = early ? ticket() : 0xFFFFFFFFu;
         // the group's dictionary: the first one named (the host sorts the list by dictionary)
         if (DICT) {
             const uint64_t named = __ballot(have && jdict != 0 && jdict <= a.ndicts);
@@ -404,6 +446,8 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
         SSTAMP(1);
 
         // =============================== headers: frame, block, literals section (every lane of the file, from LDS)
+        uint32_t why = 0; // (diagnostic build: where the file left the fast path)
+        (void)why;
         bool ok = have && fits; // still on the fast path
         bool done = false;      // finished without a block to decode (empty file, raw / RLE block)
         uint32_t out_len = 0, res_off = outo; // the decoded file: out_len bytes at LDS offset res_off
@@ -480,7 +524,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     if (regen > block_max || regen > cap || regen == 0 || (streams == 4 && regen < 6) || hl + comp >= bsize) break;
                     uint32_t p_off = b0 + hl, rem = comp;
                     if (lit_type == 2) {
-                        if (a.tab_bytes == 0) break; // no room for a private Huffman table in this launch's slots
+                        if (a.tab_bytes < 1024) break; // no room for a private Huffman table (and the weights' scratch) in this launch's slots
                         if (rem < 1) break;
                         const uint32_t hb = L8(cmp + p_off);
                         const uint32_t tl = hb >= 128 ? 1 + ((hb - 127) + 1) / 2 : 1 + hb;
@@ -506,21 +550,24 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
             } while (false);
         }
         (void)tree_len;
+        if (have && !ok) why = 1;
         bool live = ok && !done; // a compressed block to decode
+        const uint32_t stored_ck = (ok && has_ck && n >= 4) ? lds_u32(cmp + n - 4) : 0u; // (read now: the window will lie over the input)
         // raw / RLE blocks: the content is the block's bytes where they lie / the window filled with the byte
         if (ok && done && n != 0) {
             if (btype == 0) res_off = cmp + b0;
-            else { const uint32_t v = L8(cmp + b0); for (uint32_t k = sub; k < bsize; k += LPF) L8(outo + k) = (uint8_t)v; }
+            else { const uint32_t v = L8(cmp + b0); asm volatile("" ::: "memory"); for (uint32_t k = sub; k < bsize; k += LPF) L8(outo + k) = (uint8_t)v; }
         }
-        const uint32_t lit_base = lit_type == 0 ? cmp + lit_off : outo + cap - nlit; // the literals: raw where they lie, else the window's tail
+        const uint8_t* const lit_p = lit_type == 0 ? src + lit_off : lit_g; // the literals: raw where the input has them (HBM), else the scratch
+        const uint32_t job_next = early ? list_entry(g_next) : 0xFFFFFFFFu; // (trip 2)
         SSTAMP(2);
 
         // =============================== Huffman weights and decode table (one lane per file)
         uint32_t huf_log = di.huf_log, huf_off = dict_off + kDHuf; // treeless: the dictionary's table
         if (live && lit_type == 2) {
-            uint32_t good = 0, maxbits_l = 0;
+            uint32_t good = 0, maxbits_l = 0, nw_l = 0;
             if (leader) {
-                const uint32_t wts = outo + kWts, wtab = outo + kWTab, wnorm = outo + kWNorm, so = outo + kWRank;
+                const uint32_t wts = ringo, wtab = tabo + kWTab, wnorm = tabo + kWNorm;
                 uint32_t nw = 0;
                 do {
                     const uint32_t tp = cmp + tree_off; // the tree description
@@ -559,54 +606,116 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         }
                         if (!fin) break;
                     }
-                    // ---- validation, implied last weight, canonical table (A.4)
-                    SSTAMP(15);
                     if (nw < 1 || nw > 255) break;
-                    for (uint32_t r = 0; r < 16; r++) L16(so + 2 * r) = 0; // rank counters
-                    uint32_t total = 0;
-                    bool wbad = false;
-                    for (uint32_t i = 0; i < nw; i++) {
-                        const uint32_t w = L8(wts + i);
-                        if (w > 12) { wbad = true; break; }
-                        L16(so + 2 * w) = (uint16_t)(L16(so + 2 * w) + 1);
-                        total += w ? 1u << (w - 1) : 0u;
-                    }
-                    if (wbad || total == 0) break;
-                    const uint32_t maxbits = (uint32_t)hibit32(total) + 1;
-                    if (maxbits > 11 || (2u << maxbits) > a.tab_bytes) break; // (a table that does not fit the slot: the general path takes the file)
-                    const uint32_t left = (1u << maxbits) - total;
-                    if (left & (left - 1)) break;
-                    const uint32_t wl = (uint32_t)hibit32(left) + 1;
-                    L8(wts + nw) = (uint8_t)wl; nw++;
-                    L16(so + 2 * wl) = (uint16_t)(L16(so + 2 * wl) + 1);
-                    const uint32_t r1 = L16(so + 2);
-                    if (r1 < 2 || (r1 & 1)) break;
-                    uint32_t pos = 0; // rank counters -> start positions (weight 1 = longest codes first)
-                    for (uint32_t r = 1; r <= maxbits; r++) { const uint32_t c = L16(so + 2 * r); L16(so + 2 * r) = (uint16_t)pos; pos += c << (r - 1); }
-                    if (pos != (1u << maxbits)) break; // also catches weights above maxbits
-                    SSTAMP(16);
-                    for (uint32_t s = 0; s < nw; s++) {
-                        const uint32_t w = L8(wts + s);
-                        if (!w) continue;
-                        const uint32_t cnt = 1u << (w - 1), at = L16(so + 2 * w);
-                        L16(so + 2 * w) = (uint16_t)(at + cnt);
-                        const uint32_t e = s | ((maxbits + 1 - w) << 8);
-                        if (cnt == 1) L16(tabo + 2 * at) = (uint16_t)e;
-                        else for (uint32_t i = 0; i < cnt; i += 2) L32(tabo + 2 * (at + i)) = e | (e << 16);
-                    }
-                    maxbits_l = maxbits;
+                    for (uint32_t i = nw; i < (nw & ~7u) + 8; i++) L8(wts + i) = 0; // (the class lanes below read the weights eight at a time: zeros behind the last one)
+                    nw_l = nw;
                     good = 1;
                 } while (false);
             }
+            SSTAMP(15);
             good = (uint32_t)__shfl((int)good, (int)(f * LPF));
-            maxbits_l = (uint32_t)__shfl((int)maxbits_l, (int)(f * LPF));
+            nw_l = (uint32_t)__shfl((int)nw_l, (int)(f * LPF));
+            wsync();
+            // ---- validation, implied last weight, canonical table (A.4): the weight classes 1..12 on the file's lanes (class v on lane
+            // (v - 1) % LPF).  A class lane counts its symbols (eight weights per read, compared bytewise), the classes' sizes are
+            // scanned into start positions (weight 1 = longest codes first), and every lane fills the entries of its own symbols in
+            // ascending order -- no counter is read back from LDS.
+            if (good) {
+                const uint32_t wts = ringo;
+                constexpr uint32_t NCL = (12 + LPF - 1) / LPF;
+                const uint32_t words = (nw_l + 8) / 8; // (covers index nw: the implied last weight is appended below)
+                auto eqflags = [&](uint32_t word, uint32_t v) -> uint32_t { // 0x80 in every byte of `word` that equals v (all bytes < 0x80)
+                    const uint32_t x = word ^ (v * 0x01010101u);
+                    return ~((x | 0x80808080u) - 0x01010101u) & 0x80808080u;
+                };
+                uint32_t cnt[NCL];
+                uint32_t over = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < NCL; j++) cnt[j] = 0;
+                for (uint32_t wi = 0; wi < words; wi++) {
+                    const uint64_t W8 = L64(wts + 8 * wi);
+                    const uint32_t lo = (uint32_t)W8, hi = (uint32_t)(W8 >> 32);
+                    over |= ((lo + 0x73737373u) | (hi + 0x73737373u)) & 0x80808080u; // a weight above 12
+#pragma unroll
+                    for (uint32_t j = 0; j < NCL; j++) {
+                        const uint32_t v = sub + 1 + j * LPF;
+                        cnt[j] += (uint32_t)__builtin_popcount(eqflags(lo, v)) + (uint32_t)__builtin_popcount(eqflags(hi, v));
+                    }
+                }
+                uint32_t part = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < NCL; j++) { const uint32_t v = sub + 1 + j * LPF; part += v <= 12 ? cnt[j] << (v - 1) : 0u; }
+                uint32_t tot = part; // sum over the file's lanes
+                tot += seg_shr<1, LPF>(tot, sub); tot += seg_shr<2, LPF>(tot, sub);
+                if (LPF > 4) tot += seg_shr<4, LPF>(tot, sub);
+                if (LPF > 8) tot += seg_shr<8, LPF>(tot, sub);
+                const uint32_t total = bcast<LPF - 1, LPF>(tot);
+                bool g2 = over == 0 && total != 0;
+                const uint32_t maxbits = g2 ? (uint32_t)hibit32(total) + 1 : 1u;
+                g2 = g2 && maxbits <= 11 && (2u << maxbits) <= a.tab_bytes; // (a table that does not fit the slot: the general path takes the file)
+                const uint32_t left = (1u << maxbits) - total;
+                g2 = g2 && (left & (left - 1)) == 0;
+                const uint32_t wl = (uint32_t)hibit32(left | 1u) + 1; // the implied last weight, of symbol nw
+                if (g2 && leader) L8(wts + nw_l) = (uint8_t)wl;
+#pragma unroll
+                for (uint32_t j = 0; j < NCL; j++) if (sub + 1 + j * LPF == wl) cnt[j]++;
+                const uint32_t r1 = bcast<0, LPF>(cnt[0]); // symbols of weight 1: an even number, at least two
+                g2 = g2 && r1 >= 2 && (r1 & 1) == 0;
+                // start positions: exclusive scan of the class sizes, class after class
+                uint32_t start[NCL];
+                {
+                    uint32_t carry = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < NCL; j++) {
+                        const uint32_t v = sub + 1 + j * LPF;
+                        const uint32_t sz = v <= 12 ? cnt[j] << (v - 1) : 0u;
+                        uint32_t inc = sz;
+                        inc += seg_shr<1, LPF>(inc, sub); inc += seg_shr<2, LPF>(inc, sub);
+                        if (LPF > 4) inc += seg_shr<4, LPF>(inc, sub);
+                        if (LPF > 8) inc += seg_shr<8, LPF>(inc, sub);
+                        start[j] = carry + inc - sz;
+                        carry += bcast<LPF - 1, LPF>(inc);
+                    }
+                    g2 = g2 && carry == (1u << maxbits); // (also catches weights above maxbits)
+                }
+                SSTAMP(16);
+                wsync();
+                if (g2) {
+#pragma unroll
+                    for (uint32_t j = 0; j < NCL; j++) {
+                        const uint32_t v = sub + 1 + j * LPF;
+                        if (v > maxbits) continue;
+                        uint32_t pos = start[j];
+                        const uint32_t len8 = (maxbits + 1 - v) << 8, span = 1u << (v - 1);
+                        for (uint32_t wi = 0; wi < words; wi++) {
+                            const uint64_t W8 = L64(wts + 8 * wi);
+                            uint64_t z = (uint64_t)eqflags((uint32_t)W8, v) | ((uint64_t)eqflags((uint32_t)(W8 >> 32), v) << 32);
+                            while (z) {
+                                const uint32_t sym = 8 * wi + ((uint32_t)__builtin_ctzll(z) >> 3);
+                                z &= z - 1;
+                                const uint32_t e = sym | len8, e2 = e | (e << 16);
+                                const uint32_t at = tabo + 2 * pos;
+                                if (v == 1) L16(at) = (uint16_t)e;
+                                else if (v == 2) L32(at) = e2;
+                                else if (v == 3) L64(at) = (uint64_t)e2 | ((uint64_t)e2 << 32);
+                                else { const V16 q = {(uint64_t)e2 | ((uint64_t)e2 << 32), (uint64_t)e2 | ((uint64_t)e2 << 32)}; for (uint32_t o = 0; o < 2 * span; o += 16) lds_sv16(at + o, q); }
+                                pos += span;
+                            }
+                        }
+                    }
+                    maxbits_l = maxbits;
+                }
+                good = g2 ? 1u : 0u;
+            }
+            { const uint64_t gm = __ballot(good != 0); good = ((gm >> (f * LPF)) & ((1ull << LPF) - 1)) == ((1ull << LPF) - 1) ? 1u : 0u; } // (uniform in the file)
             huf_log = maxbits_l; huf_off = tabo;
-            if (!good) { ok = false; live = false; }
+            if (!good) { ok = false; live = false; why = 2; }
         }
         wsync();
+        JobRegs Jn = job_entry(job_next); // (trip 3)
         SSTAMP(3);
 
-        // =============================== Huffman streams -> the window's tail (lane = (file, stream))
+        // =============================== Huffman streams -> the literal scratch (lane = (file, stream))
         {
             uint32_t lit_bad = 0;
             if (live && lit_type >= 2 && sub < streams) {
@@ -616,42 +725,42 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                 const uint32_t rel = streams == 1 ? 0u : (st == 0 ? 0u : (st == 1 ? s_len0 : (st == 2 ? s_len0 + s_len1 : s_len0 + s_len1 + s_len2)));
                 const uint32_t lbase = cmp + s_base + rel;
                 const uint32_t nsym = streams == 1 ? nlit : (st < 3 ? seg : nlit - 3 * seg);
-                const uint32_t out = lit_base + (streams == 1 ? 0u : st * seg);
+                uint8_t* const out = lit_g + (streams == 1 ? 0u : st * seg);
                 const uint32_t Lg = huf_log, tab = huf_off;
                 bool good = sl != 0;
                 const uint32_t last = good ? L8(lbase + sl - 1) : 1u;
                 good = good && last != 0;
                 if (good) {
                     int32_t h = (int32_t)((sl - 1) * 8) + hibit32(last); // unread bits
-                    // the 64 bits below the read head, MSB-aligned; bits below the stream's start read as zero (A.4: the last symbols
+                    // the 57..64 bits below the read head, MSB-aligned; bits below the stream's start read as zero (A.4: the last symbols
                     // may peek past it).  Every stream is preceded by >= 8 bytes of its file.
-                    auto window = [&](int32_t hh, int32_t& av) -> uint64_t {
+                    auto window = [&](int32_t hh) -> uint64_t {
                         int32_t b = (hh - 1) >> 3;
                         b = b < -1 ? -1 : b;
                         uint64_t w = lds_u64(lbase + (uint32_t)(b + 9) - 16);
-                        const uint32_t sh = (uint32_t)(8 * (b + 1) - hh) & 63;
-                        w <<= sh;
-                        av = 64 - (int32_t)sh;
+                        w <<= (uint32_t)(8 * (b + 1) - hh) & 63;
                         const uint64_t keep = hh >= 64 ? ~0ull : (hh <= 0 ? 0ull : ~0ull << (64 - hh));
                         return w & keep;
                     };
-                    int32_t av;
-                    uint64_t cur = window(h, av);
+                    uint64_t cur = window(h);
                     uint32_t k = 0;
                     const uint32_t shL = 64 - Lg;
-                    for (; k + 2 <= nsym; k += 2) { // two symbols (<= 22 bits) per step
+                    for (; k + 4 <= nsym; k += 4) { // four symbols (<= 44 bits) per window, one 4-byte store
                         const uint32_t e0 = L16(tab + 2 * (uint32_t)(cur >> shL));
                         cur <<= (e0 >> 8);
                         const uint32_t e1 = L16(tab + 2 * (uint32_t)(cur >> shL));
                         cur <<= (e1 >> 8);
-                        const int32_t used = (int32_t)((e0 >> 8) + (e1 >> 8));
-                        av -= used; h -= used;
-                        L8(out + k) = (uint8_t)e0; L8(out + k + 1) = (uint8_t)e1;
-                        if (av < 22) cur = window(h, av);
+                        const uint32_t e2 = L16(tab + 2 * (uint32_t)(cur >> shL));
+                        cur <<= (e2 >> 8);
+                        const uint32_t e3 = L16(tab + 2 * (uint32_t)(cur >> shL));
+                        h -= (int32_t)((e0 >> 8) + (e1 >> 8) + (e2 >> 8) + (e3 >> 8));
+                        gs32(out + k, (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24));
+                        cur = window(h);
                     }
-                    if (k < nsym) {
+                    for (; k < nsym; k++) {
                         const uint32_t e0 = L16(tab + 2 * (uint32_t)(cur >> shL));
-                        L8(out + k) = (uint8_t)e0;
+                        gs8(out + k, e0 & 0xFF);
+                        cur <<= (e0 >> 8);
                         h -= (int32_t)(e0 >> 8);
                     }
                     good = h == 0; // consumed exactly
@@ -659,11 +768,13 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                 if (!good) lit_bad = 1;
             }
             const uint64_t badm = __ballot(lit_bad != 0); // a failed stream condemns its file
-            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) { ok = false; live = false; }
-            // RLE literals: the tail is filled with the byte
-            if (live && lit_type == 1) { const uint32_t v = L8(cmp + lit_off); for (uint32_t k = sub; k < nlit; k += LPF) L8(lit_base + k) = (uint8_t)v; }
+            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) { ok = false; live = false; why = 3; }
+            // RLE literals: the scratch is filled with the byte
+            if (live && lit_type == 1) { const uint32_t v = L8(cmp + lit_off) * 0x01010101u; for (uint32_t k = 4 * sub; k < nlit; k += 4 * LPF) gs32(lit_g + k, v); } // (slack past nlit)
         }
         wsync();
+        V16 pfn[kPF];
+        prefetch(Jn, pfn); // (trip 4: in flight from here to the next group's start)
         SSTAMP(4);
 
         // =============================== sequences section header (one lane per file): nbSeq, modes, normalized counts
@@ -729,7 +840,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
             tabL = (uint32_t)__shfl((int)tabL, ld); tabO = (uint32_t)__shfl((int)tabO, ld); tabM = (uint32_t)__shfl((int)tabM, ld);
             alL = (uint32_t)__shfl((int)alL, ld); alO = (uint32_t)__shfl((int)alO, ld); alM = (uint32_t)__shfl((int)alM, ld);
             modes3 = (uint32_t)__shfl((int)modes3, ld); rle_syms = (uint32_t)__shfl((int)rle_syms, ld); nsyms = (uint32_t)__shfl((int)nsyms, ld);
-            if (!good) { ok = false; live = false; nseq = 0; }
+            if (!good) { ok = false; live = false; nseq = 0; why = 4; }
         }
         wsync();
         SSTAMP(5);
@@ -751,22 +862,20 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                 }
             }
             const uint64_t badm = __ballot(tb_bad != 0);
-            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) { ok = false; live = false; nseq = 0; }
+            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) { ok = false; live = false; nseq = 0; why = 5; }
         }
         wsync();
         SSTAMP(6);
 
-        // =============================== FSE state walk -> field extraction -> execution, LPF sequences at a time
+        // =============================== FSE state walk -> field extraction -> the sequence scratch, LPF sequences at a time
         // Bit positions are LDS bit addresses (8 * byte offset + bit): G = the read head, bits below it are unread.
-        // Per step of LPF sequences: (1) the walk, one lane per file, branch-free: the state as it stands is the record of a
-        // sequence; (2) lane = sequence: fields from the records, positions by scans over the file's lanes, what can be checked
-        // without the offsets, and the literals -- they depend on nothing: every lane copies its own (reads of the whole step
-        // before its writes: the literals may sit in the window's tail); (3) in order, the file's lanes in step: repeat offsets
-        // and the match, a byte per lane, its fields broadcast from the sequence's lane (DPP).
+        // Per step of LPF sequences: the walk, one lane per file, branch-free -- the state as it stands is the record of a
+        // sequence --, then lane = sequence: the fields from the records, 8 bytes per sequence to the scratch (coalesced).
+        bool bad = false;
+        uint32_t nrun = 0;
         {
             const uint32_t G0 = 8 * (cmp + bs_off); // the stream's bit 0
             uint32_t Gh = G0, aL = 0, aM = 0, aO = 0;
-            bool bad = false;
             if (live && nseq) {
                 const uint32_t lastb = L8(cmp + bs_off + bs_len - 1);
                 bad = lastb == 0;
@@ -779,23 +888,16 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                 aM = tabM + 8 * bfe(Y, 0, alM); aO = tabO + 8 * bfe(Y, alM, alO); aL = tabL + 8 * bfe(Y, alM + alO, alL);
                 Gh -= need;
             }
-            const uint32_t dict_len = with_d ? di.content_len : 0u;
-            const uint8_t* const dict_end = with_d ? di.content + di.content_len : nullptr;
-            uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
-            if (with_d && di.formatted) { rep0 = di.rep[0]; rep1 = di.rep[1]; rep2 = di.rep[2]; }
-            uint32_t lpos = 0, opos = 0;
-            const uint32_t nrun = (live && !bad) ? nseq : 0u;
-            const uint32_t dump = kShDump + 8 * lane; // where the stores of lanes that have nothing to store go
+            nrun = (live && !bad) ? nseq : 0u;
 #ifdef MZD_SMALL_STAMPS
-            uint64_t tw_ = 0, tp_ = 0, te_ = 0, t0_ = __builtin_readcyclecounter(), t1_ = 0;
+            uint64_t tw_ = 0, tp_ = 0, t0_ = __builtin_readcyclecounter(), t1_ = 0;
 #define GSTAMP(acc) do { t1_ = __builtin_readcyclecounter(); acc += t1_ - t0_; t0_ = t1_; } while (0)
 #else
 #define GSTAMP(acc)
 #endif
             for (uint32_t c0 = 0; __any(c0 < nrun && !bad); c0 += LPF) {
                 const bool act = c0 < nrun && !bad;
-                GSTAMP(te_);
-                // ---- (1) the walk
+                // ---- the walk
                 uint32_t wbad = 0;
                 if (act && leader) {
                     auto record = [&](uint32_t k) { *reinterpret_cast<uint4*>(lds + ringo + 16 * k) = make_uint4(aL, aM, aO, Gh); };
@@ -825,8 +927,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                 }
                 wsync();
                 GSTAMP(tw_);
-                // ---- (2) lane = sequence c0 + sub
-                uint32_t ll = 0, ml = 0, w0 = 0; // w0: repeat code (0..3; 4 = a new offset) | (offset value - 3) << 3
+                // ---- lane = sequence c0 + sub
                 uint32_t pbad = wbad;
                 if (act && c0 + sub < nrun) {
                     const uint4 r = *reinterpret_cast<const uint4*>(lds + ringo + 16 * sub);
@@ -841,25 +942,93 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     const uint32_t vM = (uint32_t)W & (uint32_t)((1ull << xM) - 1); W >>= xM;
                     const uint32_t vO = (uint32_t)(W & ((1ull << xO) - 1));
                     const uint32_t ofv = (1u << cO) + vO;
-                    ml = (L32(kShML + 4 * cM) & 0xFFFFFF) + vM;
-                    ll = (L32(kShLL + 4 * cL) & 0xFFFFFF) + vL;
+                    const uint32_t ml = (L32(kShML + 4 * cM) & 0xFFFFFF) + vM;
+                    const uint32_t ll = (L32(kShLL + 4 * cL) & 0xFFFFFF) + vL;
                     if (c0 + sub + 1 == nrun && tL != G0) pbad = 1; // the bitstream must be consumed exactly
-                    if (((ll | ml) >> 14) | (cO > 18)) pbad = 1;     // (cannot be right for a window of <= 8 KiB and a dictionary of <= 128 KiB; keeps the packed fields and the sums below in range)
-                    w0 = ofv > 3 ? 4u | ((ofv - 3) << 3) : ofv - 1 + (ll == 0 ? 1u : 0u);
+                    if (((ll | ml) >> 14) | (cO > 18)) pbad = 1;     // (cannot be right for a window of <= 8 KiB and a dictionary of <= 128 KiB; keeps the packed fields in range)
+                    gs64(seq_g + 8 * (c0 + sub), (uint64_t)(ll | (ml << 14)) | ((uint64_t)ofv << 32));
                 }
-                // positions: inclusive scans over the file's lanes
+                {
+                    const uint64_t pm = __ballot(pbad != 0);
+                    if ((pm >> (f * LPF)) & ((1ull << LPF) - 1)) bad = true;
+                }
+                wsync();
+                GSTAMP(tp_);
+            }
+#ifdef MZD_SMALL_STAMPS
+            if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[10] = tw_; a.stamps[11] = tp_; }
+#endif
+            if (bad) { ok = false; live = false; nrun = 0; why = 6; }
+        }
+        // what this wavefront stored to the scratch is read back by its other lanes: the stores have to have left (same CU: same L1)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#ifdef MZD_EXP_AGENT_ACQ
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+        wsync();
+        SSTAMP(7);
+
+        // =============================== execution: the slot is the file's output window now, LPF sequences at a time, lane = sequence.
+        // Software pipeline over the steps: the sequences of step c + 2 and the literals of step c + 1 are in flight (HBM scratch, L2)
+        // while step c is executed.
+        //   A(c): fields, positions by scans over the file's lanes, what can be checked without the offsets, the literal requests;
+        //   B(c): repeat offsets (A.5) by a scan over references; the literals and the matches that lie wholly in the dictionary depend
+        //         on nothing: every lane stores its own; the matches inside the window in rounds, LDS -> LDS.
+        if (live) {
+            const uint32_t dict_len = with_d ? di.content_len : 0u;
+            const uint8_t* const dict_end = with_d ? di.content + di.content_len : nullptr;
+            uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+            if (with_d && di.formatted) { rep0 = di.rep[0]; rep1 = di.rep[1]; rep2 = di.rep[2]; }
+            const uint32_t dump = kShDump + 8 * lane; // where the stores of lanes that have nothing to store go
+            bool xbad = false;
+            uint32_t lpos = 0, opos = 0; // literals consumed / output produced before the step that A() looks at
+            // the literals: from the scratch (raw ones: from the input) into the TAIL of the window (cap - nlit ..), 16 bytes per lane.
+            // The write head of the execution never passes the literal read head -- what is still to be written is at least the
+            // literals still to be read -- so literals and output share the window.
+            const uint32_t lit_base = outo + cap - nlit;
+            for (uint32_t q = 16 * sub; q < nlit; q += 16 * LPF) { const V16 v = gv16(lit_p + q); lds_s64(lit_base + q, v.a); lds_s64(lit_base + q + 8, v.b); } // (<= 15 bytes past cap: the window's slack)
+            wsync();
+            auto load_rec = [&](uint32_t c0) -> uint64_t { return c0 + sub < nrun ? gu64(seq_g + 8 * (c0 + sub)) : 0ull; };
+            struct StepA { uint32_t ll, ml, w0, lp, op, chunk_l, chunk_t; };
+            auto stage_a = [&](uint64_t rec, StepA& A) {
+                uint32_t ll = (uint32_t)rec & 0x3FFF, ml = ((uint32_t)rec >> 14) & 0x3FFF;
+                const uint32_t ofv = (uint32_t)(rec >> 32);
                 uint32_t il = ll, it = ll + ml;
                 il += seg_shr<1, LPF>(il, sub); it += seg_shr<1, LPF>(it, sub);
                 il += seg_shr<2, LPF>(il, sub); it += seg_shr<2, LPF>(it, sub);
                 if (LPF > 4) { il += seg_shr<4, LPF>(il, sub); it += seg_shr<4, LPF>(it, sub); }
                 if (LPF > 8) { il += seg_shr<8, LPF>(il, sub); it += seg_shr<8, LPF>(it, sub); }
-                const uint32_t lp = lpos + il - ll, op = opos + it - ll - ml; // this sequence's literals / its output
-                if ((lp + ll > nlit) | (op + ll + ml > cap)) pbad = 1;       // literals left, room in the destination (A.5)
-                {
-                    const uint64_t pm = __ballot(pbad != 0);
-                    if ((pm >> (f * LPF)) & ((1ull << LPF) - 1)) { bad = true; ll = 0; ml = 0; w0 = 0; } // (nothing of this step is executed)
-                }
-                // ---- repeat offsets (A.5): every lane its sequence's offset
+                A.lp = lpos + il - ll; A.op = opos + it - ll - ml; // this sequence's literals / its output
+                const uint64_t pm = __ballot((A.lp + ll > nlit) | (A.op + ll + ml > cap)); // literals left, room in the destination (A.5)
+                if ((pm >> (f * LPF)) & ((1ull << LPF) - 1)) { xbad = true; ll = 0; ml = 0; if (!why) why = 7; }
+                if (xbad) { ll = 0; ml = 0; } // (nothing more of this file is executed)
+                A.ll = ll; A.ml = ml;
+                A.w0 = (ll | ml) == 0 ? 0u : (ofv > 3 ? 4u | ((ofv - 3) << 3) : ofv - 1 + (ll == 0 ? 1u : 0u)); // repeat code (0..3; 4 = a new offset) | (offset value - 3) << 3
+                A.chunk_l = bcast<LPF - 1, LPF>(il); A.chunk_t = bcast<LPF - 1, LPF>(it);
+                lpos += A.chunk_l; opos += A.chunk_t;
+            };
+#ifdef MZD_SMALL_STAMPS
+            uint64_t xa_ = 0, xr_ = 0, xl_ = 0, xm_ = 0, xn_ = 0, x0_ = __builtin_readcyclecounter(), x1_ = 0;
+#define XSTAMP(acc) do { x1_ = __builtin_readcyclecounter(); acc += x1_ - x0_; x0_ = x1_; } while (0)
+#else
+#define XSTAMP(acc)
+#endif
+            uint64_t recB = load_rec(LPF);
+            StepA cur;
+            stage_a(load_rec(0), cur);
+            for (uint32_t c0 = 0; c0 < nrun; c0 += LPF) {
+                const uint64_t recC = load_rec(c0 + 2 * LPF);
+                StepA nxt;
+                XSTAMP(xm_);
+                stage_a(recB, nxt);
+                recB = recC;
+                XSTAMP(xa_);
+                // ---- B(c)
+                uint32_t ll = cur.ll, ml = cur.ml;
+                const uint32_t w0 = cur.w0, lp = cur.lp, op = cur.op;
+                // repeat offsets: every lane its sequence's offset
                 const uint32_t c = w0 & 7, pushv = w0 >> 3;
                 uint32_t off;
                 if (__ballot(c == 3) == 0) { // the scan over references
@@ -893,15 +1062,16 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         off = sel(m_eq(sub, K), o, off);
                     });
                 }
+                XSTAMP(xr_);
                 const uint32_t mp = op + ll; // where the match goes
                 {   // offset within the history, and not zero ("rep0 - 1")
                     const uint64_t om = __ballot(ml != 0 && off - 1 >= mp + dict_len);
-                    if ((om >> (f * LPF)) & ((1ull << LPF) - 1)) { bad = true; ll = 0; ml = 0; }
+                    if ((om >> (f * LPF)) & ((1ull << LPF) - 1)) { xbad = true; ll = 0; ml = 0; if (!why) why = 8; }
                 }
-                // ---- the literals: up to 31 bytes per lane in exact pieces; longer runs by the whole wavefront, one after the other.
-                // The window's tail is their source: what a sequence writes ends at or below its own literals' end, so the order is --
-                // every short run is read; the long runs are copied, ascending (none of them reaches the source of a later run);
-                // the short runs are written.  Matches that lie wholly in the dictionary depend on nothing either: requested first.
+                // the literals (<= 31 bytes per lane in exact pieces; longer runs by the file's lanes, a byte each per round) and the
+                // matches that lie wholly in the dictionary (requested first).  The window's tail is the literals' source: what a sequence
+                // writes ends at or below its own literals' end, so the order is -- every short run is read; the long runs are copied,
+                // ascending (none of them reaches the source of a later run); the short runs are written.
                 {
                     bool dfull = false;
                     V16 D0 = {0, 0}, D1 = {0, 0};
@@ -913,15 +1083,16 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     const uint32_t sa = lit_base + lp;
                     const uint64_t A = lds_u64(sa), B = lds_u64(sa + 8), C = lds_u64(sa + 16), D = lds_u64(sa + 24);
                     asm volatile("" ::: "memory");
-                    uint64_t big = __ballot(ll >= 32);
+                    // (this loop runs per file: the lanes of files that are through are not here)
+                    uint32_t big = (uint32_t)(__ballot(ll >= 32) >> (f * LPF)) & ((1u << LPF) - 1);
                     while (big) {
-                        const int bl = __builtin_ctzll(big);
+                        const uint32_t bl4 = ((lane & ~(LPF - 1)) + (uint32_t)__builtin_ctz(big)) * 4;
                         big &= big - 1;
-                        const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)ll, bl), s2 = (uint32_t)__builtin_amdgcn_readlane((int)sa, bl), d2 = (uint32_t)__builtin_amdgcn_readlane((int)(outo + op), bl);
-                        for (uint32_t q = 0; q < n2; q += 64) { // (destination at or below the source: ascending pieces, each read before it is written)
-                            const uint32_t v = L8(s2 + q + lane);
+                        const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bl4, (int)ll), o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bl4, (int)op), s2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bl4, (int)sa);
+                        for (uint32_t q = sub; q < n2 + sub; q += LPF) { // (destination at or below the source: ascending rounds, each read before it is written)
+                            const uint32_t v = L8(s2 + q);
                             asm volatile("" ::: "memory");
-                            if (q + lane < n2) L8(d2 + q + lane) = (uint8_t)v;
+                            if (q < n2) L8(outo + o2 + q) = (uint8_t)v;
                             asm volatile("" ::: "memory");
                         }
                     }
@@ -931,10 +1102,9 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         if (dfull) ml = 0; // done
                     }
                 }
-                const uint32_t chunk_l = bcast<LPF - 1, LPF>(il), chunk_t = bcast<LPF - 1, LPF>(it);
                 wsync();
-                GSTAMP(tp_);
-                // ---- (3) the matches inside the window, in rounds: a lane copies its own match (<= 31 bytes, not overlapping itself) once
+                XSTAMP(xl_);
+                // the matches inside the window, in rounds: a lane copies its own match (<= 31 bytes, not overlapping itself) once
                 // everything below its source's end is final, i.e. once that end is at or below the match of the file's first sequence still
                 // waiting; a first sequence of any other kind -- longer, overlapping, starting in the dictionary -- is executed by the
                 // file's lanes together (its source is complete by then).  The first waiting sequence never waits, so every round ends one.
@@ -947,6 +1117,9 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     for (;;) {
                         const uint64_t pm = __ballot(pending);
                         if (!pm) break;
+#ifdef MZD_SMALL_STAMPS
+                        xn_++;
+#endif
                         const uint32_t seg = (uint32_t)(pm >> (f * LPF)) & ((1u << LPF) - 1);
                         const uint32_t first = seg ? (uint32_t)__builtin_ctz(seg) : 0u;
                         const uint32_t fl4 = (rowbase + first) * 4;
@@ -970,29 +1143,34 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         asm volatile("" ::: "memory");
                     }
                 }
-                lpos += chunk_l; opos += chunk_t;
                 wsync();
+                cur = nxt;
             }
 #ifdef MZD_SMALL_STAMPS
-            if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[10] = tw_; a.stamps[11] = tp_; a.stamps[12] = te_; }
+            if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[18] = xa_; a.stamps[19] = xr_; a.stamps[20] = xl_; a.stamps[21] = xm_; a.stamps[22] = xn_; }
 #endif
-            if (live) {
-                bool good = !bad;
+            // the literals behind the last sequence
+            bool good = !xbad;
+            if (good) {
+                const uint32_t lend = lpos, oend = opos; // (A() ran one step past the end: zero sequences, nothing added)
+                const uint32_t rest = nlit - lend;
+                good = rest <= cap - oend;
                 if (good) {
-                    const uint32_t rest = nlit - lpos;
-                    good = rest <= cap - opos;
-                    if (good) {
-                        for (uint32_t q = sub; q < rest; q += LPF) { const uint32_t v = L8(lit_base + lpos + q); asm volatile("" ::: "memory"); L8(outo + opos + q) = (uint8_t)v; asm volatile("" ::: "memory"); }
-                        opos += rest;
-                        good = !(has_fcs && opos != fcs);
-                        out_len = opos;
+                    for (uint32_t q = sub; q < rest + sub; q += LPF) { // (destination at or below the source: ascending rounds, each read before it is written)
+                        const uint32_t v = L8(lit_base + lend + q);
+                        asm volatile("" ::: "memory");
+                        if (q < rest) L8(outo + oend + q) = (uint8_t)v;
+                        asm volatile("" ::: "memory");
                     }
+                    out_len = oend + rest;
+                    good = !(has_fcs && out_len != fcs);
                 }
-                if (!good) { ok = false; live = false; }
             }
+            if (!good) { ok = false; live = false; if (!why) why = 9; }
         }
         wsync();
-        SSTAMP(7);
+        SSTAMP(17);
+
         // =============================== XXH64 over the window (lane = (file, accumulator))
         {
             uint32_t ck_bad = 0;
@@ -1019,11 +1197,13 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     } else hh = XP5;
                     hh += out_len;
                     hh = xxh_tail(hh, res_off + (out_len / 32) * 32, res_off + out_len);
-                    if ((uint32_t)hh != lds_u32(cmp + n - 4)) ck_bad = 1;
+#ifndef MZD_EXP_NOCK
+                    if ((uint32_t)hh != stored_ck) ck_bad = 1;
+#endif
                 }
             }
             const uint64_t badm = __ballot(ck_bad != 0);
-            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) ok = false;
+            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) { ok = false; if (!why) why = 10; }
         }
         SSTAMP(8);
 
@@ -1055,10 +1235,20 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
         // =============================== results: done here, or handed to the general driver
         if (have && leader) {
             if (ok) { a.jobs[job].out_len = out_len; a.jobs[job].status = MZD_OK; }
-            else { const uint32_t k = atomicAdd(&a.counter[4], 1u); a.redo_list[k] = job; }
+            else {
+                const uint32_t k = atomicAdd(&a.counter[4], 1u); a.redo_list[k] = job;
+#ifdef MZD_SMALL_STAMPS
+                if (a.stamps) { atomicAdd((unsigned long long*)&a.stamps[32 + (why & 15)], 1ull); a.stamps[48 + (why & 15)] = ((uint64_t)fidx << 32) | (uint64_t)(lane | (g << 8));
+                    const unsigned long long kk = atomicAdd((unsigned long long*)&a.stamps[64], 1ull); if (kk < 960) a.stamps[65 + kk] = ((uint64_t)why << 32) | fidx; }
+#endif
+            }
         }
         SSTAMP(9);
         first_group = false;
+        if (!early) { g_next = ticket(); Jn = job_entry(list_entry(g_next)); prefetch(Jn, pfn); } // (wave-uniform)
+        g = g_next; J = Jn;
+#pragma unroll
+        for (int k = 0; k < kPF; k++) pf[k] = pfn[k];
         wsync(); // the slots are rewritten by the next group
     }
 }
@@ -1066,8 +1256,10 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
 } // namespace lw
 
 uint32_t lds_kernel_bytes(int g, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes) {
-    return lw::kShBytes + (with_dict ? lw::kDictImg : 0u) + (uint32_t)g * (tab_bytes + lw::kAux + comp_bytes + out_bytes);
+    const uint32_t ent = tab_bytes + lw::kAux + comp_bytes;
+    return lw::kShBytes + (with_dict ? lw::kDictImg : 0u) + (uint32_t)g * (ent > out_bytes ? ent : out_bytes);
 }
+size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap) { return (size_t)lit_stride + 8u * (size_t)seq_cap; }
 
 void launch_lds(const LdsArgs& a, uint32_t grid, int g, int with_dict, void* stream) {
     const uint32_t bytes = lds_kernel_bytes(g, with_dict, a.tab_bytes, a.comp_bytes, a.out_bytes);

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 import corpus, fuse_zstd_amd as mzd
 import fuse_zstd_amd.api as api
+if os.environ.get('MZD_SO'): api._SO = os.path.join(os.path.dirname(api._SO), os.environ['MZD_SO'])
 
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 mzd.init()
@@ -43,8 +44,9 @@ def run(name, cp, did=0, mode=3, reps=3):
         i = wrong[0]; o, sz = int(cp.raw_offs[i]), int(cp.raw_sizes[i])
         d = np.nonzero(got[o:o + sz] != cp.raw[o:o + sz])[0]
         print("   first wrong files", wrong[:8], "file", i, "size", sz, "first diffs at", d[:10], "ndiff", len(d))
-        print("   got ", bytes(got[o + int(d[0]) - 8:o + int(d[0]) + 24]))
-        print("   want", bytes(cp.raw[o + int(d[0]) - 8:o + int(d[0]) + 24]))
+        print("   got ", bytes(got[o + int(d[0]) - 8:o + int(d[0]) + 40]))
+        print("   want", bytes(cp.raw[o + int(d[0]) - 8:o + int(d[0]) + 40]))
+        print("   all diff positions of this file:", [int(x) for x in d[:64]])
     if badst[:5]: print("   bad status (file, status, len, want):", badst[:8])
     return len(wrong) + len(badst)
 

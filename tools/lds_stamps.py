@@ -27,18 +27,23 @@ jobs = api.make_jobs([comp.data_ptr() + int(o) for o in cp.comp_offs], cp.comp_s
                      [did] * n if did else None)
 torch.cuda.synchronize()
 names = ["take group, job entries, input -> LDS", "headers", "Huffman weights + table", "Huffman streams", "sequence header, counts",
-         "FSE tables", "walk + extract + execute", "XXH64", "flush + results"]
+         "FSE tables", "walk + extract -> scratch", "execute (window)", "XXH64", "flush + results"]
 mzd.set_driver(3)
 for rep in range(3):
     res = mzd.decode_batch_device(0, jobs)
     assert all(st == 0 for st, _ in res)
-    st = (C.c_uint64 * 24)()
+    st = (C.c_uint64 * 1032)()
     api.lib().mzd_debug_small_stamps.argtypes = [C.c_int, C.c_void_p]
     api.lib().mzd_debug_small_stamps(0, st)
     t = list(st)
+    if t[64] and rep == 2:
+        import json
+        json.dump([(x >> 32, x & 0xFFFFFFFF) for x in t[65:65 + min(t[64], 960)]], open("gpurun_out/lds_failed.json", "w"))
+    if any(t[32:48]): print("    left the fast path, by reason 0..15:", t[32:48], "last (file, group<<8|lane):", [(x >> 32, hex(x & 0xFFFFFFFF)) for x in t[48:64] if x])
     if rep == 2:
         print("%s G=%s: kernel %.3f ms; workgroup 0, first group: total %d cycles" % (wl, os.environ.get("MZD_LDS_G", "auto"), mzd.last_kernel_ms(0), t[9] - t[0]))
-        print("    inside: walk %d, extract %d, execute %d cycles" % (t[10], t[11], t[12]))
-        print("    Huffman: counts %d, weights' FSE table %d, weights %d, ranks %d, table fill %d" % (t[13] - t[2], t[14] - t[13], t[15] - t[14], t[16] - t[15], t[3] - t[16]))
-        for k in range(9):
+        print("    inside: walk %d, extract %d cycles" % (t[10], t[11]))
+        print("    execute: stage A %d, repeat offsets %d, literals %d, match rounds %d cycles (%d rounds)" % (t[18], t[19], t[20], t[21], t[22]))
+        t = t[:8] + [t[17]] + t[8:10] + t[10:]  # (the execute stamp was added later: index 17)
+        for k in range(10):
             print("    %-46s %8d cycles" % (names[k], t[k + 1] - t[k]))
