@@ -15,7 +15,7 @@ CONTENTSIZE_ERROR = 2**64 - 2
 
 # every symbol include/mzd.h declares
 EXPORTS = [
-    "mzd_init", "mzd_shutdown", "mzd_device_count", "mzd_content_size", "mzd_decode", "mzd_decode_batch",
+    "mzd_init", "mzd_init_ex", "mzd_shutdown", "mzd_device_count", "mzd_content_size", "mzd_decode", "mzd_decode_batch",
     "mzd_decode_batch_device", "mzd_batch_prepare", "mzd_batch_launch", "mzd_batch_collect", "mzd_batch_free",
     "mzd_load_dict", "mzd_unload_dict", "mzd_debug_last_block", "mzd_debug_set_driver", "mzd_debug_counters", "mzd_debug_host_path", "mzd_debug_stamps", "mzd_debug_small_stamps", "mzd_debug_tfin_all",
     "mzd_host_alloc", "mzd_host_free", "mzd_last_kernel_ms", "mzd_strerror", "mzd_version",
@@ -134,13 +134,22 @@ def strerror(code):
         return "error %d" % code
 
 
-def init(device_ids=None):
+class Config(C.Structure):  # mzd_config
+    _fields_ = [("struct_size", C.c_size_t), ("device_ids", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("max_workgroups", C.c_uint32),
+                ("small_scratch_bytes", C.c_size_t), ("resolve_ahead", C.c_int)]
+
+
+def init(device_ids=None, max_workgroups=0, small_scratch_bytes=0, resolve_ahead=True):
+    """mzd_init; with any of the keyword arguments, mzd_init_ex (per-device memory spelled out).  An ordinal may be listed
+    more than once: every entry is a device of its own to the library."""
     L = lib()
-    if device_ids:
-        arr = (C.c_int * len(device_ids))(*device_ids)
-        rc = L.mzd_init(arr, len(device_ids))
+    arr = (C.c_int * len(device_ids))(*device_ids) if device_ids else None
+    if max_workgroups or small_scratch_bytes or not resolve_ahead:
+        cfg = Config(C.sizeof(Config), arr, len(device_ids) if device_ids else 0, max_workgroups, small_scratch_bytes, 1 if resolve_ahead else 0)
+        L.mzd_init_ex.argtypes = [C.POINTER(Config)]
+        rc = L.mzd_init_ex(C.byref(cfg))
     else:
-        rc = L.mzd_init(None, 0)
+        rc = L.mzd_init(arr, len(device_ids) if device_ids else 0)
     if rc != OK:
         raise MzdError(rc, "mzd_init")
 

@@ -89,7 +89,8 @@ struct Device {
     uint4* seq_scratch = nullptr;
     uint4* walk_scratch = nullptr;
     uint8_t* small_lit = nullptr;
-    uint32_t* resolve_map = nullptr; // kResMapStride words per workgroup slot (mzd_k_resolve.h)
+    size_t small_lit_total = 0;
+    uint32_t* resolve_map = nullptr; // kResMapStride words per workgroup slot (mzd_k_resolve.h); null: blocks are never resolved ahead (mzd_config::resolve_ahead)
     DebugSlot* debug = nullptr;
     uint32_t* counters = nullptr; // 2 x (kSlots + 1) blocks of kCounterWords
     Lane lane[kSlots];
@@ -142,7 +143,9 @@ void free_device(Device& d) {
     if (d.copy_out) hipStreamDestroy(d.copy_out);
 }
 
-int init_device(Device& d, int hip_id, int index) {
+struct InitCfg { uint32_t max_workgroups = 0; size_t small_scratch_bytes = 0; bool resolve_ahead = true; };
+
+int init_device(Device& d, int hip_id, int index, const InitCfg& cfg) {
     d.hip_id = hip_id; d.index = index;
     HIPCHK(hipSetDevice(hip_id));
     int cus = 0, per_cu = 0, per_cu2 = 0;
@@ -154,11 +157,13 @@ int init_device(Device& d, int hip_id, int index) {
     if (per_cu > 8) per_cu = 8;
     d.cus = (uint32_t)cus;
     d.max_wg = (uint32_t)(cus * per_cu);
+    if (cfg.max_workgroups) d.max_wg = std::max<uint32_t>(4u * kSlots, std::min<uint32_t>(d.max_wg, cfg.max_workgroups)) / kSlots * kSlots;
+    d.small_lit_total = std::max<size_t>(16u << 20, cfg.small_scratch_bytes ? cfg.small_scratch_bytes : kSmallLitBytes) / (kSlots * kAlign) * (kSlots * kAlign);
     HIPCHK(hipMalloc(&d.lit_scratch, (size_t)d.max_wg * kLitStride));
     HIPCHK(hipMalloc(&d.seq_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
     HIPCHK(hipMalloc(&d.walk_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
-    HIPCHK(hipMalloc(&d.small_lit, kSmallLitBytes));
-    HIPCHK(hipMalloc(&d.resolve_map, (size_t)d.max_wg * kResMapStride * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d.small_lit, d.small_lit_total));
+    if (cfg.resolve_ahead) HIPCHK(hipMalloc(&d.resolve_map, (size_t)d.max_wg * kResMapStride * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&d.debug, (size_t)d.max_wg * sizeof(DebugSlot)));
     HIPCHK(hipMemset(d.debug, 0, (size_t)d.max_wg * sizeof(DebugSlot)));
     HIPCHK(hipMalloc(&d.counters, 2 * (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
@@ -171,7 +176,7 @@ int init_device(Device& d, int hip_id, int index) {
         HIPCHK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         l.cnt[0] = d.counters + (size_t)(2 * k) * kCounterWords; l.cnt[1] = l.cnt[0] + kCounterWords; l.counter = l.cnt[0];
         l.wg0 = (uint32_t)k * share; l.nwg = share;
-        l.small_lit = d.small_lit + (size_t)k * (kSmallLitBytes / kSlots); l.small_lit_bytes = kSmallLitBytes / kSlots;
+        l.small_lit = d.small_lit + (size_t)k * (d.small_lit_total / kSlots); l.small_lit_bytes = d.small_lit_total / kSlots;
         HIPCHK(hipEventCreate(&l.ev0));
         HIPCHK(hipEventCreate(&l.ev1));
     }
@@ -180,7 +185,7 @@ int init_device(Device& d, int hip_id, int index) {
     Lane& w = d.whole;
     w.stream = d.lane[0].stream;
     w.cnt[0] = d.counters + (size_t)(2 * kSlots) * kCounterWords; w.cnt[1] = w.cnt[0] + kCounterWords; w.counter = w.cnt[0];
-    w.wg0 = 0; w.nwg = d.max_wg; w.small_lit = d.small_lit; w.small_lit_bytes = kSmallLitBytes;
+    w.wg0 = 0; w.nwg = d.max_wg; w.small_lit = d.small_lit; w.small_lit_bytes = d.small_lit_total;
     HIPCHK(hipEventCreate(&w.ev0));
     HIPCHK(hipEventCreate(&w.ev1));
     return MZD_OK;
@@ -269,12 +274,13 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
     bool all_dict = true;
     uint64_t tasks = 0;
     size_t maxcap = 0;
-    // The lane-per-file kernel pays off from a few thousand small files on (its launch lasts ~0.6 ms however few they are,
-    // and runs before the general driver); fewer of them fill the general driver's idle workgroup slots for less
-    // (measured on the log-uniform mix cfg4lu, 13 % small files: 12.8 ms without it against 14.1 ms with it)
+    // The small-file kernel pays off from about two thousand small files on: its launch lasts as long as one group of files
+    // (~0.25 ms for 4 KiB files) however few they are, and runs before the general driver, while fewer files fill the general
+    // driver's idle workgroup slots for less (profiles/r03_small_policy.txt: 4 KiB files, general driver / small-file kernel:
+    // 1 024 files 0.15 / 0.23 ms, 2 048 0.26 / 0.25, 4 096 0.46 / 0.29, 10 000 1.04 / 0.57; 512-byte files cross at 1 024)
     size_t eligible = 0, maxsrc = 0;
     for (size_t i = 0; i < njobs; i++) eligible += jobs[i].dst_cap <= kSmallCap && jobs[i].src_len <= kSmallSrcMax;
-    const bool small_ok = force == 3 || force == 6 || (force == 0 && eligible >= 8ull * max_wg); // (3, 6: whenever a file is eligible -- tests)
+    const bool small_ok = force == 3 || force == 6 || (force == 0 && eligible >= 2ull * max_wg); // (3, 6: whenever a file is eligible -- tests)
     for (size_t i = 0; i < njobs; i++) {
         const DevJob& j = jobs[i];
         const bool is_small = small_ok && j.dst_cap <= kSmallCap && j.src_len <= kSmallSrcMax;
@@ -356,7 +362,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     // 1: every task after a file's first resolves ahead (up to ~8 blocks per workgroup slot -- the measured crossover on cfg4lu --
     // or a few very big files, which are chains however many blocks they have); 2: only tasks whose predecessor is still
     // running when they start (launches with more tasks than that)
-    ka.resolve = !use_tasks || force == 5 ? 0u : ((force == 4 || p.blocks <= 8ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : 2u);
+    ka.resolve = !use_tasks || force == 5 || !d.resolve_map ? 0u : ((force == 4 || p.blocks <= 8ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : 2u);
     HIPCHK(hipEventRecord(ev0, s));
     uint32_t grid;
     if (p.nsmall && p.lds_kernel) {
@@ -831,30 +837,41 @@ struct mzd_batch {
 
 extern "C" {
 
-int mzd_init(const int* device_ids, int n) {
-    // The host path keeps kSlots kernel streams and two copy streams busy at once: ask the HIP runtime for enough hardware
-    // queues (its default, 4, makes streams share queues, i.e. serialises them).  Only effective before the runtime starts;
-    // a process that has used HIP already sets GPU_MAX_HW_QUEUES itself (bench.py does).
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+int mzd_init_ex(const mzd_config* cfg) {
+    if (!cfg || cfg->struct_size < offsetof(mzd_config, max_workgroups)) return MZD_E_PARAM;
+    auto has = [&](size_t off, size_t sz) { return cfg->struct_size >= off + sz; };
+    InitCfg ic;
+    if (has(offsetof(mzd_config, max_workgroups), sizeof(uint32_t))) ic.max_workgroups = cfg->max_workgroups;
+    if (has(offsetof(mzd_config, small_scratch_bytes), sizeof(size_t))) ic.small_scratch_bytes = cfg->small_scratch_bytes;
+    if (has(offsetof(mzd_config, resolve_ahead), sizeof(int))) ic.resolve_ahead = cfg->resolve_ahead != 0;
+    // (nothing here touches the environment: the number of hardware queues the HIP runtime maps streams onto, GPU_MAX_HW_QUEUES,
+    //  is the application's to set before its first HIP call -- include/mzd.h)
     std::vector<std::shared_ptr<Device>> old;
     { std::lock_guard<std::mutex> lk(g_mu); old.swap(g_dev); }
     drop_devices(old); // (calls in flight on the old devices finish first)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MZD_E_DEVICE;
     std::vector<int> ids;
-    if (!device_ids || n <= 0) ids.push_back(0);
-    else ids.assign(device_ids, device_ids + n);
+    if (!cfg->device_ids || cfg->n_devices <= 0) ids.push_back(0);
+    else ids.assign(cfg->device_ids, cfg->device_ids + cfg->n_devices);
     std::vector<std::shared_ptr<Device>> fresh;
     for (int id : ids) {
         if (id < 0 || id >= count) { for (auto& d : fresh) free_device(*d); return MZD_E_PARAM; }
         auto d = std::make_shared<Device>();
-        int rc = init_device(*d, id, (int)fresh.size());
+        int rc = init_device(*d, id, (int)fresh.size(), ic);
         if (rc) { free_device(*d); for (auto& e : fresh) free_device(*e); return rc; }
         fresh.push_back(std::move(d));
     }
     std::lock_guard<std::mutex> lk(g_mu);
     g_dev = std::move(fresh);
     return MZD_OK;
+}
+
+int mzd_init(const int* device_ids, int n) {
+    mzd_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = sizeof(cfg); cfg.device_ids = device_ids; cfg.n_devices = n; cfg.resolve_ahead = 1;
+    return mzd_init_ex(&cfg);
 }
 
 void mzd_shutdown(void) {
@@ -1086,7 +1103,7 @@ int mzd_unload_dict(uint32_t dict_id) {
 }
 
 int mzd_debug_set_driver(int driver) {
-    if (driver < 0 || driver > 5) return MZD_E_PARAM;
+    if (driver < 0 || driver > 6) return MZD_E_PARAM; // (6: the round-2 lane-per-file kernel instead of the LDS kernel -- measurements only)
     g_force_driver.store(driver, std::memory_order_relaxed);
     return MZD_OK;
 }

@@ -67,6 +67,26 @@ typedef struct mzd_job {
  * Allocates per-device scratch (literal + sequence buffers for every resident workgroup).
  * Calling it again re-initialises.  Returns MZD_OK or MZD_E_DEVICE. */
 int mzd_init(const int* device_ids, int n);
+
+/* The same with the per-device memory spelled out (mzd_init uses the defaults: about 2.3 GB per device).  Nothing here or in
+ * mzd_init touches the process environment.  The host path keeps four kernel streams and two copy streams busy per device;
+ * the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the runtime starts: a
+ * process that wants them all concurrent exports GPU_MAX_HW_QUEUES=8 itself before its first HIP call (bench.py and
+ * INTEGRATION.md's daemon patch do; with the default the streams share queues -- correct, a few percent slower end to end).
+ * Unknown trailing fields are ignored: set struct_size = sizeof(mzd_config). */
+typedef struct mzd_config {
+    size_t struct_size;
+    const int* device_ids;        /* HIP ordinals; NULL / 0 -> device 0 only.  An ordinal may appear more than once:
+                                     each entry is a device of its own to the library (tests of the N-device path on one card) */
+    int n_devices;
+    uint32_t max_workgroups;      /* resident workgroups the general drivers may use per device (0: all the device holds,
+                                     1 024 on MI355X).  Their scratch is 1.6 MB each: literals, walk records, plan */
+    size_t small_scratch_bytes;   /* scratch of the small-file kernel per device: literals + sequences of every resident
+                                     small file (0: 512 MiB; at least 16 MiB) */
+    int resolve_ahead;            /* 1 (default when struct_size does not reach it): byte maps for blocks resolved ahead of
+                                     their predecessors (0.5 MB per resident workgroup); 0: none, blocks copy in order */
+} mzd_config;
+int mzd_init_ex(const mzd_config* cfg);
 void mzd_shutdown(void);
 int mzd_device_count(void); /* devices initialised by mzd_init (0 before) */
 

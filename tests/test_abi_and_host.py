@@ -100,3 +100,36 @@ def test_product_never_links_the_oracle():
     for f in ("api.py", "__init__.py"):
         text = open(os.path.join(ROOT, "fuse_zstd_amd", f)).read()
         assert "import oracle" not in text and "from oracle" not in text
+
+
+def test_init_does_not_touch_the_environment():
+    """The library leaves the process environment alone (round 2's mzd_init exported GPU_MAX_HW_QUEUES: a side effect on the host
+    application that only worked if HIP had not started).  Checked in a fresh process through ctypes, without the Python wrapper:
+    mzd_init and mzd_init_ex -- which fail with MZD_E_DEVICE here, there is no GPU -- leave os.environ as it was."""
+    import subprocess, sys
+    code = r"""
+import ctypes as C, os, sys
+before = dict(os.environ)
+L = C.CDLL(sys.argv[1])
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_size_t), ("device_ids", C.POINTER(C.c_int)), ("n_devices", C.c_int), ("max_workgroups", C.c_uint32),
+                ("small_scratch_bytes", C.c_size_t), ("resolve_ahead", C.c_int)]
+rc1 = L.mzd_init(None, 0)
+cfg = Config(C.sizeof(Config), None, 0, 128, 64 << 20, 0)
+rc2 = L.mzd_init_ex(C.byref(cfg))
+bad = Config(4, None, 0, 0, 0, 0)
+rc3 = L.mzd_init_ex(C.byref(bad))
+# the C runtime's view, not Python's cached os.environ
+libc = C.CDLL(None); libc.getenv.restype = C.c_char_p
+q = libc.getenv(b"GPU_MAX_HW_QUEUES")
+print(rc1, rc2, rc3, q, dict(os.environ) == before)
+"""
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code, mzd.api._SO], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rc1, rc2, rc3, q, same = out.stdout.split()
+    import torch
+    if not torch.cuda.is_available():
+        assert int(rc1) == mzd.E_DEVICE and int(rc2) == mzd.E_DEVICE
+    assert int(rc3) == mzd.E_PARAM      # a struct too short to hold the device list
+    assert q == "None" and same == "True"

@@ -267,6 +267,82 @@ def test_multi_gpu_product_path_round_robin():
 
 
 @needs_zstd
+def test_two_devices_on_one_card_round_robin_dictionaries_and_concurrent_callers():
+    """SURVEY.md 8(e) on the hardware this pool has: mzd_init([0, 0]) makes two devices of ordinal 0 -- each with its own streams,
+    scratch, dictionary tables and host thread -- so the N > 1 branch of mzd_decode_batch (deal job i to device i mod N, a thread
+    per device), mzd_load_dict over several devices and mzd_job.device all run on one GPU: 2 000 dictionary records and six
+    multi-block files, bytes exact, device == i mod 2, then two callers at once."""
+    import threading
+    mzd.shutdown()
+    mzd.init([0, 0])
+    try:
+        assert mzd.device_count() == 2
+        sizes = [int(x) for x in np.random.RandomState(55).randint(300, 3001, size=2000)]
+        d = corpus.train_dict("json", 5, sizes[:1000], cap=60000)
+        h = mzd.load_dict(d)  # on both devices
+        cp = corpus.build_corpus("json", 5, sizes, dictionary=d)
+        L = mzd.api.lib()
+
+        def run_dict_batch():
+            out = np.zeros(int(cp.raw_offs[-1] + cp.raw_sizes[-1]) + 64, dtype=np.uint8)
+            jobs = mzd.api.make_jobs([cp.comp.ctypes.data + int(o) for o in cp.comp_offs], cp.comp_sizes,
+                                     [out.ctypes.data + int(o) for o in cp.raw_offs], cp.raw_sizes, [h] * cp.nfiles)
+            assert L.mzd_decode_batch(jobs, cp.nfiles) == 0
+            for i, j in enumerate(jobs):
+                assert j.status == 0 and j.out_len == sizes[i] and j.device == i % 2, (i, j.status, j.device)
+                o = int(cp.raw_offs[i])
+                assert out[o:o + sizes[i]].tobytes() == cp.raw_file(i).tobytes(), i
+
+        run_dict_batch()
+        # multi-block files: block tasks on both devices
+        cp2 = corpus.build_corpus("json", 7, [300000, 131072, 1 << 20, 4096, 700000, 70000])
+        srcs2 = [cp2.comp_file(i).tobytes() for i in range(cp2.nfiles)]
+
+        def run_big_batch():
+            res = mzd.decode_batch(srcs2, [int(s) for s in cp2.raw_sizes])
+            for i, (st, o) in enumerate(res):
+                assert st == 0 and o == cp2.raw_file(i).tobytes(), i
+
+        run_big_batch()
+        # two callers at once, each over both devices
+        errs = []
+
+        def guarded(fn):
+            try:
+                fn()
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+        ts = [threading.Thread(target=guarded, args=(run_dict_batch,)), threading.Thread(target=guarded, args=(run_big_batch,))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        mzd.unload_dict(h)
+    finally:
+        mzd.shutdown()
+        mzd.init()
+
+
+@needs_zstd
+def test_init_ex_sizes_the_device_memory():
+    """mzd_init_ex (include/mzd.h: mzd_config): fewer resident workgroups, a small scratch for the small-file kernel and no byte
+    maps -- a small-memory configuration -- still decodes every kind of launch byte-exactly (small files in several waves of
+    groups, multi-block files copied in order)."""
+    mzd.shutdown()
+    mzd.init([0], max_workgroups=256, small_scratch_bytes=32 << 20, resolve_ahead=False)
+    try:
+        cp = corpus.build_corpus("json", 4, [4096] * 6000)
+        res, got, end = _device_resident(cp)
+        _check_corpus(cp, res, got, end, sample=40)
+        cp2 = corpus.build_corpus("json", 7, [300000, 131072, 1 << 20, 4096, 700000, 70000] * 4)
+        res = mzd.decode_batch([cp2.comp_file(i).tobytes() for i in range(cp2.nfiles)], [int(s) for s in cp2.raw_sizes])
+        for i, (st, o) in enumerate(res):
+            assert st == 0 and o == cp2.raw_file(i).tobytes(), i
+    finally:
+        mzd.shutdown()
+        mzd.init()
+
+
+@needs_zstd
 def test_lazy_open_decodes_only_what_reads_need():
     """mzd_fs_open_lazy decodes nothing; a read decodes the frames that cover its range and, inside a
     multi-block frame, only the blocks up to the range's end.  Bytes equal the oracle's; the decoded-bytes counter stays
