@@ -145,13 +145,24 @@ __device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want, int32_
 }
 
 
-// wave-wide inclusive scans on the DPP path (row_shr / row_bcast: no LDS traffic, no ds_bpermute latency)
+// wave-wide inclusive scans, hand-written on the DPP path (no LDS traffic, no ds_bpermute latency): Hillis-Steele inside a row
+// of 16 lanes (row_shr 1, 2, 4, 8: a lane whose source lies outside its row keeps the identity), then a row's total into the row
+// above it (row_bcast:15 into rows 1 and 3) and the lower half's total into the upper half (row_bcast:31 into rows 2 and 3).
+// op(earlier, later); `ident` is op's identity.
+template <int CTRL, int ROWMASK> __device__ __forceinline__ uint32_t dpp_take(uint32_t ident, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+template <class Op> __device__ __forceinline__ uint32_t wave_incl_scan_op(uint32_t v, uint32_t ident, Op op) {
+    v = op(dpp_take<0x111, 0xF>(ident, v), v);
+    v = op(dpp_take<0x112, 0xF>(ident, v), v);
+    v = op(dpp_take<0x114, 0xF>(ident, v), v);
+    v = op(dpp_take<0x118, 0xF>(ident, v), v);
+    v = op(dpp_take<0x142, 0xA>(ident, v), v);
+    v = op(dpp_take<0x143, 0xC>(ident, v), v);
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     (void)lane;
-    using WS = rocprim::warp_scan<uint32_t, 64>;
-    WS::storage_type* st = nullptr; // the DPP implementation keeps no state in LDS
-    uint32_t r;
-    WS().inclusive_scan(v, r, *st, rocprim::plus<uint32_t>());
-    return r;
+    return wave_incl_scan_op(v, 0u, [](uint32_t a, uint32_t b) { return a + b; });
 }
 

@@ -210,11 +210,22 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
             else if (idx == 1) { op.s = 1 | (0 << 2) | (2 << 4); op.v0 = 0; op.v1 = 0; op.v2 = 0; }
             else if (idx == 2) { op.s = 2 | (0 << 2) | (1 << 4); op.v0 = 0; op.v1 = 0; op.v2 = 0; }
             else { op.s = 0 | (0 << 2) | (1 << 4); op.v0 = -1; op.v1 = 0; op.v2 = 0; }
-            RepOp acc; // inclusive scan: acc = op_lane o ... o op_0 (DPP path)
+            RepOp acc = op; // inclusive scan: acc = op_lane o ... o op_0 (the DPP steps of wave_incl_scan_op, four words at a time)
             {
-                using WR = rocprim::warp_scan<RepOp, 64>;
-                WR::storage_type* st = nullptr;
-                WR().inclusive_scan(op, acc, *st, [](const RepOp& earlier, const RepOp& later) { return rep_compose(later, earlier); });
+                constexpr uint32_t kIdS = 0u | (1u << 2) | (2u << 4); // the identity: every slot is itself
+                auto step = [&](auto ctrl_c, auto rows_c) {
+                    constexpr int CTRL = decltype(ctrl_c)::value, ROWS = decltype(rows_c)::value;
+                    RepOp e;
+                    e.s = dpp_take<CTRL, ROWS>(kIdS, acc.s);
+                    e.v0 = (int32_t)dpp_take<CTRL, ROWS>(0u, (uint32_t)acc.v0); e.v1 = (int32_t)dpp_take<CTRL, ROWS>(0u, (uint32_t)acc.v1); e.v2 = (int32_t)dpp_take<CTRL, ROWS>(0u, (uint32_t)acc.v2);
+                    acc = rep_compose(acc, e);
+                };
+                step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xF>{});
+                step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xF>{});
+                step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xF>{});
+                step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xF>{});
+                step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});
+                step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});
             }
             RepOp before; // exclusive
             before.s = __shfl_up(acc.s, 1); before.v0 = __shfl_up(acc.v0, 1); before.v1 = __shfl_up(acc.v1, 1); before.v2 = __shfl_up(acc.v2, 1);

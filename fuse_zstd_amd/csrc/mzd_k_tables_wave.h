@@ -4,11 +4,7 @@
 // ------------------------------------------------------------------------------------ K3 (wave-parallel)
 __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, int lane) {
     (void)lane;
-    using WS = rocprim::warp_scan<uint32_t, 64>;
-    WS::storage_type* st = nullptr;
-    uint32_t r;
-    WS().inclusive_scan(v, r, *st, rocprim::maximum<uint32_t>());
-    return r;
+    return wave_incl_scan_op(v, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
 }
 
 // FSE decode table (A.3) built by the 64 lanes of one wavefront; same result as build_seq_table.

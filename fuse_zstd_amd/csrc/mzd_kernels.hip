@@ -30,7 +30,7 @@
 #include <cstring>
 #include <type_traits>
 
-#include <rocprim/warp/warp_scan.hpp>
+#include <type_traits>
 
 #include "../../include/mzd.h"
 #include "mzd_device.h"

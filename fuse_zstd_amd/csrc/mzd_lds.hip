@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     V16 D0 = {0, 0}, D1 = {0, 0};
                     if (DICT) {
                         dfull = ml != 0 && ml < 32 && off > mp && off - mp >= ml;
-                        const uint8_t* dp = dfull ? dict_end - (off - mp) : dict_end; // (dictionary buffers are readable 32 bytes past their end)
+                        const uint8_t* dp = dfull ? dict_end - (off - mp) : seq_g; // (dictionary buffers are readable 32 bytes past their end; a lane without such a match reads anything readable)
                         D0 = gv16(dp); D1 = gv16(dp + 16);
                     }
                     const uint32_t sa = lit_base + lp;
