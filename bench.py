@@ -53,14 +53,18 @@ WORKLOADS = {
     "cfg4": ("json", 4, 0, "4 KiB JSON files, parallel-files.fio shape (BASELINE configs[3])"),
     "cfg4lu": ("json", 4, 0, "JSON files log-uniform 4 KiB..1 MiB (BASELINE configs[3] variant)"),
     "cfg5": ("json", 5, 0, "JSON records of 300..3000 B, one shared ZDICT-trained dictionary (BASELINE configs[4]; 50 000 files per GPU by default)"),
+    # the same generators with enough files to fill the machine several times over: the sustained rate of the kernel, where the
+    # headline configurations measure one launch's latency (1 000 files on 1 024 workgroup slots; 10 000 small files: two rounds of groups)
+    "cfg2x8": ("json", 2, 0, "8 000 x 128 KiB single-block JSON frames (cfg2's generator, eight times the files: the sustained single-block rate)"),
+    "cfg4x4": ("json", 4, 0, "40 000 x 4 KiB JSON files (cfg4's generator, four times the files: the sustained small-file rate)"),
 }
-DEFAULT_FILES = {"cfg2": 1000, "cfg3": 1000, "cfg4": 10000, "cfg4lu": 10000, "cfg5": 50000}
+DEFAULT_FILES = {"cfg2": 1000, "cfg3": 1000, "cfg4": 10000, "cfg4lu": 10000, "cfg5": 50000, "cfg2x8": 8000, "cfg4x4": 40000}
 
 
 def file_sizes(workload, nfiles, rank, world):
-    if workload in ("cfg2", "cfg3"):
+    if workload in ("cfg2", "cfg3", "cfg2x8"):
         return [131072] * nfiles
-    if workload == "cfg4":
+    if workload in ("cfg4", "cfg4x4"):
         return [4096] * nfiles
     if workload == "cfg5":
         rng = np.random.RandomState(55)
@@ -211,6 +215,8 @@ def cpu_baseline_dict(cp, dictionary, budget_s=10.0):
 
 
 def recorded_traffic(workload):
+    """HBM bytes per step from the last committed counter passes (tools/rocprof.sh; not measured in this run: the PMC passes need
+    rocprofv3 around the process).  profiles/pmc_traffic.json carries the commit and date they were taken at ("_recorded_at")."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         return json.load(open(p)).get(workload)
@@ -218,11 +224,19 @@ def recorded_traffic(workload):
         return None
 
 
+def traffic_recorded_at():
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(p)).get("_recorded_at")
+    except (OSError, ValueError):
+        return None
+
+
 def kernel_name(cp):
     """The dominant kernel of a launch over this corpus (mzd_host.cpp: make_plan)."""
     mx = int(cp.raw_sizes.max())
-    if int((cp.raw_sizes <= 8192).sum()) >= 8192 and mx <= 8192:  # (fewer small files than that go to a general driver)
-        return "mzd_small_kernel"
+    if int((cp.raw_sizes <= 8192).sum()) >= 2048 and mx <= 8192:  # (fewer small files than that go to a general driver)
+        return "mzd_lds_kernel"
     return "mzd_decode_kernel_tasks" if mx > 131072 else "mzd_decode_kernel_files"
 
 
@@ -500,7 +514,7 @@ def main():
             "verified_byte_exact": True,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
-                         "traffic": recorded_traffic(args.workload),
+                         "traffic": recorded_traffic(args.workload), "traffic_recorded_at": traffic_recorded_at(),
                          "kernel": kernel_name(w.cp), "kernel_ms_avg": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": w.C + w.U},
         }
@@ -518,11 +532,11 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_others:
             others = {}
-            for name in ("cfg3", "cfg4", "cfg4lu", "cfg5"):
+            for name in ("cfg3", "cfg4", "cfg4lu", "cfg5", "cfg2x8", "cfg4x4"):
                 if name == args.workload:
                     continue
                 ow = Workload(name, DEFAULT_FILES[name], 0, 1, args.level, dev, mzd, corpus)
-                steps = 10 if name != "cfg4lu" else 6
+                steps = 10 if name not in ("cfg4lu", "cfg2x8") else 6
                 el, kms = time_t1(ow, steps, 2, stream, local_fence)
                 ach = (ow.C + ow.U) / (kms * 1e-3) / 1e9
                 others[name] = {"workload": ow.desc, "files": ow.nfiles, "value": round(ow.U * steps / el / GIB, 3), "unit": "GiB/s",

@@ -108,7 +108,12 @@ private:
                 cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
                 if (stop_ && q_.empty()) return;
                 // one request is here: give the other session threads a moment to add theirs
+#ifdef __SANITIZE_THREAD__ // (GCC 11's ThreadSanitizer does not know pthread_cond_clockwait, which a steady_clock deadline uses: it
+                           //  would take the mutex for held across the wait and report double locks that are not there)
+                auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(wait_us_);
+#else
                 auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us_);
+#endif
                 while ((int)q_.size() < max_ && !stop_ && cv_.wait_until(lk, deadline) != std::cv_status::timeout) {}
                 size_t n = std::min<size_t>(q_.size(), (size_t)max_);
                 batch.assign(q_.begin(), q_.begin() + (long)n);
@@ -129,7 +134,9 @@ private:
             uint64_t want = mzd_content_size(it.src.data(), it.src.size());
             if (want == MZD_CONTENTSIZE_ERROR) { it.out->status = MZD_E_CORRUPT; skip[i] = true; continue; } // not a zstd file
             if (want == MZD_CONTENTSIZE_UNKNOWN) { later.push_back(i); skip[i] = true; continue; }
-            it.out->bytes.resize((size_t)want);
+            // (a header may promise anything: what the file's bytes can regenerate is bounded -- a block gives <= 128 KiB and costs >= 4 bytes)
+            if (want > ((uint64_t)it.src.size() / 4 + 1) * (128u << 10)) { it.out->status = MZD_E_CORRUPT; skip[i] = true; continue; }
+            try { it.out->bytes.resize((size_t)want); } catch (const std::exception&) { it.out->status = MZD_E_DEVICE; skip[i] = true; continue; }
             jobs[i].src = it.src.data(); jobs[i].src_len = it.src.size();
             jobs[i].dst = it.out->bytes.data(); jobs[i].dst_cap = it.out->bytes.size();
         }
@@ -149,11 +156,12 @@ private:
         for (size_t i : later) {
             auto& it = *batch[i];
             size_t cap = std::max<size_t>(it.src.size() * 8, 1u << 20);
+            const uint64_t cap_max = ((uint64_t)it.src.size() / 4 + 1) * (128u << 10);
             for (;;) {
-                it.out->bytes.resize(cap);
+                try { it.out->bytes.resize(cap); } catch (const std::exception&) { it.out->status = MZD_E_DEVICE; it.out->bytes.clear(); break; }
                 size_t n = 0;
                 int rc = mzd_decode(it.src.data(), it.src.size(), it.out->bytes.data(), cap, &n);
-                if (rc == MZD_E_DSTSIZE && cap < ((size_t)1 << 40)) { cap *= 4; continue; }
+                if (rc == MZD_E_DSTSIZE && cap < cap_max) { cap = (size_t)std::min<uint64_t>((uint64_t)cap * 4, cap_max); continue; }
                 it.out->status = rc;
                 it.out->bytes.resize(rc == MZD_OK ? n : 0);
                 if (rc == MZD_OK) files_++;
@@ -388,7 +396,8 @@ public:
         while (!done_) {
             ssize_t n = ::read(fd_, buf.data(), buf.size());
             if (n < 0 && (errno == EINTR || errno == EAGAIN || errno == ENOENT)) continue;
-            if (n < (ssize_t)sizeof(fuse_in_header)) break; // unmounted / peer closed
+            if (n <= 0) break; // unmounted / peer closed
+            if (n < (ssize_t)sizeof(fuse_in_header)) continue; // (not a request: nothing to answer)
             dispatch(buf.data(), (size_t)n);
         }
         done_ = true;
@@ -413,9 +422,24 @@ private:
         const fuse_in_header* in = reinterpret_cast<const fuse_in_header*>(p);
         const uint8_t* arg = p + sizeof(*in);
         const size_t alen = n - sizeof(*in);
+        // the fixed part of a request's body must be there (what arrived counts, not what the header claims)
+        size_t need = 0;
+        switch (in->opcode) {
+        case FUSE_INIT: need = 8; break; // major, minor (7.5 and older send no more)
+        case FUSE_GETATTR: need = 0; break; // (the body is optional before 7.9 and unused here)
+        case FUSE_OPEN: case FUSE_OPENDIR: need = sizeof(fuse_open_in); break;
+        case FUSE_READ: case FUSE_READDIR: need = offsetof(fuse_read_in, read_flags); break; // fh, offset, size (7.8 and older end there)
+        case FUSE_RELEASE: need = sizeof(uint64_t); break; // fh
+        case FUSE_LOOKUP: need = 1; break;
+        default: break;
+        }
+        if (alen < need) { reply(in->unique, EINVAL); return; }
         switch (in->opcode) {
         case FUSE_INIT: {
-            const fuse_init_in* ii = reinterpret_cast<const fuse_init_in*>(arg);
+            fuse_init_in iibuf;
+            memset(&iibuf, 0, sizeof(iibuf));
+            memcpy(&iibuf, arg, std::min(alen, sizeof(iibuf)));
+            const fuse_init_in* ii = &iibuf;
             fuse_init_out o;
             memset(&o, 0, sizeof(o));
             o.major = FUSE_KERNEL_VERSION;

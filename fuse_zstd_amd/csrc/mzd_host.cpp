@@ -1265,6 +1265,10 @@ extern "C" {
 mzd_fs* mzd_fs_new(void) { return new mzd_fs(); }
 void mzd_fs_free(mzd_fs* fs) { delete fs; }
 
+// What n bytes of frames can regenerate at most: every block regenerates <= 128 KiB and costs >= 4 bytes (header + an RLE byte).
+// Content sizes come from untrusted headers and size allocations: one above this bound is refused before anything is allocated.
+static uint64_t max_regenerated(size_t n) { return ((uint64_t)n / 4 + 1) * kBlockMax; }
+
 int64_t mzd_fs_open(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t* zst, size_t zst_len, uint64_t* real_size) {
     if (!fs) return -EINVAL;
     std::lock_guard<std::mutex> lk(fs->mu);
@@ -1283,9 +1287,10 @@ int64_t mzd_fs_open(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t* zst,
     auto file = std::make_shared<DecodedFile>();
     uint64_t want = mzd_content_size(zst, zst_len);
     if (want == MZD_CONTENTSIZE_ERROR) return -EFAULT;
+    if (want != MZD_CONTENTSIZE_UNKNOWN && want > max_regenerated(zst_len)) return -EFAULT; // (a header that promises more than its blocks can hold)
     size_t cap = want == MZD_CONTENTSIZE_UNKNOWN ? std::max<size_t>(zst_len * 8, 1 << 20) : (size_t)want;
     for (int attempt = 0; attempt < 8; attempt++) { // frames without a content size: grow until it fits
-        file->bytes.resize(cap);
+        try { file->bytes.resize(cap); } catch (const std::exception&) { return -ENOMEM; }
         size_t out_len = 0;
         int rc = mzd_decode(zst, zst_len, file->bytes.data(), cap, &out_len);
         fs->decodes++;
@@ -1375,10 +1380,13 @@ int64_t mzd_fs_open_lazy(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t*
     auto file = std::make_shared<DecodedFile>();
     uint64_t total = 0;
     if (!lazy_index(zst, zst_len, file->frames, &total) || total > (1ull << 40)) return mzd_fs_open(fs, ino, flags, zst, zst_len, real_size);
+    if (total > max_regenerated(zst_len)) return -EFAULT; // (headers that promise more than their blocks can hold)
     if (mzd_device_count() == 0) return -EFAULT; // (no GPU: the first read could not decode either; fail at open like the eager path)
     file->lazy = true;
-    file->zst.assign(zst, zst + zst_len);
-    file->bytes.resize((size_t)total); // (untouched pages cost nothing until a read decodes into them)
+    try {
+        file->zst.assign(zst, zst + zst_len);
+        file->bytes.resize((size_t)total);
+    } catch (const std::exception&) { return -ENOMEM; }
     std::lock_guard<std::mutex> lk(fs->mu);
     uint64_t fh;
     if (!fs->new_fh(&fh)) return -EBUSY;
@@ -1389,6 +1397,18 @@ int64_t mzd_fs_open_lazy(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t*
 }
 
 // decode what [lo, hi) of a lazy file needs; false: the file is corrupt (the reference would have failed at open with EFAULT)
+// The first `nblocks` blocks of frame `fr` of the file `zst`, as a frame of their own: a header without content size / checksum
+// (window descriptor only), the blocks' bytes as they are, the last kept block marked Last_Block.
+static void lazy_synth(const std::vector<uint8_t>& zst, const LazyFrame& fr, size_t nblocks, std::vector<uint8_t>& synth) {
+    const LazyBlock& lb = fr.blocks[nblocks - 1];
+    const size_t body_end = lb.hdr + 3 + (lb.type == 1 ? 1 : lb.size);
+    synth.reserve(6 + (body_end - (fr.in_off + fr.hdr_len)) + MZD_SRC_PADDING);
+    const uint8_t head[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x00, (uint8_t)((fr.window_log - 10) << 3)};
+    synth.assign(head, head + 6);
+    synth.insert(synth.end(), zst.begin() + (ptrdiff_t)(fr.in_off + fr.hdr_len), zst.begin() + (ptrdiff_t)body_end);
+    synth[6 + (lb.hdr - (fr.in_off + fr.hdr_len))] |= 1; // Last_Block
+}
+
 static bool lazy_fill(mzd_fs* fs, DecodedFile& f, uint64_t lo, uint64_t hi) {
     struct Want { LazyFrame* fr; uint64_t upto; size_t nblocks; std::vector<uint8_t> synth; };
     for (int round = 0; round < 40; round++) {
@@ -1414,13 +1434,7 @@ static bool lazy_fill(mzd_fs* fs, DecodedFile& f, uint64_t lo, uint64_t hi) {
             if (w.nblocks >= fr.blocks.size()) { // the whole frame, as it is (content size and checksum verified)
                 j.src = f.zst.data() + fr.in_off; j.src_len = fr.in_len; j.dst_cap = (size_t)fr.out_len;
             } else { // its first blocks as a frame of their own: a header without content size / checksum, the last kept block marked last
-                const LazyBlock& lb = fr.blocks[w.nblocks - 1];
-                const size_t body_end = lb.hdr + 3 + (lb.type == 1 ? 1 : lb.size);
-                w.synth.reserve(6 + (body_end - (fr.in_off + fr.hdr_len)) + MZD_SRC_PADDING);
-                const uint8_t head[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x00, (uint8_t)((fr.window_log - 10) << 3)};
-                w.synth.assign(head, head + 6);
-                w.synth.insert(w.synth.end(), f.zst.begin() + (ptrdiff_t)(fr.in_off + fr.hdr_len), f.zst.begin() + (ptrdiff_t)body_end);
-                w.synth[6 + (lb.hdr - (fr.in_off + fr.hdr_len))] |= 1; // Last_Block
+                lazy_synth(f.zst, fr, w.nblocks, w.synth);
                 j.src = w.synth.data(); j.src_len = w.synth.size();
                 j.dst_cap = (size_t)std::min<uint64_t>(fr.out_len, (uint64_t)w.nblocks * kBlockMax);
             }
@@ -1436,6 +1450,29 @@ static bool lazy_fill(mzd_fs* fs, DecodedFile& f, uint64_t lo, uint64_t hi) {
         }
     }
     return false;
+}
+
+// Diagnostic / host-side test hook (no GPU needed): the lazy open's index of `zst` and, for frame `frame`, the synthetic frame
+// made of its first `nblocks` blocks.  Returns the number of frames indexed (0: the file is not seekable -- it would be opened
+// eagerly), < 0 on bad arguments; *total = the content size the index promises; the synthetic frame goes to synth (cap bytes;
+// *synth_len = its length, also when it does not fit); *nblocks_of_frame = the blocks frame `frame` has.
+int mzd_debug_lazy_plan(const uint8_t* zst, size_t n, uint32_t frame, uint32_t nblocks, uint8_t* synth, size_t cap, size_t* synth_len, uint64_t* total, uint32_t* nblocks_of_frame) {
+    if (!zst && n) return MZD_E_PARAM;
+    std::vector<LazyFrame> frames;
+    uint64_t tot = 0;
+    if (!lazy_index(zst, n, frames, &tot)) return 0;
+    if (total) *total = tot;
+    if (frame < frames.size()) {
+        const LazyFrame& fr = frames[frame];
+        if (nblocks_of_frame) *nblocks_of_frame = (uint32_t)fr.blocks.size();
+        if (nblocks >= 1 && nblocks <= fr.blocks.size()) {
+            std::vector<uint8_t> z(zst, zst + n), out;
+            lazy_synth(z, fr, nblocks, out);
+            if (synth_len) *synth_len = out.size();
+            if (synth && out.size() <= cap) memcpy(synth, out.data(), out.size());
+        }
+    }
+    return (int)std::min<size_t>(frames.size(), 0x7FFFFFFF);
 }
 
 int64_t mzd_fs_read(mzd_fs* fs, uint64_t fh, int64_t offset, uint32_t size, uint8_t* out) {

@@ -161,6 +161,9 @@ int mzd_debug_stamps(int device, uint64_t* out22);
 /* (a build with -DMZD_SMALL_STAMPS, `make sstamps`) the lane-per-file kernel's phase stamps: 12 values, tools/small_stamps.py */
 int mzd_debug_small_stamps(int device, uint64_t* out12);
 int mzd_debug_tfin_all(int device, uint64_t* out, int max_slots);
+/* Host-side test hook (no GPU needed): the lazy open's index of `zst` and the synthetic frame of the first `nblocks` blocks of
+ * frame `frame` (what a partial read decodes).  Returns the frames indexed, 0 when the file is not seekable. */
+int mzd_debug_lazy_plan(const uint8_t* zst, size_t n, uint32_t frame, uint32_t nblocks, uint8_t* synth, size_t cap, size_t* synth_len, uint64_t* total, uint32_t* nblocks_of_frame);
 
 /* Milliseconds the decode kernel of the last launch on `device` took (hipEvents on the
  * launch stream).  Valid after the launch has been collected. */
