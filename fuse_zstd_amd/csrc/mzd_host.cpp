@@ -374,8 +374,10 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         la.stamps = reinterpret_cast<uint64_t*>(d.debug); // (diagnostic builds: the first debug slot's first bytes; unused otherwise)
         const uint32_t ngroups = (p.nsmall + (uint32_t)p.lds_g - 1) / (uint32_t)p.lds_g;
         const uint32_t lds = lds_kernel_bytes(p.lds_g, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out);
-        uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(12u, (160u * 1024u) / lds)); // one wavefront per workgroup
-        resident = std::max<uint32_t>(1u, resident * l.nwg / d.max_wg);
+        // one wavefront per workgroup; as many as the whole device holds, also for a launch on one of the host path's lanes: this
+        // kernel uses none of the per-workgroup scratch the lanes divide, and a chunk of small files that gets a quarter of the wave
+        // slots takes four rounds of groups where one would do (cfg4 host -> host: 1.5 -> ms)
+        const uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(12u, (160u * 1024u) / lds));
         la.lit_stride = p.lit_stride; la.seq_cap = (p.lit_stride - 64) / 3 + 2;
         la.scratch = l.small_lit;
         const size_t per_wave = (size_t)p.lds_g * lds_scratch_per_file(la.lit_stride, la.seq_cap);
@@ -595,6 +597,9 @@ Layout make_layout(const mzd_job* jobs, const std::vector<size_t>& idx, bool inp
 // HOST-pointer jobs `idx` on one device, as a pipeline of chunks: while chunk k decodes, chunk k+1 crosses the link one way
 // and chunk k-1 the other (kSlots launches in flight, each on its own stream and its own share of the scratch).
 int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
+    static const bool trace = getenv("MZD_T2_TRACE") != nullptr; // diagnostic: where a call's wall time goes, to stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) { if (trace) fprintf(stderr, "[mzd t2] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count()); };
     HIPCHK(hipSetDevice(d.hip_id));
     const size_t n = idx.size();
     if (n == 0) return MZD_OK;
@@ -627,9 +632,11 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
             if (L.run_len[r] && !(L.run_host[r] && is_pinned_host(L.run_host[r]) && is_pinned_host(L.run_host[r] + L.run_len[r] - 1))) return false;
         return true;
     };
+    mark("layouts");
     // inputs cross the link straight from the caller's memory when that is pinned and the runs are few (a copy call costs
     // microseconds); outputs are written into pinned caller memory by the kernels themselves, wherever the buffers lie
     const bool in_direct = few_runs(Lin) && pinned(Lin, true), out_direct = pinned(Lout, false);
+    mark("pinned lookups");
     auto grow_dev = [&](uint8_t*& p, size_t& cap, size_t want) -> int {
         if (want <= cap) return MZD_OK;
         hipFree(p); p = nullptr; cap = 0;
@@ -659,6 +666,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         // so the way back over PCIe overlaps the decode instead of following it
         fill_devjob(st->h_jobs[k], st->d_in + Lin.off[k], j.src_len, st->d_out + Lout.off[k], j.dst_cap, j.dict_id, d, out_direct ? j.dst : nullptr);
     }
+    mark("job table filled");
     // chunks: at least kSlots when the batch is worth splitting, ~kChunkBytes each, cut at job boundaries
     size_t bytes_total = 0;
     for (size_t k = 0; k < n; k++) bytes_total += jobs[idx[k]].src_len + jobs[idx[k]].dst_cap;
@@ -703,6 +711,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         plans[c] = make_plan(st->h_jobs + cut[c], cut[c + 1] - cut[c], st->h_lists + 2 * cut[c], d.lane[0].nwg);
         any_small = any_small || plans[c].nsmall != 0;
     }
+    mark("plans");
     // One chunk with more block tasks than a lane has workgroup slots (a single big file): the whole device instead of a
     // quarter of it (the call then waits until no other launch is in flight, like a call on device pointers).
     constexpr int kWholeLane = -2;
@@ -776,6 +785,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         for (size_t c = 0; c < submitted; c++) hipStreamSynchronize(ch[c].lane == kWholeLane ? d.whole.stream : d.lane[ch[c].lane].stream);
         hipStreamSynchronize(d.copy_out);
     }
+    mark("all chunks submitted");
     float ms_sum = 0.f;
     for (size_t c = 0; c < nchunks; c++) { // retire in order: wait, hand bytes and results to the caller
         Chunk& k = ch[c];
@@ -800,6 +810,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
             if (!out_direct && ncopy && j.dst) memcpy(j.dst, st->h_out + Lout.off[q], ncopy);
         });
     }
+    mark("retired");
     if (result == MZD_OK) d.last_ms = ms_sum;
     return result;
 }

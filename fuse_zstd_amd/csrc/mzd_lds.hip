@@ -585,24 +585,44 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         SSTAMP(13);
                         if (!build_fse_lane(wtab, wnorm, nsym, log, 3)) break;
                         SSTAMP(14);
-                        LBack rd;
-                        if (!rd.init(tp + 1 + hdr, hb - hdr)) break;
-                        rd.refill();
-                        uint32_t s1 = wtab + 8 * rd.read(log), s2 = wtab + 8 * rd.read(log);
+                        // two interleaved states over a backward bitstream of <= 127 bytes; the stream's over-read ends it (A.4).  Both
+                        // states' entries are fetched together (one round trip per two weights); the unread bits sit top-aligned in a
+                        // 64-bit register, re-read from LDS once per pair (two fields of <= 6 bits).
+                        const uint32_t sb = tp + 1 + hdr, sl = hb - hdr;
+                        const uint32_t lastb = L8(sb + sl - 1);
+                        if (lastb == 0) break;
+                        int32_t h = (int32_t)((sl - 1) * 8) + hibit32(lastb); // unread bits
+                        auto window = [&](int32_t hh) -> uint64_t { // the bits below the read head, top-aligned; zero below the stream's start
+                            if (hh <= 0) return 0ull;
+                            const int32_t bb = (hh - 1) >> 3;
+                            const uint64_t W = bb >= 7 ? lds_u64(sb + (uint32_t)(bb - 7)) : lds_u64(sb) << (8 * (7 - bb)); // (bytes before the stream are not its own)
+                            uint64_t c = W << (8 * (bb + 1) - hh);
+                            if (hh < 64) c &= ~0ull << (64 - hh);
+                            return c;
+                        };
+                        uint64_t cur = window(h);
+                        uint32_t s1 = wtab + 8 * (uint32_t)(cur >> (64 - log)); cur <<= log;
+                        uint32_t s2 = wtab + 8 * (uint32_t)(cur >> (64 - log));
+                        h -= 2 * (int32_t)log;
                         bool fin = false;
-                        for (;;) { // two interleaved states; the stream's over-read ends it (A.4)
-                            if (nw > 253) break;
-                            uint64_t e = L64(s1);
-                            uint32_t eh = (uint32_t)(e >> 32);
-                            L8(wts + nw) = (uint8_t)(eh >> 16); nw++;
-                            s1 = (uint32_t)e + 8 * rd.read(eh & 31);
-                            if (rd.h < 0) { L8(wts + nw) = (uint8_t)(L32(s2 + 4) >> 16); nw++; fin = true; break; }
-                            if (nw > 253) break;
-                            e = L64(s2);
-                            eh = (uint32_t)(e >> 32);
-                            L8(wts + nw) = (uint8_t)(eh >> 16); nw++;
-                            s2 = (uint32_t)e + 8 * rd.read(eh & 31);
-                            if (rd.h < 0) { L8(wts + nw) = (uint8_t)(L32(s1 + 4) >> 16); nw++; fin = true; break; }
+                        for (;;) {
+                            if (nw > 252) break;
+                            cur = window(h);
+                            const uint64_t e1 = L64(s1), e2 = L64(s2);
+                            const uint32_t h1 = (uint32_t)(e1 >> 32), h2 = (uint32_t)(e2 >> 32);
+                            const uint32_t n1 = h1 & 31, n2 = h2 & 31;
+                            const uint32_t b1 = n1 ? (uint32_t)(cur >> (64 - n1)) : 0u;
+                            L8(wts + nw) = (uint8_t)(h1 >> 16);
+                            s1 = (uint32_t)e1 + 8 * b1;
+                            h -= (int32_t)n1;
+                            if (h < 0) { L8(wts + nw + 1) = (uint8_t)(h2 >> 16); nw += 2; fin = true; break; }
+                            cur <<= n1;
+                            const uint32_t b2 = n2 ? (uint32_t)(cur >> (64 - n2)) : 0u;
+                            L8(wts + nw + 1) = (uint8_t)(h2 >> 16);
+                            s2 = (uint32_t)e2 + 8 * b2;
+                            h -= (int32_t)n2;
+                            nw += 2;
+                            if (h < 0) { L8(wts + nw) = (uint8_t)(L32(s1 + 4) >> 16); nw++; fin = true; break; }
                         }
                         if (!fin) break;
                     }

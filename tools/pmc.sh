@@ -11,7 +11,7 @@ acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r.get("Kernel_Name", "")
-        if "mzd_decode_kernel" in kn or "mzd_small_kernel" in kn:
+        if "mzd_decode_kernel" in kn or "mzd_small_kernel" in kn or "mzd_lds_kernel" in kn:
             acc[(kn.split("(")[0].split("::")[-1][:28], r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (kn, k), v in sorted(acc.items()):
     print("%-28s %-20s per launch %.4g  (launches %d)" % (kn, k, sum(v) / len(v), len(v)))

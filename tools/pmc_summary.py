@@ -10,7 +10,7 @@ def counter(dirname, name):
     for f in glob.glob(out + "/" + dirname + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r.get("Kernel_Name", "")
-            if r.get("Counter_Name") == name and ("mzd_decode_kernel" in kn or "mzd_small_kernel" in kn):
+            if r.get("Counter_Name") == name and ("mzd_decode_kernel" in kn or "mzd_small_kernel" in kn or "mzd_lds_kernel" in kn):
                 acc[kn.split("(")[0].replace("void ", "").replace("mzd::", "")].append(float(r["Counter_Value"]))
     return acc
 fe, wr = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
