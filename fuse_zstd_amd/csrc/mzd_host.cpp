@@ -382,7 +382,8 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         la.scratch = l.small_lit;
         const size_t per_wave = (size_t)p.lds_g * lds_scratch_per_file(la.lit_stride, la.seq_cap);
         const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / per_wave);
-        launch_lds(la, std::min(ngroups, std::min(resident, by_scratch)), p.lds_g, p.with_dict ? 1 : 0, s);
+        static const uint32_t env_grid = getenv("MZD_LDS_GRID") ? (uint32_t)atoi(getenv("MZD_LDS_GRID")) : 0u; // (experiments: fewer resident wavefronts)
+        launch_lds(la, std::min(ngroups, std::min(env_grid ? env_grid : resident, by_scratch)), p.lds_g, p.with_dict ? 1 : 0, s);
         HIPCHK(hipGetLastError());
         ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig;
         grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
@@ -410,6 +411,8 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         grid = use_tasks ? std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(njobs, l.nwg)) : njobs;
     }
     grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, l.nwg));
+    // (the launch behind the small-file kernel is not optional even when nothing is handed on: its last workgroup zeroes the
+    //  counter block of the lane's next launch)
     launch_decode(ka, grid, s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev1, s));

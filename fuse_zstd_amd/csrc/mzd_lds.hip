@@ -1097,7 +1097,11 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     V16 D0 = {0, 0}, D1 = {0, 0};
                     if (DICT) {
                         dfull = ml != 0 && ml < 32 && off > mp && off - mp >= ml;
-                        const uint8_t* dp = dfull ? dict_end - (off - mp) : seq_g; // (dictionary buffers are readable 32 bytes past their end; a lane without such a match reads anything readable)
+#ifdef MZD_EXP_NODICTFETCH // (experiment: what the trips to the dictionary content in L2 cost -- the bytes stored are wrong)
+                        const uint8_t* dp = seq_g;
+#else
+                        const uint8_t* dp = dfull ? dict_end - (off - mp) : seq_g;
+#endif // (dictionary buffers are readable 32 bytes past their end; a lane without such a match reads anything readable)
                         D0 = gv16(dp); D1 = gv16(dp + 16);
                     }
                     const uint32_t sa = lit_base + lp;
@@ -1218,7 +1222,9 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     hh += out_len;
                     hh = xxh_tail(hh, res_off + (out_len / 32) * 32, res_off + out_len);
 #ifndef MZD_EXP_NOCK
+#ifndef MZD_EXP_NODICTFETCH
                     if ((uint32_t)hh != stored_ck) ck_bad = 1;
+#endif
 #endif
                 }
             }
