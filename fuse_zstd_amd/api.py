@@ -17,7 +17,7 @@ CONTENTSIZE_ERROR = 2**64 - 2
 EXPORTS = [
     "mzd_init", "mzd_init_ex", "mzd_shutdown", "mzd_device_count", "mzd_content_size", "mzd_decode", "mzd_decode_batch",
     "mzd_decode_batch_device", "mzd_batch_prepare", "mzd_batch_launch", "mzd_batch_collect", "mzd_batch_free",
-    "mzd_load_dict", "mzd_unload_dict", "mzd_debug_last_block", "mzd_debug_set_driver", "mzd_debug_counters", "mzd_debug_host_path", "mzd_debug_stamps", "mzd_debug_small_stamps", "mzd_debug_tfin_all", "mzd_debug_lazy_plan",
+    "mzd_load_dict", "mzd_unload_dict", "mzd_debug_last_block", "mzd_debug_set_driver", "mzd_debug_counters", "mzd_debug_host_path", "mzd_debug_stamps", "mzd_debug_small_stamps", "mzd_debug_small_scratch", "mzd_debug_tfin_all", "mzd_debug_lazy_plan",
     "mzd_host_alloc", "mzd_host_free", "mzd_last_kernel_ms", "mzd_strerror", "mzd_version",
     "mzd_fs_new", "mzd_fs_free", "mzd_fs_open", "mzd_fs_open_lazy", "mzd_fs_read", "mzd_fs_release", "mzd_fs_decode_count", "mzd_fs_decoded_bytes",
 ]
@@ -37,7 +37,7 @@ class Job(C.Structure):  # mzd_job
 def build(force=False):
     """hipcc --offload-arch=gfx950 build of libmzd.so, in-tree (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("mzd_kernels.hip", "mzd_small.hip", "mzd_host.cpp", "mzd_device.h", "mzd_tables.h") + tuple(f for f in os.listdir(src_dir) if f.startswith("mzd_k_"))]
+    srcs = [os.path.join(src_dir, f) for f in ("mzd_kernels.hip", "mzd_lds.hip", "mzd_host.cpp", "mzd_device.h", "mzd_tables.h") + tuple(f for f in os.listdir(src_dir) if f.startswith("mzd_k_"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mzd.h"))
     def stale():
         return force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)

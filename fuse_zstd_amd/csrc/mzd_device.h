@@ -140,28 +140,11 @@ struct KernelArgs {
     uint32_t resolve;      // 1: use it
 };
 
-// ---- the small-file kernel (mzd_small.hip): one lane per file, a group of G files per wavefront ------------------------
+// ---- the small-file kernel (mzd_lds.hip) ---------------------------------------------------------------------------------
 constexpr uint32_t kSmallCap = 8192;                   // eligible: dst_cap <= kSmallCap ...
 constexpr uint32_t kSmallSrcMax = kSmallCap + 1024;    // ... and src_len <= kSmallSrcMax
-constexpr uint32_t kSmallGroupMax = 64;
-struct SmallArgs {
-    DevJob* jobs;
-    const uint32_t* small_list; // job indices, sorted by dictionary
-    uint32_t nsmall;
-    uint32_t* counter;          // the launch's counter block (words 4 and 5)
-    uint32_t* redo_list;        // = job_list + nlist_fixed
-    uint8_t* lit_scratch;       // gridDim.x * G * lit_stride bytes
-    uint32_t lit_stride;        // bytes per file: >= the largest capacity of the launch + 64
-    const DevDict* dicts;
-    uint32_t ndicts;
-    uint32_t with_dict;         // some job names a dictionary: LDS holds one dictionary's tables
-    uint64_t* stamps;           // diagnostic build (-DMZD_SMALL_STAMPS): 9 cycle stamps of workgroup 0's first group, else unused
-};
 
-void launch_small(const SmallArgs& a, uint32_t grid, int g, uint32_t lds_at_least, void* stream);
-uint32_t small_lds_bytes(int g, int with_dict);
-
-// ---- the small-file kernel with the whole file in LDS (mzd_lds.hip): G files per wavefront, 64 / G lanes per file; a file's
+// The whole file in LDS: G files per wavefront, 64 / G lanes per file; a file's
 // slot = [tables | ring | compressed input | output window], sized by the host for the launch's largest file
 struct LdsArgs {
     DevJob* jobs;

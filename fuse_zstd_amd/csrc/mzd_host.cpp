@@ -3,7 +3,7 @@
 // round-robin sharding of files over GPUs, and the C++ mirror of the reference's file-handle table (reference
 // src/file.rs:10-135) with open/read/release (reference src/main.rs:451-513, 595-599).
 //
-// All decoding happens in mzd_kernels.hip / mzd_small.hip; nothing here decodes (there is no CPU fallback:
+// All decoding happens in mzd_kernels.hip / mzd_lds.hip; nothing here decodes (there is no CPU fallback:
 // without a usable GPU every decode entry point returns MZD_E_DEVICE).
 #include <hip/hip_runtime.h>
 
@@ -90,6 +90,7 @@ struct Device {
     uint4* walk_scratch = nullptr;
     uint8_t* small_lit = nullptr;
     size_t small_lit_total = 0;
+    uint32_t last_lds_lit_stride = 0, last_lds_seq_cap = 0; // geometry of the small-file kernel's scratch in the most recent whole-device launch (mzd_debug_small_scratch)
     uint32_t* resolve_map = nullptr; // kResMapStride words per workgroup slot (mzd_k_resolve.h); null: blocks are never resolved ahead (mzd_config::resolve_ahead)
     DebugSlot* debug = nullptr;
     uint32_t* counters = nullptr; // 2 x (kSlots + 1) blocks of kCounterWords
@@ -254,11 +255,9 @@ int ensure_task_state(Lane& l, size_t n) {
 // than one block, else a workgroup per file.
 struct Plan {
     uint32_t njobs = 0, nsmall = 0, nbig = 0;
-    int small_g = 16;
     bool with_dict = false, multi = false;
-    uint32_t lit_stride = 0;   // literal scratch per small file: largest capacity + 64 (the lane-per-file kernel, debug mode 6)
-    bool lds_kernel = true;    // small files take mzd_lds.hip (the whole file in LDS); false: mzd_small.hip (debug mode 6)
-    int lds_g = 4;             // files per wavefront of that kernel
+    uint32_t lit_stride = 0;   // literal scratch per small file: largest capacity + 64
+    int lds_g = 4;             // files per wavefront of the small-file kernel (mzd_lds.hip)
     uint32_t lds_tab = 0, lds_comp = 0, lds_out = 0; // its slot geometry (LdsArgs)
     uint32_t big_tasks = 0;    // workgroups worth launching for the files that are not small
     uint64_t blocks = 0;       // block tasks of those files, estimated from their capacities
@@ -280,7 +279,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
     // 1 024 files 0.15 / 0.23 ms, 2 048 0.26 / 0.25, 4 096 0.46 / 0.29, 10 000 1.04 / 0.57; 512-byte files cross at 1 024)
     size_t eligible = 0, maxsrc = 0;
     for (size_t i = 0; i < njobs; i++) eligible += jobs[i].dst_cap <= kSmallCap && jobs[i].src_len <= kSmallSrcMax;
-    const bool small_ok = force == 3 || force == 6 || (force == 0 && eligible >= 2ull * max_wg); // (3, 6: whenever a file is eligible -- tests)
+    const bool small_ok = force == 3 || (force == 0 && eligible >= 2ull * max_wg); // (3: whenever a file is eligible -- tests)
     for (size_t i = 0; i < njobs; i++) {
         const DevJob& j = jobs[i];
         const bool is_small = small_ok && j.dst_cap <= kSmallCap && j.src_len <= kSmallSrcMax;
@@ -297,9 +296,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
         }
     }
     if (p.nsmall) {
-        p.small_g = (p.with_dict && all_dict) ? 64 : 16;
         p.lit_stride = (uint32_t)align_up(maxcap + 64, 64);
-        p.lds_kernel = force != 6;
         // The files of a group run in lockstep, so a group takes as long as its largest file: the list is sorted by size (a
         // counting sort: capacity in steps of 32 bytes), and by dictionary first -- a group shares one dictionary's tables.
         {
@@ -365,7 +362,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     ka.resolve = !use_tasks || force == 5 || !d.resolve_map ? 0u : ((force == 4 || p.blocks <= 8ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : 2u);
     HIPCHK(hipEventRecord(ev0, s));
     uint32_t grid;
-    if (p.nsmall && p.lds_kernel) {
+    if (p.nsmall) {
         LdsArgs la;
         la.jobs = d_jobs; la.list = d_lists; la.n = p.nsmall; la.counter = l.counter;
         la.redo_list = const_cast<uint32_t*>(d_lists) + njobs + p.nbig;
@@ -380,32 +377,13 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         const uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(12u, (160u * 1024u) / lds));
         la.lit_stride = p.lit_stride; la.seq_cap = (p.lit_stride - 64) / 3 + 2;
         la.scratch = l.small_lit;
+        if (&l == &d.whole) { d.last_lds_lit_stride = la.lit_stride; d.last_lds_seq_cap = la.seq_cap; }
         const size_t per_wave = (size_t)p.lds_g * lds_scratch_per_file(la.lit_stride, la.seq_cap);
         const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / per_wave);
         static const uint32_t env_grid = getenv("MZD_LDS_GRID") ? (uint32_t)atoi(getenv("MZD_LDS_GRID")) : 0u; // (experiments: fewer resident wavefronts)
         launch_lds(la, std::min(ngroups, std::min(env_grid ? env_grid : resident, by_scratch)), p.lds_g, p.with_dict ? 1 : 0, s);
         HIPCHK(hipGetLastError());
         ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig;
-        grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
-    } else if (p.nsmall) {
-        SmallArgs sa;
-        sa.jobs = d_jobs; sa.small_list = d_lists; sa.nsmall = p.nsmall; sa.counter = l.counter;
-        sa.redo_list = const_cast<uint32_t*>(d_lists) + njobs + p.nbig;
-        const uint32_t ngroups = (p.nsmall + (uint32_t)p.small_g - 1) / (uint32_t)p.small_g;
-        const uint32_t lds = small_lds_bytes(p.small_g, p.with_dict);
-        uint32_t resident = d.cus * std::min<uint32_t>(8u, (160u * 1024u) / lds); // one wavefront per workgroup
-        resident = std::max<uint32_t>(1u, resident * l.nwg / d.max_wg);
-        const size_t per_wave = (size_t)p.small_g * p.lit_stride;
-        const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / per_wave);
-        const uint32_t sgrid = std::min(ngroups, std::min(resident, by_scratch));
-        sa.lit_scratch = l.small_lit; sa.lit_stride = p.lit_stride;
-        sa.dicts = d.d_dicts; sa.ndicts = d.ndicts; sa.with_dict = p.with_dict ? 1u : 0u;
-        sa.stamps = reinterpret_cast<uint64_t*>(d.debug); // (diagnostic builds: the first debug slot's first bytes; unused otherwise)
-        launch_small(sa, sgrid, p.small_g, 0, s);
-        HIPCHK(hipGetLastError());
-        ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig;
-        // what is left for the general driver: the files that are not small, and whatever the small-file kernel hands on
-        // (normally nothing; a corpus of malformed small files: all of them)
         grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
     } else {
         grid = use_tasks ? std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(njobs, l.nwg)) : njobs;
@@ -1117,7 +1095,7 @@ int mzd_unload_dict(uint32_t dict_id) {
 }
 
 int mzd_debug_set_driver(int driver) {
-    if (driver < 0 || driver > 6) return MZD_E_PARAM; // (6: the round-2 lane-per-file kernel instead of the LDS kernel -- measurements only)
+    if (driver < 0 || driver > 5) return MZD_E_PARAM;
     g_force_driver.store(driver, std::memory_order_relaxed);
     return MZD_OK;
 }
@@ -1176,6 +1154,22 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
     for (int i = 0; i < 8; i++) out8[i] = ds.stamp[i];
     for (int i = 0; i < 8; i++) out8[8 + i] = ds.cstamp[i];
     for (int i = 0; i < 6; i++) out8[16 + i] = ds.tfin[i];
+    return MZD_OK;
+}
+
+// Diagnostic: what the small-file kernel's entropy phase left in its scratch for resident file slot `slot` (the f-th file of the group
+// that workgroup b decoded last: slot = b * G + f) in the most recent call on device pointers: its literals (lit_n bytes) and its
+// sequences, 8 bytes each -- literal length | match length << 14 | offset VALUE << 32 (before repeat-offset resolution, A.5).
+int mzd_debug_small_scratch(int device, uint32_t slot, uint8_t* lit, size_t lit_n, uint64_t* seq, size_t seq_n) {
+    auto dp = get_device(device);
+    if (!dp) return MZD_E_PARAM;
+    WholeGuard g(*dp);
+    HIPCHK(hipSetDevice(dp->hip_id));
+    if (!dp->last_lds_lit_stride) return MZD_E_PARAM;
+    const size_t per = (size_t)dp->last_lds_lit_stride + 8u * (size_t)dp->last_lds_seq_cap;
+    if ((slot + 1) * per > dp->small_lit_total || lit_n > dp->last_lds_lit_stride || seq_n > dp->last_lds_seq_cap) return MZD_E_PARAM;
+    if (lit && lit_n) HIPCHK(hipMemcpy(lit, dp->small_lit + slot * per, lit_n, hipMemcpyDeviceToHost));
+    if (seq && seq_n) HIPCHK(hipMemcpy(seq, dp->small_lit + slot * per + dp->last_lds_lit_stride, 8 * seq_n, hipMemcpyDeviceToHost));
     return MZD_OK;
 }
 

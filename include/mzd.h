@@ -144,12 +144,12 @@ int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit
                          uint32_t* seq4, size_t seq_cap, size_t* n_seq);
 
 /* Diagnostics (tests, tools/): which kernel a launch takes.  0 automatic (small files, when there are thousands of them:
- * the lane-per-file kernel; 3: that kernel for every eligible file however few; then a
+ * the small-file kernel; 3: that kernel for every eligible file however few; then a
  * workgroup per file, or block tasks when a file can have several blocks), 1 / 2: that general driver only; 4 / 5: block
  * tasks, with / without resolving blocks ahead of their predecessors whatever the size of the launch. */
 int mzd_debug_set_driver(int driver);
 /* The 8 counter words of the launch that decoded job 0 of the most recent call: [0] queue tickets, [2] block tasks pushed,
- * [3] files finished by the block-task driver, [4] small files the lane-per-file kernel handed on to the general driver,
+ * [3] files finished by the block-task driver, [4] small files the small-file kernel handed on to the general driver,
  * [5] groups it took. */
 int mzd_debug_counters(int device, uint32_t* out8);
 /* Host-path diagnostics.  what 2: at most `value` chunks per call when the kernels mirror the outputs into pinned caller
@@ -158,8 +158,11 @@ int mzd_debug_host_path(int device, int what, int value);
 /* Diagnostic builds only (make diag / tfin): per-phase cycle sums of the workgroup that ran job 0; role finish times of
  * every workgroup slot.  In the product build they return zeros. */
 int mzd_debug_stamps(int device, uint64_t* out22);
-/* (a build with -DMZD_SMALL_STAMPS, `make sstamps`) the lane-per-file kernel's phase stamps: 12 values, tools/small_stamps.py */
-int mzd_debug_small_stamps(int device, uint64_t* out12);
+/* (a build with -DMZD_SMALL_STAMPS, `make sstamps`) the small-file kernel's phase stamps: 1 032 values, tools/lds_stamps.py */
+int mzd_debug_small_stamps(int device, uint64_t* out);
+/* the small-file kernel's intermediates of resident file slot `slot` after a call on device pointers: literals, and sequences as
+ * literal length | match length << 14 | offset value << 32 (before repeat-offset resolution) */
+int mzd_debug_small_scratch(int device, uint32_t slot, uint8_t* lit, size_t lit_n, uint64_t* seq, size_t seq_n);
 int mzd_debug_tfin_all(int device, uint64_t* out, int max_slots);
 /* Host-side test hook (no GPU needed): the lazy open's index of `zst` and the synthetic frame of the first `nblocks` blocks of
  * frame `frame` (what a partial read decodes).  Returns the frames indexed, 0 when the file is not seekable. */

@@ -1,4 +1,4 @@
-"""GPU tests at BASELINE.json's FULL configuration sizes (run with -m gpu on an MI355X), the lane-per-file kernel's
+"""GPU tests at BASELINE.json's FULL configuration sizes (run with -m gpu on an MI355X), the small-file kernel's
 hand-over to the general drivers, the pipelined host path (pinned / pageable buffers, calls in flight from several
 threads), dictionary unloading, and -- where the box has two GPUs -- the multi-GPU product path.
 
@@ -71,7 +71,7 @@ def test_config3_full_size():
 @needs_zstd
 def test_config4_full_size_takes_the_small_file_kernel():
     """BASELINE configs[3] / the north_star's corpus: 10 000 x 4 KiB JSON files (parallel-files.fio shape) in one launch:
-    the lane-per-file kernel decodes all of them (nothing is handed on: counter word 4)."""
+    the small-file kernel decodes all of them (nothing is handed on: counter word 4)."""
     cp = corpus.build_corpus("json", 4, [4096] * 10000)
     res, got, end = _device_resident(cp)
     _check_corpus(cp, res, got, end, sample=100)
@@ -84,7 +84,7 @@ def test_config4_full_size_takes_the_small_file_kernel():
 def test_config4_log_uniform_mix_of_small_and_multi_block_files(mode):
     """The log-uniform variant in small (1 KB .. 1 MiB, 600 files) in ONE launch: block tasks, every block after a file's first
     resolved ahead of its predecessor (few tasks for the machine).  Mode 0, the library's own choice, gives the few small files
-    to the general driver as well; mode 3 sends them through the lane-per-file kernel first."""
+    to the general driver as well; mode 3 sends them through the small-file kernel first."""
     rng = np.random.RandomState(1234)
     sizes = [int(x) for x in np.exp(rng.uniform(np.log(1000), np.log(1 << 20), size=600)).astype(np.int64)]
     cp = corpus.build_corpus("json", 4, sizes)
@@ -126,11 +126,11 @@ def test_config5_full_size_shared_dictionary():
 @needs_zstd
 @pytest.mark.parametrize("kind", ["json", "text", "markup", "int32", "dna", "xray", "random", "repeats"])
 def test_small_files_of_every_class_and_size(kind):
-    """Files of 0 .. 8 KiB (the lane-per-file kernel's range) and a little beyond, levels 1 / 3 / 19: every literal mode
+    """Files of 0 .. 8 KiB (the small-file kernel's range) and a little beyond, levels 1 / 3 / 19: every literal mode
     (raw, RLE, Huffman 1 and 4 streams), predefined / RLE / FSE tables, raw and RLE blocks, long overlapping matches."""
     sizes = [0, 1, 2, 7, 15, 16, 17, 31, 32, 33, 63, 64, 100, 255, 256, 300, 511, 700, 1000, 1023, 1024, 2000, 3000, 4095, 4096, 4097,
              5000, 6000, 8191, 8192, 8193, 9000, 12000]
-    mzd.set_driver(3)  # the lane-per-file kernel for every eligible file (by itself it only takes thousands at a time)
+    mzd.set_driver(3)  # the small-file kernel for every eligible file (by itself it only takes thousands at a time)
     for level in (1, 3, 19):
         cp = corpus.build_corpus(kind, 77, sizes * 3, level=level)
         srcs = [cp.comp_file(i).tobytes() for i in range(cp.nfiles)]
@@ -144,7 +144,7 @@ def test_small_files_of_every_class_and_size(kind):
 
 def test_small_kernel_hands_on_what_is_not_plain():
     """In one launch: the reference's own test payloads (raw-block frames of a few bytes), an empty file, small multi-frame
-    files, skippable frames, truncated and corrupted frames, too-small outputs.  The lane-per-file kernel decodes the plain
+    files, skippable frames, truncated and corrupted frames, too-small outputs.  The small-file kernel decodes the plain
     ones and hands the others to the general driver, whose verdict must be the oracle's."""
     vs = [v for v in VECS if v.dict is None and len(v.comp) <= 8192 and (not v.ok or v.out_len <= 8192)]
     assert len(vs) > 40
@@ -155,7 +155,7 @@ def test_small_kernel_hands_on_what_is_not_plain():
     caps += [v.out_len - 1 for v in vs if v.ok and v.out_len > 2]
     srcs += [v.comp for v in vs if v.ok]
     caps += [v.out_len + 5 for v in vs if v.ok]
-    mzd.set_driver(3)  # (the lane-per-file kernel however few the files)
+    mzd.set_driver(3)  # (the small-file kernel however few the files)
     try:
         res = mzd.decode_batch(srcs, caps)
     finally:

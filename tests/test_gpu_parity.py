@@ -1,5 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
 (include/mzd.h), against the oracle and the committed golden vectors -- byte-exact."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -20,7 +22,7 @@ def gpu():
     mzd.shutdown()
 
 
-DRIVERS = ["auto", "1", "4", "5"]  # auto (mode 3): small files take the lane-per-file kernel however few they are, the rest (and what it hands on) a general driver;
+DRIVERS = ["auto", "1", "4", "5"]  # auto (mode 3): small files take the small-file kernel however few they are, the rest (and what it hands on) a general driver;
                                     # 4 / 5: block tasks with / without blocks resolved ahead of their predecessors (mzd_k_resolve.h)
 
 
@@ -61,8 +63,8 @@ def test_golden_negative(v):
                                   "hand_long_nbseq", "hand_direct_weights_4s", "json_1m"])
 def test_phase_intermediates_match_cpu_twin(name, force_driver):
     """Literal buffer (K2) and sequence triples (K4) of the last compressed block, as the block pipeline
-    left them in its scratch, against the oracle's dump of the same block.  (The lane-per-file kernel keeps no
-    sequence records -- it executes a sequence the moment it is decoded -- so the general drivers are forced.)"""
+    left them in its scratch, against the oracle's dump of the same block.  (The general drivers are forced; the small-file
+    kernel's intermediates: test_small_file_kernel_intermediates_match_cpu_twin.)"""
     v = next(x for x in VECS if x.name == name)
     force_driver("2" if v.out_len > 131072 else "1")
     rc, out, blocks, dump = oracle.decode(v.comp, cap=v.out_len, want_trace=True, dump=True)
@@ -113,11 +115,68 @@ def test_dictionary_frames():
 needs_zstd = pytest.mark.skipif(not corpus.have_zstd(), reason="no libzstd shared object to compress a corpus with")
 
 
+@needs_zstd
+def test_small_file_kernel_intermediates_match_cpu_twin():
+    """The small-file kernel (mzd_lds.hip) hands its entropy phase's results to its execute phase through a scratch in HBM: the
+    literals (K1/K2) and, per sequence, literal length, match length and offset VALUE (K3/K4, before repeat-offset resolution).
+    Both against the oracle's dump of the same block, for files of every data class decoded alone on device pointers (resident
+    file slot 0); the offsets are resolved here with the rule of A.5 and compared with the oracle's resolved ones."""
+    import torch
+    L = mzd.lib()
+    L.mzd_debug_small_scratch.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    dev = torch.device("cuda:0")
+    checked = 0
+    skipped = []
+    mzd.set_driver(3)
+    try:
+        for kind, size, level in (("json", 4096, 3), ("json", 8000, 19), ("text", 3000, 3), ("markup", 2500, 1), ("int32", 4096, 3), ("dna", 6000, 3), ("repeats", 8192, 3), ("json", 700, 3),
+                                  ("json", 2000, 1), ("markup", 4096, 3), ("text", 1500, 19), ("json", 5000, 3)):
+            cp = corpus.build_corpus(kind, 31, [size], level=level)
+            comp = cp.comp_file(0).tobytes()
+            rc, want, blocks, dump = oracle.decode(comp, cap=size, want_trace=True, dump=True)
+            assert rc == 0 and len(blocks) == 1
+            b = blocks[0]
+            if b["block_type"] != 2 or b["huf_max_bits"] > 10:
+                continue  # (raw / RLE blocks have no intermediates; 11-bit Huffman tables are handed on to the general driver)
+            src = torch.from_numpy(np.frombuffer(comp + b"\0" * 64, dtype=np.uint8).copy()).to(dev)
+            out = torch.zeros(size + 64, dtype=torch.uint8, device=dev)
+            jobs = mzd.api.make_jobs([src.data_ptr()], [len(comp)], [out.data_ptr()], [size])
+            res = mzd.decode_batch_device(0, jobs)
+            assert res[0][0] == 0 and bytes(out.cpu().numpy()[:size]) == want
+            if mzd.debug_counters(0)[4] != 0:
+                skipped.append((kind, size, level))  # handed on to the general driver (tables that do not fit the slot): no scratch to look at
+                continue
+            nlit, nseq = b["n_lit"], b["n_seq"]
+            lit = (C.c_uint8 * max(nlit, 1))()
+            seq = (C.c_uint64 * max(nseq, 1))()
+            assert L.mzd_debug_small_scratch(0, 0, lit, nlit if b["lit_type"] != 0 else 0, seq, nseq) == 0
+            if b["lit_type"] != 0:  # (raw literals stay in the input: nothing is written to the scratch)
+                assert bytes(lit[:nlit]) == dump["lit"], (kind, size)
+            rep = [1, 4, 8]
+            for k, (ll, ml, off) in enumerate(dump["seq"]):
+                v = seq[k]
+                gll, gml, ofv = v & 0x3FFF, (v >> 14) & 0x3FFF, v >> 32
+                assert (gll, gml) == (ll, ml), (kind, size, k)
+                if ofv > 3:
+                    got = ofv - 3; rep = [got, rep[0], rep[1]]
+                else:
+                    idx = ofv - 1 + (1 if ll == 0 else 0)
+                    if idx == 0: got = rep[0]
+                    elif idx == 1: got = rep[1]; rep = [rep[1], rep[0], rep[2]]
+                    elif idx == 2: got = rep[2]; rep = [rep[2], rep[0], rep[1]]
+                    else: got = rep[0] - 1; rep = [got, rep[0], rep[1]]
+                assert got == off, (kind, size, k, got, off)
+            checked += 1
+    finally:
+        mzd.set_driver(0)
+    assert checked >= 6, (checked, skipped)
+
+
 @pytest.mark.parametrize("driver", DRIVERS)
 def test_both_drivers_decode_every_vector(driver, force_driver):
     """The library has two kernel drivers: one workgroup per file (launches whose capacities are all <= 128 KiB) and
     block tasks (the blocks of a frame on different workgroups: tables, repeat offsets, output position and checksum
-    state handed from task to task).  Forced through mzd_debug_set_driver (and left to the library: 'auto', where small files take the lane-per-file kernel first), each must decode every positive vector (single- and
+    state handed from task to task).  Forced through mzd_debug_set_driver (and left to the library: 'auto', where small files take the small-file kernel first), each must decode every positive vector (single- and
     multi-block, multi-frame, skippable, windows > 128 KiB) byte-exactly, in one batch and one by one, and report the
     oracle's error class on every negative vector."""
     force_driver(driver)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.getcwd())
 import numpy as np
 import corpus, oracle, fuse_zstd_amd as mzd
 mzd.init()
-if os.environ.get('MZD_DRIVER'): mzd.set_driver(int(os.environ['MZD_DRIVER']))  # (3: the lane-per-file kernel for the small frames)
+if os.environ.get('MZD_DRIVER'): mzd.set_driver(int(os.environ['MZD_DRIVER']))  # (3: the small-file kernel for the small frames)
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 cases = []
 for kind, seed, size in (("json", 41, 131072), ("text", 42, 100000), ("markup", 43, 60000), ("xray", 44, 131072), ("json", 45, 20000), ("dna", 46, 50000), ("repeats", 47, 131072), ("json", 48, 4096)):

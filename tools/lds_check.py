@@ -64,6 +64,4 @@ d = corpus.train_dict("json", 5, [int(x) for x in rs[:4000]], cap=112640)
 h = mzd.load_dict(d)
 nf = 2000 if quick else 50000
 bad += run("cfg5: dict records x %d" % nf, corpus.build_corpus("json", 5, [int(x) for x in rs[:nf]], dictionary=d), did=h)
-if os.environ.get("OLD"):
-    run("cfg4 old kernel (mode 6)", corpus.build_corpus("json", 4, [4096] * 10000), mode=6)
 print("TOTAL BAD", bad)

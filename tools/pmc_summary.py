@@ -1,6 +1,6 @@
 """Summarise the two --pmc passes of tools/rocprof.sh (FETCH_SIZE, WRITE_SIZE; separate passes, as MI355X_MICROARCH.md prescribes)
 into HBM bytes per bench step: python tools/pmc_summary.py gpurun_out/prof_<tag> <tag>  ->  gpurun_out/prof_<tag>_pmc.json
-A bench step may be more than one kernel (the lane-per-file kernel, then a general driver for what it hands on; the second
+A bench step may be more than one kernel (the small-file kernel, then a general driver for what it hands on; the second
 kernel's counters also carry the write-back of lines the first left dirty in L2): the step's traffic is the sum over the
 step's kernels."""
 import collections, csv, glob, json, sys

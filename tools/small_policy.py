@@ -1,5 +1,5 @@
 """Diagnostic: kernel time of N small JSON files under each kernel choice -- the general driver alone (mode 1), the LDS kernel
-(mode 3), the round-2 lane-per-file kernel (mode 6) -- per file size and file count: the data behind the launch policy
+(mode 3), and -- while it existed: mode 6, removed after this measurement -- the round-2 lane-per-file kernel -- per file size and file count: the data behind the launch policy
 (mzd_host.cpp: make_plan) and the record asked for by "measure LDS-window vs before per size class".
   python tools/small_policy.py"""
 import os, sys
@@ -29,5 +29,5 @@ for size in (512, 1024, 2048, 4096, 8192):
     for n in (64, 256, 1024, 2048, 4096, 10000, 40000):
         if size * n > 200 << 20: continue
         cp = corpus.build_corpus("json", 4, [size] * n)
-        a, b, c = t(cp, 1), t(cp, 3), t(cp, 6)
+        a, b = t(cp, 1), t(cp, 3); c = float("nan")  # (mode 6 is gone: see profiles/r03_small_policy.txt for its last measurement)
         print("%-8d %-7d %12.3f %12.3f %12.3f   %.1f" % (size, n, a, b, c, size * n / min(a, b, c) / 1e-3 / 2**30), flush=True)
