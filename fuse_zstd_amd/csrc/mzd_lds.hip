@@ -253,19 +253,19 @@ DI bool build_fse_lane(uint32_t tab_off, uint32_t norm_off, uint32_t nsym, uint3
     uint32_t high = size;
     for (uint32_t s = 0; s < nsym; s++) // "less than one": a single state at the top, numbered 1 -> nbBits = log, next-state base 0
         if (L16s(norm_off + 2 * s) == -1) { high--; L64(tab_off + 8 * high) = fse_entry(tab_off, 0, log, s, extra_of(s)); }
-    // pass 1
+    // pass 1 (the count of the symbol after the current one is always in flight: stepping to the next symbol waits for nothing)
     {
-        uint32_t pos = 0, s = 0xFFFFFFFFu, val = 0;
-        int32_t left = 0;
+        uint32_t pos = 0, s = 0xFFFFFFFFu;
+        int32_t left = 0, ahead = nsym ? (int32_t)L16s(norm_off) : 0; // ahead = count of symbol s + 1
         bool over = false;
         for (uint32_t j = 0; j < high; j++) {
             while (left <= 0 && !over) { // the next symbol that has states (at most nsym steps in all)
                 s++;
                 over = s >= nsym;
-                left = over ? 1 : (int32_t)L16s(norm_off + 2 * s);
-                val = over ? 0u : (s | (extra_of(s) << 8));
+                left = over ? 1 : ahead;
+                ahead = s + 1 < nsym ? (int32_t)L16s(norm_off + 2 * (s + 1)) : 0;
             }
-            L32(tab_off + 8 * pos) = val;
+            L32(tab_off + 8 * pos) = s;
             left--;
             do { pos = (pos + step) & mask; } while (pos >= high);
         }
@@ -274,23 +274,22 @@ DI bool build_fse_lane(uint32_t tab_off, uint32_t norm_off, uint32_t nsym, uint3
         for (s++; s < nsym; s++) if (L16s(norm_off + 2 * s) > 0) return false;
     }
     // pass 2
-    auto number = [&](uint32_t i, uint32_t v, uint32_t old) {
-        const uint32_t s = v & 0xFF, extra = v >> 8;
+    auto number = [&](uint32_t i, uint32_t s, uint32_t old, uint32_t extra) {
         const uint32_t d = (old >> (16 * (s & 1))) & 0xFFFF;
         const uint32_t nb = log - (uint32_t)hibit32(d | 1u);
         L64(tab_off + 8 * i) = fse_entry(tab_off, (d << nb) - size, nb, s, extra);
     };
-    auto bump = [&](uint32_t v) -> uint32_t {
-        const uint32_t s = v & 0xFF;
+    auto bump = [&](uint32_t s) -> uint32_t {
         return __hip_atomic_fetch_add(static_cast<uint32_t*>(__builtin_assume_aligned(lds + norm_off + 2 * (s & ~1u), 4)), 1u << (16 * (s & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     uint32_t i = 0;
     for (; i + 4 <= high; i += 4) {
         const uint32_t v0 = L32(tab_off + 8 * i), v1 = L32(tab_off + 8 * i + 8), v2 = L32(tab_off + 8 * i + 16), v3 = L32(tab_off + 8 * i + 24);
         const uint32_t o0 = bump(v0), o1 = bump(v1), o2 = bump(v2), o3 = bump(v3);
-        number(i, v0, o0); number(i + 1, v1, o1); number(i + 2, v2, o2); number(i + 3, v3, o3);
+        const uint32_t x0 = extra_of(v0), x1 = extra_of(v1), x2 = extra_of(v2), x3 = extra_of(v3);
+        number(i, v0, o0, x0); number(i + 1, v1, o1, x1); number(i + 2, v2, o2, x2); number(i + 3, v3, o3, x3);
     }
-    for (; i < high; i++) { const uint32_t v = L32(tab_off + 8 * i); number(i, v, bump(v)); }
+    for (; i < high; i++) { const uint32_t v = L32(tab_off + 8 * i); number(i, v, bump(v), extra_of(v)); }
     return true;
 }
 
@@ -343,6 +342,62 @@ __device__ __noinline__ void rare_match(uint32_t outo, uint32_t mp, uint32_t off
     asm volatile("" ::: "memory");
 }
 
+// The state walk's hot form, hand-scheduled (mzd_k_walk.h's step with per-lane tables: an entry's low word is the LDS address of its
+// next-state base, so the new state's address is low + 8 * bits; bit positions are LDS bit addresses).  One call walks N sequences and
+// records each one's state {LL, ML, OF entry addresses, read head - 32} in the ring (16 bytes a sequence) before stepping over it.
+// Per step: the three entries (ds_read_b64) and the aligned dword pair that holds the read head (32..63 of its bits lie below the
+// head), issued together; then the bit budget from the entries' second bytes (SDWA), one 64-bit shift, three field extracts, three
+// shift-adds -- ~20 instructions against the compiler's 27, and the next step's reads are in flight before this step's record is
+// stored.  A step whose sequence is wider than the window leaves `slack` negative: the caller takes the whole step again with
+// the C++ form from the state it saved.  LDS addresses are spelled as they are: the dynamic LDS segment must start at 0 (checked).
+#define MZD_SDWA_B1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define MZD_LW_READS \
+    "ds_read_b64 v[48:49], v86\n" \
+    "ds_read_b64 v[50:51], v85\n" \
+    "ds_read_b64 v[52:53], v84\n" \
+    "v_and_b32_e32 v71, 0x3fffc, v71\n" \
+    "ds_read2_b32 v[54:55], v71 offset1:1\n"
+#define MZD_LW_STEP(SH) \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_add3_u32 v64, v49, v51, v53\n"                 /* nbBits sums | total bits << 8 */ \
+    "v_add_u32_e32 v65, v49, v51\n"                   /* bit offset of the LL field: nbO + nbM (low 5 bits) */ \
+    "v_sub_u32_sdwa " SH ", %[av], v64" MZD_SDWA_B1   /* window bits below what this sequence consumes */ \
+    "v_sub_u32_sdwa v87, v87, v64" MZD_SDWA_B1 \
+    "v_lshrrev_b64 v[66:67], " SH ", v[54:55]\n" \
+    "v_lshrrev_b32_e32 v71, 3, v87\n" \
+    "v_bfe_u32 v64, v66, 0, v49\n" \
+    "v_bfe_u32 v69, v66, v49, v51\n" \
+    "v_bfe_u32 v70, v66, v65, v53\n" \
+    "v_lshl_add_u32 v86, v64, 3, v48\n" \
+    "v_lshl_add_u32 v85, v69, 3, v50\n" \
+    "v_lshl_add_u32 v84, v70, 3, v52\n"
+#define MZD_LW_NEXT(RECOFF) MZD_LW_READS "ds_write_b128 %[ring], v[84:87] offset:" RECOFF "\n" "v_and_or_b32 %[av], v87, 31, 32\n"
+#define MZD_LW_PAIR(R1, R2) MZD_LW_STEP("%[sa]") MZD_LW_NEXT(R1) MZD_LW_STEP("%[sb]") MZD_LW_NEXT(R2) "v_min3_i32 %[slack], %[slack], %[sa], %[sb]\n"
+#define MZD_LW_LAST(R1) MZD_LW_STEP("%[sa]") MZD_LW_NEXT(R1) MZD_LW_STEP("%[sb]") "v_min3_i32 %[slack], %[slack], %[sa], %[sb]\n"
+template <int N>
+DI void walk_asm(uint32_t& aL, uint32_t& aM, uint32_t& aO, uint32_t& Gm, int32_t& slack, uint32_t ring) {
+    uint32_t av, sa, sb;
+#define MZD_LW_HEAD \
+        "v_mov_b32_e32 v84, %[aL]\n v_mov_b32_e32 v85, %[aM]\n v_mov_b32_e32 v86, %[aO]\n v_mov_b32_e32 v87, %[Gm]\n" \
+        "v_lshrrev_b32_e32 v71, 3, v87\n" \
+        MZD_LW_READS \
+        "ds_write_b128 %[ring], v[84:87]\n" \
+        "v_and_or_b32 %[av], v87, 31, 32\n"
+#define MZD_LW_TAIL \
+        "v_mov_b32_e32 %[aL], v84\n v_mov_b32_e32 %[aM], v85\n v_mov_b32_e32 %[aO], v86\n v_mov_b32_e32 %[Gm], v87\n"
+#define MZD_LW_OPS \
+        : [aL] "+v"(aL), [aM] "+v"(aM), [aO] "+v"(aO), [Gm] "+v"(Gm), [slack] "+v"(slack), [av] "=&v"(av), [sa] "=&v"(sa), [sb] "=&v"(sb) \
+        : [ring] "v"(ring) \
+        : "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v69", "v70", "v71", "v84", "v85", "v86", "v87", "memory"
+    if constexpr (N == 16)
+        asm volatile(MZD_LW_HEAD MZD_LW_PAIR("16", "32") MZD_LW_PAIR("48", "64") MZD_LW_PAIR("80", "96") MZD_LW_PAIR("112", "128")
+                     MZD_LW_PAIR("144", "160") MZD_LW_PAIR("176", "192") MZD_LW_PAIR("208", "224") MZD_LW_LAST("240") MZD_LW_TAIL MZD_LW_OPS);
+    else if constexpr (N == 8)
+        asm volatile(MZD_LW_HEAD MZD_LW_PAIR("16", "32") MZD_LW_PAIR("48", "64") MZD_LW_PAIR("80", "96") MZD_LW_LAST("112") MZD_LW_TAIL MZD_LW_OPS);
+    else
+        asm volatile(MZD_LW_HEAD MZD_LW_PAIR("16", "32") MZD_LW_LAST("48") MZD_LW_TAIL MZD_LW_OPS);
+}
+
 struct DictInfo { // the dictionary whose image sits in LDS (wave-uniform)
     uint32_t handle, formatted, dict_id, content_len, huf_log;
     uint32_t al[3], rep[3];
@@ -374,6 +429,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
     di.handle = 0; di.formatted = 0; di.dict_id = 0; di.content_len = 0; di.huf_log = 0; di.content = nullptr;
     for (int t = 0; t < 3; t++) { di.al[t] = 0; di.rep[t] = 0; }
 
+    const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds == 0; // (walk_asm spells LDS addresses out)
     const uint32_t ngroups = (a.n + G - 1) / G;
     bool first_group = true;
     (void)first_group;
@@ -920,7 +976,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                 // ---- the walk
                 uint32_t wbad = 0;
                 if (act && leader) {
-                    auto record = [&](uint32_t k) { *reinterpret_cast<uint4*>(lds + ringo + 16 * k) = make_uint4(aL, aM, aO, Gh); };
+                    auto record = [&](uint32_t k) { *reinterpret_cast<uint4*>(lds + ringo + 16 * k) = make_uint4(aL, aM, aO, Gh - 32); };
                     auto step = [&]() {
                         const uint32_t e = (Gh + 7) >> 3;
                         const uint64_t X = lds_u64(e - 8); // the 57..64 bits below the read head
@@ -937,8 +993,17 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         Gh -= tot;
                     };
                     if (c0 + LPF < nrun) { // every sequence of the step is followed by a state update
+                        bool done_asm = false;
+                        if (lds_at_zero) {
+                            uint32_t xL = aL, xM = aM, xO = aO, xG = Gh - 32;
+                            int32_t slack = 64;
+                            walk_asm<(int)LPF>(xL, xM, xO, xG, slack, ringo);
+                            if (slack >= 0) { aL = xL; aM = xM; aO = xO; Gh = xG + 32; done_asm = true; } // (else: a sequence wider than 32..63 bits met the window's edge)
+                        }
+                        if (!done_asm) {
 #pragma unroll
-                        for (uint32_t k = 0; k < LPF; k++) { record(k); step(); }
+                            for (uint32_t k = 0; k < LPF; k++) { record(k); step(); }
+                        }
                     } else { // the file's last step
                         const uint32_t cnt = nrun - c0;
                         for (uint32_t k = 0; k < cnt; k++) { record(k); if (k + 1 < cnt) step(); }
@@ -955,7 +1020,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     const uint32_t xL = hL >> 24, xM = hM >> 24, xO = hO >> 24;
                     const uint32_t cL = (hL >> 16) & 0xFF, cM = (hM >> 16) & 0xFF, cO = (hO >> 16) & 0xFF;
                     const uint32_t xs = xL + xM + xO;
-                    const uint32_t tL = r.w - xs; // bottom of the LL field
+                    const uint32_t tL = r.w + 32 - xs; // bottom of the LL field (the record holds the read head - 32)
                     if ((int32_t)(tL - G0) < 0 || xs + (tL & 7) > 64) pbad = 1;
                     uint64_t W = lds_u64(tL >> 3) >> (tL & 7);
                     const uint32_t vL = (uint32_t)W & (uint32_t)((1ull << xL) - 1); W >>= xL;
