@@ -194,6 +194,12 @@ __device__ __forceinline__ void clean_next_counters(const KernelArgs& a, int tid
 // than one block (every output capacity <= 128 KiB): nothing is forked, nothing is published, the file's state
 // stays in registers and LDS.
 __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) {
+    // A workgroup's first ticket is its own index: one past the queue's end has nothing to do -- the launch behind the small-file
+    // kernel when that kernel handed nothing on.  Leaving at once keeps most of the kernel's private-segment stores out of HBM (1 200
+    // bytes per lane: the roles' register spills, and a copy per lane of the launch's arguments, whose address the roles take): an idle
+    // launch of 256 workgroups wrote 22.5 MB (profiles/r02_cfg4_pmc.json), now 10 (the per-lane argument copy, made on entry).  A body
+    // in a function of its own, called behind this test, brings that to 7 MB but costs the headline 3 % (measured): not taken.
+    if (blockIdx.x >= queue_len(a)) { clean_next_counters(a, threadIdx.x); return; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t slot = a.wg0 + blockIdx.x; // this workgroup's place in the scratch arrays
     uint8_t* const lit_buf = a.lit_scratch + (size_t)slot * kLitStride;
@@ -359,7 +365,6 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
     }
     clean_next_counters(a, tid);
 }
-
 
 // ---- driver 2: block tasks (the hand-over helpers are above, in front of the shared block pipeline)
 __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) {
