@@ -72,3 +72,21 @@ def test_round_robin_sharding_two_gloo_ranks(tmp_path):
         assert p.returncode == 0, se.decode()[-2000:]
     lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]
     assert len(lines) == 2
+
+
+def test_recorded_two_rank_bench_line_carries_per_rank():
+    """profiles/r03_rehearsal.json is the rank-0 line of `bench.py --gpus 2` run as two ranks on a one-GPU box (gloo
+    collectives, MZD_BENCH_REHEARSAL=1).  Its value means nothing; the N > 1 line's shape is what the driver's scaling
+    runs rely on: whole-job value, one entry per rank, weak scaling, the bench contract's keys."""
+    import json
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_rehearsal.json")
+    d = json.load(open(p))
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "GiB/s" and d["verified_byte_exact"] is True
+    pr = d["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1]
+    assert all(r["value"] > 0 and r["kernel_ms"] > 0 and 0 < r["roofline_frac"] < 1 for r in pr)
+    assert d["config"]["files_total"] == 2 * d["config"]["files_per_gpu"]
+    # the whole-job value is total bytes over the slowest rank's time: at least the slower rank's own rate, at most the sum
+    assert min(r["value"] for r in pr) <= d["value"] <= sum(r["value"] for r in pr) * 1.001
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d
