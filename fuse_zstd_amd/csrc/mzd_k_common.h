@@ -50,8 +50,8 @@ struct Ctl {
 constexpr uint32_t kResSymMax = 30;
 struct __attribute__((aligned(16))) Shared {
     uint8_t ring[kRingBytes + 16]; // first: at LDS offset 0 the walker's window address needs no base add
-    // FSE decode entries, 8 bytes: low dword = byte offset of the next state's entry before the
-    // fresh bits are added (8 * nextStateBase); high dword = nbBits | (extra+nbBits) << 8 | symbol << 16 | extra << 24
+    // FSE decode entries, 8 bytes: low dword = LDS address (offset into S) of the next state's entry before the
+    // fresh bits are added (table + 8 * nextStateBase); high dword = nbBits | (extra+nbBits) << 8 | symbol << 16 | extra << 24
     uint64_t ll[512];
     uint64_t ml[512];
     uint64_t of[256];
@@ -71,6 +71,7 @@ struct __attribute__((aligned(16))) Shared {
                                     // copier's literal scratch (kLitScratch): the copying wavefront is the one that decodes the weights, earlier
     uint32_t wtab[64];  // sym | nb << 8 | base << 16
     uint8_t weights[256];
+    uint64_t walk_dummy; // {its own address, 0}: the entry the walker's fourth lane follows (mzd_k_walk.h); outside what mzd_k_resolve.h overlays
     Ctl c;
     // driver 1, files of one block: while the copier and the hasher finish file A, the idle walking wavefront takes the
     // next file and parses its headers into `c2` (header bytes staged in a free part of the ring)
@@ -91,6 +92,9 @@ struct __attribute__((aligned(16))) Shared {
 // instructions and immediate offsets (a `Shared&` parameter would be a flat pointer).
 static_assert(sizeof(Shared) <= 40 * 1024, "four workgroups per CU");
 __shared__ Shared S;
+constexpr uint32_t kLdsLL = (uint32_t)offsetof(Shared, ll), kLdsML = (uint32_t)offsetof(Shared, ml), kLdsOF = (uint32_t)offsetof(Shared, of);
+constexpr uint32_t kLdsWalkDummy = (uint32_t)offsetof(Shared, walk_dummy);
+__device__ __forceinline__ uint64_t lds_entry(uint32_t state_addr) { uint64_t v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(&S) + state_addr, 8); return v; }
 
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 __device__ __forceinline__ uint32_t ld24(const uint8_t* p) { return ld16(p) | ((uint32_t)p[2] << 16); }

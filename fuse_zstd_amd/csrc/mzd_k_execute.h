@@ -50,6 +50,15 @@ __device__ __forceinline__ uint32_t rep_eval(RepOp f, int j, uint32_t r0, uint32
     return (src == 3 ? 0u : in) + (uint32_t)v;
 }
 
+// The same chain as a scan over REFERENCES (plan_wave's common case): a transform is three bytes -- new slot j holds old slot b (b = 0..2)
+// or the offset value lane k brought (0x40 | k); byte 3 is 3 so that the identity is v_perm's identity selector.
+constexpr uint32_t kRefId = 0x03020100u;
+__device__ __forceinline__ uint32_t ref_compose(uint32_t later, uint32_t earlier) {
+    const uint32_t p = __builtin_amdgcn_perm(0u, earlier, later); // later's bytes select among earlier's ...
+    const uint32_t mask = ((later & 0x00404040u) >> 6) * 0xFFu;   // ... except where they are lanes
+    return (later & mask) | (p & ~mask);
+}
+
 // Per-lane copies of n (<= 64) bytes, 8 bytes at a time plus one (over-reading) 8-byte tail word stored
 // as exact 4/2/1 pieces.  On a SIMD machine every step costs issue slots whether or not a lane takes
 // part, so the chunk loops stop at the longest copy in the wavefront (wave-uniform `__any` exits:
@@ -160,7 +169,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
     auto issue_bits = [&](uint4 w, bool live, Win& o) {
         const uint32_t vL = w.x, vM = w.y, vO = w.z;
         o.G = w.w + 32; // records carry the read head - 32
-        o.hL = (uint32_t)(S.ll[vL >> 3] >> 32); o.hM = (uint32_t)(S.ml[vM >> 3] >> 32); o.hO = (uint32_t)(S.of[vO >> 3] >> 32);
+        o.hL = (uint32_t)(lds_entry(vL) >> 32); o.hM = (uint32_t)(lds_entry(vM) >> 32); o.hO = (uint32_t)(lds_entry(vO) >> 32); // (records hold state addresses)
         o.bO = 0; o.bM = 0; o.bL = 0;
         if (live) {
             const uint32_t xM = o.hM >> 24, xO = o.hO >> 24, xL = o.hL >> 24;
@@ -202,9 +211,48 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         win = next; recB = recC;
         // ---- repeat offsets
         uint32_t off;
-        {
-            RepOp op;
-            uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
+        const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u); // (meaningful when ofv <= 3)
+        if (!__any(valid && ofv <= 3 && idx == 3)) {
+            // The common chunk (no "repeat 0 minus one", the only rule that makes a new VALUE out of the state): the scan runs over
+            // REFERENCES, not values.  The state before a sequence is three bytes, each the chunk's start slot 0..2 or "the offset lane k
+            // brought" (0x40 | k); a sequence permutes / pushes that triple, and composing two of them is one v_perm_b32 + a byte merge
+            // (ref_compose) instead of the ~45 instructions of the value-carrying rep_compose (this scan was half of the planner's VALU work).
+            const uint32_t pushv = ofv - 3;
+            uint32_t T = kRefId;
+            if (valid) {
+                if (ofv > 3) T = 0x03010040u | (uint32_t)lane;
+                else if (idx == 1) T = 0x03020001u;
+                else if (idx == 2) T = 0x03010002u;
+            }
+            const uint32_t P = wave_incl_scan_op(T, kRefId, [](uint32_t earlier, uint32_t later) { return ref_compose(later, earlier); });
+            uint32_t Ex = __shfl_up(P, 1);
+            if (lane == 0) Ex = kRefId;
+            // the chunk's start slots as the plan spells them: a plain value, or "block start slot + delta" (uniform)
+            const uint32_t r_s = __builtin_amdgcn_readfirstlane(R.s);
+            const int32_t r_v0 = __builtin_amdgcn_readfirstlane(R.v0), r_v1 = __builtin_amdgcn_readfirstlane(R.v1), r_v2 = __builtin_amdgcn_readfirstlane(R.v2);
+            auto start_word = [&](uint32_t j, int32_t v) -> uint32_t {
+                const uint32_t src = (r_s >> (2 * j)) & 3;
+                return src == 3 ? (v > 0 ? (uint32_t)v : 0u) : off_symbolic(src, v);
+            };
+            const uint32_t w0 = start_word(0, r_v0), w1 = start_word(1, r_v1), w2 = start_word(2, r_v2);
+            const uint32_t slot = idx == 1 ? 1u : (idx == 2 ? 2u : 0u);
+            const uint32_t ref = (Ex >> (8 * slot)) & 0xFF;
+            const uint32_t from_lane = (uint32_t)__shfl((int)pushv, (int)(ref & 63));
+            const uint32_t from_start = (uint32_t)sel3(ref & 3, (int32_t)w0, (int32_t)w1, (int32_t)w2);
+            off = ofv > 3 ? pushv : ((ref & 0x40) ? from_lane : from_start);
+            // chunk end -> R of the next chunk (uniform)
+            const uint32_t PL = __builtin_amdgcn_readlane(P, 63);
+            uint32_t ns = 0;
+            int32_t nv[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const uint32_t b = (PL >> (8 * j)) & 0xFF;
+                if (b & 0x40) { ns |= 3u << (2 * j); nv[j] = (int32_t)__builtin_amdgcn_readlane(pushv, b & 63); }
+                else { ns |= ((r_s >> (2 * (b & 3))) & 3) << (2 * j); nv[j] = sel3(b & 3, r_v0, r_v1, r_v2); }
+            }
+            R.s = ns; R.v0 = nv[0]; R.v1 = nv[1]; R.v2 = nv[2];
+        } else {
+            RepOp op; // (a chunk that holds a "repeat 0 minus one": the value-carrying scan)
             if (!valid || (ofv <= 3 && idx == 0)) { op.s = 0 | (1 << 2) | (2 << 4); op.v0 = 0; op.v1 = 0; op.v2 = 0; }
             else if (ofv > 3) { op.s = 3 | (0 << 2) | (1 << 4); op.v0 = (int32_t)(ofv - 3); op.v1 = 0; op.v2 = 0; }
             else if (idx == 1) { op.s = 1 | (0 << 2) | (2 << 4); op.v0 = 0; op.v1 = 0; op.v2 = 0; }

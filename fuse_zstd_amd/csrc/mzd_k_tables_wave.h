@@ -74,7 +74,7 @@ __device__ __noinline__ void build_seq_table_wave(uint64_t* tab, const int16_t* 
                 const uint32_t nb = log - (uint32_t)hibit(d);
                 const uint32_t extra = sext[sy];
                 const uint32_t hi = nb | ((extra + nb) << 8) | (sy << 16) | (extra << 24);
-                tab[i] = (uint64_t)(((d << nb) - size) * 8u) | ((uint64_t)hi << 32);
+                tab[i] = (uint64_t)(table_lds(kind) + ((d << nb) - size) * 8u) | ((uint64_t)hi << 32);
                 if ((uint32_t)lane == 63u - (uint32_t)__builtin_clzll(m)) { // the symbol's highest position in this step
                     scnt[sy] = basec + (uint32_t)__builtin_popcountll(m);
                     __atomic_store_n(&smask[sy], 0ull, __ATOMIC_RELAXED);

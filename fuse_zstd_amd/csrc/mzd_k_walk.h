@@ -69,62 +69,69 @@ constexpr uint32_t kPreStage = 2304;        // S.ring[2304 .. 3072): between the
 constexpr uint32_t kInRing = 0x80000000u;   // parse_seq_header: the staged header lies in S.ring, not in S.stage
 
 // The hot form of the chain, hand-scheduled: runs of kWalkGroup steps until n steps are done, or a group met a
-// sequence wider than its window (slack < 0: the group is void, the caller takes it again carefully from {sx, sy}, the
-// packed state at the group's start), or the read head comes within one group of the lowest resident ring chunk
-// (Gm < thresh: the caller refills).  A lone wavefront issues in order, 6.25 (4-byte encodings) to 7.5 cycles (8-byte) an instruction, and the four LDS reads
-// return through a 64 B/clk path (32 clks): a step is the 12 chain instructions + the reads' round trip, ~137 cycles
-// (tools/micro/asm_micro.hip); whatever the chain does not need -- the record store, packing the next record, the
-// slack bookkeeping, publishing progress -- sits behind the reads, in the shadow of their latency.  Same arithmetic
-// as the careful C++ step.  Progress (records visible to the planner: all but the newest kWalkLag stores have landed) is
-// published once per group.  Registers: v[48:55] the three entries and the window, v[64:71] temporaries, v[80:81]
-// the packed record (all caller-saved in the AMDGPU calling convention).  Table and ring addresses are immediates:
-// S must start at LDS address 0 (checked by the caller, which otherwise keeps the C++ form).
+// sequence wider than its window (slack < 0: the group is void, the caller takes it again carefully from the state saved
+// at the group's start), or the read head comes within one group of the lowest resident ring chunk (Gm < thresh: the caller refills).
+//
+// What a step costs on a lone wavefront is its instruction SLOTS: in-order issue, 6.25 (4-byte encodings) to 7.5 cycles (8-byte)
+// each whether the instructions depend on each other or not -- more when the other wavefronts of the SIMD are busy -- plus one LDS
+// round trip (~50 cycles).  So the three states live in three LANES of a quad (lane 0 LL, 1 ML, 2 OF; lane 3 walks a dummy entry
+// that consumes nothing and leads to itself; the 16 quads of the wavefront do the same work -- a sparse wavefront issues slower):
+// ONE table read, ONE field extract and ONE address add per step instead of three, the bit counts of the other two states come
+// through DPP quad permutes of the entry's high word (all of them read the word as loaded -- a DPP read of a register written by
+// the VALU instruction before it would need wait states).  In front of the table read: 4 DPP adds/moves, the shift amount, the
+// 64-bit shift, the field, the address = 8 VALU slots (the one-lane form: 12 + three reads).  Everything the chain does not need --
+// the read head, the next window's address and read, the record store, publishing progress -- sits behind the read, in the shadow
+// of its latency; the window is waited for separately, right before the shift (it was issued last and is needed later).
+// Same arithmetic as the careful C++ step.  The record of a step is the state as it stands: lane k of quad 0 stores dword k
+// {LL, ML, OF state address, read head - 32}.  Progress (records visible to the planner: all but the newest kWalkLag stores have
+// landed) is published once per group.  Registers: v[48:49] the lane's entry, v[54:55] the window, v[64:71] temporaries, v84 the
+// lane's state address, v87 the read head - 32.  Entries hold ABSOLUTE LDS addresses (pack_entry) and the ring's address is an
+// immediate: S must start at LDS address 0 (checked by the caller, which otherwise keeps the C++ form).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kWalkGroup = 8;
 constexpr uint32_t kWalkLag = 32;
 #define MZD_SDWA_B1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
-// v[84:87] = {LL, ML, OF state offsets, read head - 32}: the record of a step is its state, stored as it stands
+#define MZD_DPP_ALL " row_mask:0xf bank_mask:0xf\n"
 #define MZD_WALK_STEP(SH, RECOFF, TAIL) \
+    "s_waitcnt lgkmcnt(1)\n"                                             /* the entry is there (the window may still be on its way) */ \
+    "v_add_u32_dpp v64, v49, v49 quad_perm:[1,0,3,2]" MZD_DPP_ALL        /* pair sums of the high words */ \
+    "v_mov_b32_dpp v65, v49 quad_perm:[1,2,3,3]" MZD_DPP_ALL             /* the high word one lane up (lane 2: the dummy's, 0) */ \
+    "v_add_u32_dpp v65, v49, v65 quad_perm:[2,3,3,3]" MZD_DPP_ALL        /* + two lanes up: bit offset of the own field (low 5 bits): nbO + nbM, nbO, 0 */ \
+    "v_add_u32_dpp v64, v64, v64 quad_perm:[2,3,0,1]" MZD_DPP_ALL        /* all four: nbBits sums | total bits << 8 | ...  (v64: written two slots ago) */ \
+    "v_sub_u32_sdwa " SH ", %[av], v64" MZD_SDWA_B1                      /* window bits below what this sequence consumes */ \
     "s_waitcnt lgkmcnt(0)\n" \
-    "v_add3_u32 v64, v49, v51, v53\n"                 /* nbBits sums | total bits << 8 | ... */ \
-    "v_add_u32_e32 v65, v49, v51\n"                   /* bit offset of the LL field: nbO + nbM (low 5 bits) */ \
-    "v_sub_u32_sdwa " SH ", %[av], v64" MZD_SDWA_B1   /* window bits below what this sequence consumes */ \
-    "v_sub_u32_sdwa v87, v87, v64" MZD_SDWA_B1 \
     "v_lshrrev_b64 v[66:67], " SH ", v[54:55]\n" \
+    "v_bfe_u32 v69, v66, v65, v49\n"                                     /* the lane's fresh state bits: width = nbBits, the low bits of the entry */ \
+    "v_lshl_add_u32 v84, v69, 3, v48\n" \
+    "ds_read_b64 v[48:49], v84\n" \
+    "v_sub_u32_sdwa v87, v87, v64" MZD_SDWA_B1                           /* (behind the read from here on) the read head */ \
     "v_lshrrev_b32_e32 v71, 3, v87\n" \
-    "v_bfe_u32 v64, v66, 0, v49\n" \
-    "v_bfe_u32 v69, v66, v49, v51\n" \
-    "v_bfe_u32 v70, v66, v65, v53\n" \
-    "v_lshl_add_u32 v86, v64, 3, v48\n" \
-    "v_lshl_add_u32 v85, v69, 3, v50\n" \
-    "v_lshl_add_u32 v84, v70, 3, v52\n" \
-    "ds_read_b64 v[48:49], v86 offset:%[oO]\n" \
-    "ds_read_b64 v[50:51], v85 offset:%[oM]\n" \
-    "ds_read_b64 v[52:53], v84 offset:%[oL]\n" \
     "v_and_b32_e32 v71, 0x1ffc, v71\n" \
     "ds_read2_b32 v[54:55], v71 offset1:1\n" \
-    "global_store_dwordx4 %[woff], v[84:87], %[base] offset:" RECOFF "\n" /* the NEXT step's record: the state as it is now */ \
+    "v_cndmask_b32_e64 v70, v84, v87, %[l3]\n" \
+    "global_store_dword %[woff], v70, %[base] offset:" RECOFF "\n"       /* the NEXT step's record: the state as it is now */ \
     "v_and_or_b32 %[av], v87, 31, 32\n" \
     TAIL
 #define MZD_WALK_SLACK "v_min3_i32 %[slack], %[slack], %[sa], %[sb]\n"
-__device__ __forceinline__ void walk_run_asm(uint32_t& vL, uint32_t& vM, uint32_t& vO, uint32_t& Gm, uint32_t& woff, int32_t& slack, uint32_t& n,
-                                             int32_t pv, uint4& start, int32_t thresh, uint32_t prog_lds,
+// A: the lane's state address (lane & 3: LL, ML, OF, the dummy); woff: byte offset of the lane's dword of the next record
+__device__ __forceinline__ void walk_run_asm(uint32_t& A, uint32_t& Gm, uint32_t& woff, int32_t& slack, uint32_t& n,
+                                             int32_t pv, uint32_t& startA, uint32_t& startG, int32_t thresh, uint32_t prog_lds,
                                              __attribute__((address_space(1))) uint8_t* gwalk) {
     static_assert(kRingBytes - 4 == 0x1ffc && offsetof(Shared, ring) == 0, "the window address mask / the ring's place are spelled out in MZD_WALK_STEP");
     static_assert(kWalkGroup == 8 && kWalkLag == 32, "spelled out below");
     uint32_t av, sa, sb;
+    const uint64_t l3 = 0x8888888888888888ull; // lane 3 of every quad: its record dword is the read head
     asm volatile(
-        "v_mov_b32_e32 v84, %[vL]\n v_mov_b32_e32 v85, %[vM]\n v_mov_b32_e32 v86, %[vO]\n v_mov_b32_e32 v87, %[Gm]\n"
+        "v_mov_b32_e32 v84, %[A]\n v_mov_b32_e32 v87, %[Gm]\n"
         "v_lshrrev_b32_e32 v71, 3, v87\n"
-        "ds_read_b64 v[48:49], v86 offset:%[oO]\n"
-        "ds_read_b64 v[50:51], v85 offset:%[oM]\n"
-        "ds_read_b64 v[52:53], v84 offset:%[oL]\n"
+        "ds_read_b64 v[48:49], v84\n"
         "v_and_b32_e32 v71, 0x1ffc, v71\n"
         "ds_read2_b32 v[54:55], v71 offset1:1\n"
-        "global_store_dwordx4 %[woff], v[84:87], %[base]\n" // the first step's record
+        "v_cndmask_b32_e64 v70, v84, v87, %[l3]\n"
+        "global_store_dword %[woff], v70, %[base]\n" // the first step's record
         "v_and_or_b32 %[av], v87, 31, 32\n"
         "1:\n"
-        "v_mov_b32_e32 %[s0], v84\n v_mov_b32_e32 %[s1], v85\n v_mov_b32_e32 %[s2], v86\n v_mov_b32_e32 %[s3], v87\n" // the group's starting state (the reads are in flight)
+        "v_mov_b32_e32 %[s0], v84\n v_mov_b32_e32 %[s3], v87\n" // the group's starting state (the reads are in flight)
         MZD_WALK_STEP("%[sa]", "16", "")
         MZD_WALK_STEP("%[sb]", "32", MZD_WALK_SLACK "s_waitcnt vmcnt(32)\n v_max_i32_e32 v69, 0, %[pv]\n ds_write_b32 %[prog], v69\n v_add_u32_e32 %[pv], 8, %[pv]\n") // publish
         MZD_WALK_STEP("%[sa]", "48", "")
@@ -139,12 +146,11 @@ __device__ __forceinline__ void walk_run_asm(uint32_t& vL, uint32_t& vM, uint32_
         "s_cbranch_scc1 1b\n"
         "2:\n"
         "s_waitcnt lgkmcnt(0)\n" // (the reads issued by the last step: nothing may be in flight into v[48:55] past this block)
-        "v_mov_b32_e32 %[vL], v84\n v_mov_b32_e32 %[vM], v85\n v_mov_b32_e32 %[vO], v86\n v_mov_b32_e32 %[Gm], v87\n"
-        : [vL] "+v"(vL), [vM] "+v"(vM), [vO] "+v"(vO), [Gm] "+v"(Gm), [woff] "+v"(woff), [slack] "+v"(slack), [av] "=&v"(av), [n] "+s"(n),
-          [pv] "+v"(pv), [s0] "=&v"(start.x), [s1] "=&v"(start.y), [s2] "=&v"(start.z), [s3] "=&v"(start.w), [sa] "=&v"(sa), [sb] "=&v"(sb)
-        : [base] "s"(gwalk), [thresh] "s"(thresh), [prog] "v"(prog_lds),
-          [oL] "n"(offsetof(Shared, ll)), [oM] "n"(offsetof(Shared, ml)), [oO] "n"(offsetof(Shared, of))
-        : "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v84", "v85", "v86", "v87", "vcc", "scc", "memory");
+        "v_mov_b32_e32 %[A], v84\n v_mov_b32_e32 %[Gm], v87\n"
+        : [A] "+v"(A), [Gm] "+v"(Gm), [woff] "+v"(woff), [slack] "+v"(slack), [av] "=&v"(av), [n] "+s"(n),
+          [pv] "+v"(pv), [s0] "=&v"(startA), [s3] "=&v"(startG), [sa] "=&v"(sa), [sb] "=&v"(sb)
+        : [base] "s"(gwalk), [thresh] "s"(thresh), [prog] "v"(prog_lds), [l3] "s"(l3)
+        : "v48", "v49", "v54", "v55", "v64", "v65", "v66", "v67", "v69", "v70", "v71", "v84", "v87", "vcc", "scc", "memory");
 }
 
 __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, uint32_t nseq_in, uint4* walk, uint32_t* prog, int lane) {
@@ -184,11 +190,11 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         vO = alO ? (uint32_t)(B >> (64 - alO)) : 0; B <<= alO;
         vM = alM ? (uint32_t)(B >> (64 - alM)) : 0;
         G -= n;
-        vL *= 8; vO *= 8; vM *= 8;
+        vL = vL * 8 + kLdsLL; vO = vO * 8 + kLdsOF; vM = vM * 8 + kLdsML; // state addresses (entries hold addresses: pack_entry)
     }
-    const uint8_t* const tL = reinterpret_cast<const uint8_t*>(S.ll);
-    const uint8_t* const tM = reinterpret_cast<const uint8_t*>(S.ml);
-    const uint8_t* const tO = reinterpret_cast<const uint8_t*>(S.of);
+    const uint8_t* const tL = reinterpret_cast<const uint8_t*>(&S); // (one base: the states are offsets into S)
+    const uint8_t* const tM = tL;
+    const uint8_t* const tO = tL;
     uint32_t i = 0;
     const uint32_t nupd = nseq - 1; // sequences followed by a state update
     const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)S.ring == 0; // (walk_run_asm spells LDS addresses out)
@@ -230,11 +236,19 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         Gm -= total;
     };
     constexpr int32_t kLook = (int32_t)(kWalkGroup * 12 + 24) * 8; // bits a group can consume (<= 89 a sequence) + the window above the head
+#if defined(MZD_STAMPS) && defined(MZD_EXP_WALKSTAT)
+    uint64_t ws_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_ = __builtin_readcyclecounter(), wu_;
+#define WSTAT(k, cnt) do { wu_ = __builtin_readcyclecounter(); ws_[k] += wu_ - wt_; wt_ = wu_; ws_[(k) + 1] += (cnt); } while (0)
+#else
+#define WSTAT(k, cnt)
+#endif
     while (i < nupd) {
+        WSTAT(6, 0);
         // keep the ring one group ahead of the read head
         while (st.lowest > 0 && (int32_t)Gm < st.lowest * (int32_t)(kChunk * 8) + kLook) {
             st.lowest--;
             ring_load_chunk(st, st.lowest, lane);
+            WSTAT(0, 1);
         }
         const uint32_t left = nupd - i;
         if (lds_at_zero && left >= kWalkGroup) {
@@ -245,14 +259,20 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
             //  records younger than kWalkLag are not published, so stopping at the group's end is early enough)
             const int32_t thresh = __builtin_amdgcn_readfirstlane(st.lowest > 0 ? st.lowest * (int32_t)(kChunk * 8) + kLook : (int32_t)Gzero - 32);
             int32_t slack = 64; // minimum over a group of (window bits - bits needed)
-            uint4 start;
-            walk_run_asm(vL, vM, vO, Gm, woff, slack, n, (int32_t)i - (int32_t)kWalkLag, start, thresh, prog_lds, gwalk);
+            const uint32_t q = (uint32_t)lane & 3;
+            uint32_t A = q == 0 ? vL : (q == 1 ? vM : (q == 2 ? vO : kLdsWalkDummy));
+            uint32_t wl = woff + 4 * q, startA, startG;
+            walk_run_asm(A, Gm, wl, slack, n, (int32_t)i - (int32_t)kWalkLag, startA, startG, thresh, prog_lds, gwalk);
             i += n0 - n;
+            woff += 16 * (n0 - n);
+            vL = __builtin_amdgcn_readlane(A, 0); vM = __builtin_amdgcn_readlane(A, 1); vO = __builtin_amdgcn_readlane(A, 2);
+            WSTAT(2, 1);
             if (__builtin_amdgcn_ballot_w64(slack < 0) != 0) { // the last group is void: once more from its start, carefully
                 i -= kWalkGroup; woff -= 16 * kWalkGroup;
-                vL = start.x; vM = start.y; vO = start.z; Gm = start.w;
+                vL = __builtin_amdgcn_readlane(startA, 0); vM = __builtin_amdgcn_readlane(startA, 1); vO = __builtin_amdgcn_readlane(startA, 2); Gm = startG;
                 for (uint32_t k = 0; k < kWalkGroup; k++) careful_step();
                 i += kWalkGroup;
+                WSTAT(4, 1);
             }
         } else {
             const uint32_t stop = left < kWalkGroup ? nupd : i + kWalkGroup;
@@ -260,6 +280,9 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         }
         if ((int32_t)(Gm + 32 - Gzero) < 0) return MZD_E_CORRUPT; // over-read
     }
+#if defined(MZD_STAMPS) && defined(MZD_EXP_WALKSTAT)
+    if (lane == 0) for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = ws_[k_];
+#endif
     G = Gm + 32;
     // last sequence: extra bits only
     {

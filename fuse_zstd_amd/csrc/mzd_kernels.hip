@@ -78,8 +78,10 @@ namespace mzd {
 #define STAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
 #define STAMP_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 8; k_++) { a.debug[a.wg0 + blockIdx.x].stamp[k_] = st_acc[k_]; a.debug[a.wg0 + blockIdx.x].cstamp[k_] = S.cdiag[k_]; } a.debug[a.wg0 + blockIdx.x].stamp[2] = S.c.diag_slow; } } while (0)
 #define CSTAMP_DECL uint64_t cs_prev = __builtin_readcyclecounter()
+#ifdef MZD_EXP_WALKSTAT // (the copier's slots show the walker's statistics instead: tools/stamps.py prints them raw)
+#define CSTAMP(k) do { } while (0)
+#else
 #define CSTAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); if (lane == 0) S.cdiag[k] += t_ - cs_prev; cs_prev = t_; } while (0)
-#if 0
 #endif
 #else
 #define STAMP_DECL
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
+    if (tid == 0) S.walk_dummy = kLdsWalkDummy; // {own address, no bits}: what the walker's fourth lane follows
     if (tid == 0) { c.lds_dict_fse = 0; c.lds_dict_huf = 0; S.pre_job = kNoJob; S.pre_valid = 0; S.dcache.id = 0; S.took_first = 0; }
 
     for (;;) {
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) 
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
+    if (tid == 0) S.walk_dummy = kLdsWalkDummy; // {own address, no bits}: what the walker's fourth lane follows
     if (tid == 0) S.took_first = 0;
 
     for (;;) {

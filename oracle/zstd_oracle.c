@@ -376,6 +376,9 @@ static int decode_sequences(dctx* d, scratch* sc, const uint8_t* src, size_t n, 
     used = seq_table(&d->of, ofm, p, (size_t)(end - p), 8, 31, OF_DEF, 29, 5, d->fse_valid); CHECK(used >= 0, OZS_E_CORRUPT); p += used;
     used = seq_table(&d->ml, mlm, p, (size_t)(end - p), 9, 52, ML_DEF, 53, 6, d->fse_valid); CHECK(used >= 0, OZS_E_CORRUPT); p += used;
     d->fse_valid = 1; /* libzstd sets fseEntropy once a block with sequences is decoded */
+#ifdef OZS_SEQ_HOOK /* experiments under tests/native include this file and look at the tables and the bitstream here */
+    OZS_SEQ_HOOK(&d->ll, &d->of, &d->ml, p, (size_t)(end - p), nseq);
+#endif
     bbr b; CHECK(bbr_init(&b, p, (size_t)(end - p)) == 0, OZS_E_CORRUPT);
     uint32_t sll = bbr_read(&b, d->ll.log), sof = bbr_read(&b, d->of.log), sml = bbr_read(&b, d->ml.log);
     CHECK(b.pos >= 0, OZS_E_CORRUPT);

@@ -22,6 +22,10 @@ for nm, v in zip(names, st[:8]):
     print("%-22s %10d cycles %5.1f%%" % (nm, v, 100.0 * v / max(tot, 1)))
 cn = ["wait plan", "loop top", "chunk setup + classify + issue HBM loads", "lit/old-match regs -> LDS (waits for the loads)", "matches from previous runs (LDS) / big (HBM)", "rounds LDS->LDS", "fence before flush", "flush"]
 print("cycles after block start: tables ready %d, literals ready %d, walker done %d, planner done %d, copier done %d, hasher done %d" % (st[21], st[20], st[16], st[19], st[17], st[18]))
+if os.environ.get("MZD_WALKSTAT"):  # (a build with -DMZD_STAMPS -DMZD_EXP_WALKSTAT: the walker's statistics in the copier's slots)
+    w = list(st[8:16])
+    print("walker: ring refills %d (%d cycles), assembly runs %d (%d cycles), void groups taken again %d (%d cycles), between %d cycles" % (w[1], w[0], w[3], w[2], w[5], w[4], w[6]))
+    sys.exit(0)
 print("copier wavefront:")
 for nm, v in zip(cn, st[8:]):
     print("   %-26s %10d cycles" % (nm, v))
