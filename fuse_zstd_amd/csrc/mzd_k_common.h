@@ -131,6 +131,10 @@ __device__ __noinline__ uint32_t bits_at(const uint8_t* p, uint32_t nbytes, int3
 // Intra-workgroup flags in LDS (the block pipeline): relaxed atomics + workgroup fences.  Every spin
 // also ends when an error is posted, and is bounded.
 __device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+// The same for a wavefront that branches on the word: all lanes read one address, but the compiler cannot know that -- a branch on the
+// loaded value counts as divergent, and every wave-uniform boolean alive across it is then merged through exec-mask arithmetic
+// (three scalar instructions each, at every join).  Reading it through readfirstlane makes value and branch uniform.
+__device__ __forceinline__ uint32_t flag_load_u(const uint32_t* p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__atomic_load_n(p, __ATOMIC_RELAXED)); }
 __device__ __forceinline__ void flag_store(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 // first error wins: a wavefront that merely gave up because another one failed must not overwrite the cause
 __device__ __forceinline__ void post_err(int32_t* err, int rc) {

@@ -156,7 +156,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         if (need > nseq) need = nseq;
         uint32_t pg = 0, it = 0;
         for (; it < (1u << 24); it++) {
-            pg = flag_load(cx.prog);
+            pg = flag_load_u(cx.prog);
             if ((pg & ~kWalkFin) >= need || (pg & kWalkFin)) break;
             __builtin_amdgcn_s_sleep(4);
         }
@@ -453,7 +453,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     auto wait_plan = [&](uint32_t nchunks_needed) -> bool { // true when that many chunks are planned
         uint32_t pg = 0, it = 0;
         for (; it < (1u << 24); it++) {
-            pg = flag_load(&S.c.plan_prog);
+            pg = flag_load_u(&S.c.plan_prog);
             if ((pg & ~kPlanFin) >= nchunks_needed || (pg & kPlanFin)) break;
             __builtin_amdgcn_s_sleep(4);
         }
@@ -467,11 +467,11 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         if (need <= lit_avail) return true;
         if (need > nlit_all) return false; // more literals than the block has (the caller tells the two failures apart)
         for (uint32_t it = 0; it < (1u << 24); it++) {
-            const uint32_t m = flag_load(&S.c.streams_mask);
+            const uint32_t m = flag_load_u(&S.c.streams_mask);
             const uint32_t k = (uint32_t)__builtin_ctz(~m); // first stream not decoded yet
-            lit_avail = k >= lit_streams ? nlit_all : S.c.s_out[k];
+            lit_avail = k >= lit_streams ? nlit_all : u32(S.c.s_out[k]);
             if (need <= lit_avail) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
-            if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return false;
+            if (flag_load_u((const uint32_t*)&S.c.err)) return false;
             __builtin_amdgcn_s_sleep(4);
         }
         post_err(&S.c.err, MZD_E_DEVICE);
@@ -523,6 +523,9 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         bool pending = r.kind() == 1;
         uint64_t pm = __ballot(pending);
         while (pm) {
+#if defined(MZD_STAMPS) && defined(MZD_EXP_ROUNDS)
+            if (lane == 0) S.c.diag_slow += 1; // (diagnostic: LDS -> LDS rounds of the block)
+#endif
             const int first = __builtin_ctzll(pm);
             const int32_t hwm = (int32_t)__builtin_amdgcn_readlane(rel_m, first);
             const bool ready = pending && r.ready_at <= hwm;
@@ -582,7 +585,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
                 CSTAMP(0);
                 const uint32_t j = base + 64 + (uint32_t)lane;
                 pe_next = j < nseq ? plan[j] : make_uint4(0, 0, 0, 0);
-            } else if (__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED) == 1) cut = true;
+            } else if (flag_load_u(&S.c.plan_too_long) == 1) cut = true;
             else return MZD_E_CORRUPT;
         }
         const bool valid = (uint32_t)lane < cnt;
@@ -703,15 +706,15 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     if (nseq) {
         uint32_t it = 0;
         for (; it < (1u << 24); it++) {
-            if (flag_load(&S.c.plan_prog) & kPlanFin) break;
+            if (flag_load_u(&S.c.plan_prog) & kPlanFin) break;
             __builtin_amdgcn_s_sleep(4);
         }
         if (it == (1u << 24)) post_err(&S.c.err, MZD_E_DEVICE);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
-        if (__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED) == 2) // only the literals after the last sequence pass the block limit: the destination's end comes first
+        if (flag_load_u((const uint32_t*)&S.c.err)) return MZD_E_CORRUPT;
+        if (flag_load_u(&S.c.plan_too_long) == 2) // only the literals after the last sequence pass the block limit: the destination's end comes first
             return exec_verdict(cap - *opos_io <= kBlockMax ? MZD_E_DSTSIZE : MZD_E_CORRUPT, nseq, lit_streams);
-        if (lpos != __atomic_load_n(&S.c.plan_lit_used, __ATOMIC_RELAXED)) return MZD_E_CORRUPT;
+        if (lpos != flag_load_u(&S.c.plan_lit_used)) return MZD_E_CORRUPT;
         if (nlit_all - lpos > cap - opos) return MZD_E_DSTSIZE;
     } else {
         if (nlit_all > kBlockMax) return MZD_E_CORRUPT;

@@ -114,7 +114,7 @@ __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint
                     exitp = walk(start, cnt, nullptr);
                     if (cnt < 256 && (uint32_t)(exitp - q1) < 15) memo_put(j, (uint32_t)(exitp - q1 + 1) | (cnt << 4));
                 }
-#ifdef MZD_STAMPS
+#if defined(MZD_STAMPS) && !defined(MZD_EXP_ROUNDS)
                 if (lane == 0) atomicAdd(&S.c.diag_slow, 1u); // diagnostic: synchronisation rounds that had to walk
 #endif
             }

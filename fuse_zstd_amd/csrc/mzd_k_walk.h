@@ -118,7 +118,7 @@ __device__ __forceinline__ void walk_run_asm(uint32_t& A, uint32_t& Gm, uint32_t
                                              int32_t pv, uint32_t& startA, uint32_t& startG, int32_t thresh, uint32_t prog_lds,
                                              __attribute__((address_space(1))) uint8_t* gwalk) {
     static_assert(kRingBytes - 4 == 0x1ffc && offsetof(Shared, ring) == 0, "the window address mask / the ring's place are spelled out in MZD_WALK_STEP");
-    static_assert(kWalkGroup == 8 && kWalkLag == 32, "spelled out below");
+    static_assert(kWalkGroup == 8 && kWalkLag == 32 && kWalkLag >= kWalkGroup + 2, "spelled out below");
     uint32_t av, sa, sb;
     const uint64_t l3 = 0x8888888888888888ull; // lane 3 of every quad: its record dword is the read head
     asm volatile(
@@ -203,7 +203,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
     // One careful step of the chain: the window moves down a dword at a time until the sequence fits (long extra-bit
     // fields: about one sequence in hundreds).  The hot form (walk_run_asm) has no such branch -- a branch on freshly
     // loaded LDS data costs ~35 cycles per sequence on a lone wavefront -- it only notes that a group met such a sequence.
-    auto careful_step = [&]() {
+    auto careful_step = [&]() -> bool { // true: the sequence was wider than the first window
         uint64_t eL, eM, eO;
         __builtin_memcpy(&eL, tL + vL, 8);
         __builtin_memcpy(&eM, tM + vM, 8);
@@ -219,6 +219,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         const uint32_t hL = (uint32_t)(eL >> 32), hM = (uint32_t)(eM >> 32), hO = (uint32_t)(eO >> 32);
         const uint32_t total = ((hL + hM + hO) >> 8) & 0xFF;
         uint32_t av = (u & 31) | 32; // bits of the window below the read head: 32..63
+        const bool wide = __builtin_amdgcn_ballot_w64(total > av) != 0;
         while (__builtin_amdgcn_ballot_w64(total > av) != 0) {
             ra = (ra - 4) & (kRingBytes - 4);
             __builtin_memcpy(&X, &S.ring[ra], 8);
@@ -234,6 +235,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         vM = (uint32_t)eM + (bM << 3);
         vL = (uint32_t)eL + (bL << 3);
         Gm -= total;
+        return wide;
     };
     constexpr int32_t kLook = (int32_t)(kWalkGroup * 12 + 24) * 8; // bits a group can consume (<= 89 a sequence) + the window above the head
 #if defined(MZD_STAMPS) && defined(MZD_EXP_WALKSTAT)
@@ -270,8 +272,8 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
             if (__builtin_amdgcn_ballot_w64(slack < 0) != 0) { // the last group is void: once more from its start, carefully
                 i -= kWalkGroup; woff -= 16 * kWalkGroup;
                 vL = __builtin_amdgcn_readlane(startA, 0); vM = __builtin_amdgcn_readlane(startA, 1); vO = __builtin_amdgcn_readlane(startA, 2); Gm = startG;
-                for (uint32_t k = 0; k < kWalkGroup; k++) careful_step();
-                i += kWalkGroup;
+                // ... up to and including the first sequence that needed the wider window (what follows goes back to the hot form)
+                for (uint32_t k = 0; k < kWalkGroup; k++) { i++; if (careful_step()) break; }
                 WSTAT(4, 1);
             }
         } else {

@@ -88,7 +88,11 @@ namespace mzd {
 #define STAMP(k)
 #define STAMP_FLUSH()
 #define CSTAMP_DECL
+#ifdef MZD_MARKS // (reading the ISA: where the copier's phases begin)
+#define CSTAMP(k) asm volatile("; ======== CSTAMP " #k)
+#else
 #define CSTAMP(k)
+#endif
 #endif
 
 
