@@ -25,8 +25,10 @@ struct DevJob {
                      // decoded (the host path: the copy back over PCIe overlaps the decode instead of following it); null: none
 };
 
-// A parsed dictionary resident in HBM (A.7): tables are stored exactly as the kernel keeps
-// them in LDS so that a frame start is a straight copy.
+// A parsed dictionary resident in HBM (A.7): tables are stored exactly as the block pipeline keeps
+// them in LDS so that a frame start is a straight copy.  An FSE entry's low word is the LDS ADDRESS of the next state's base entry
+// in that pipeline's image (mzd_k_common.h: Shared; asserted there): the small-file kernel, whose tables live elsewhere, rebases them.
+constexpr uint32_t kBlkLdsLL = 8208, kBlkLdsML = 12304, kBlkLdsOF = 16400;
 struct DevDict {
     uint64_t ll[512];
     uint64_t ml[512];

@@ -94,6 +94,7 @@ static_assert(sizeof(Shared) <= 40 * 1024, "four workgroups per CU");
 __shared__ Shared S;
 constexpr uint32_t kLdsLL = (uint32_t)offsetof(Shared, ll), kLdsML = (uint32_t)offsetof(Shared, ml), kLdsOF = (uint32_t)offsetof(Shared, of);
 constexpr uint32_t kLdsWalkDummy = (uint32_t)offsetof(Shared, walk_dummy);
+static_assert(kLdsLL == kBlkLdsLL && kLdsML == kBlkLdsML && kLdsOF == kBlkLdsOF, "mzd_device.h names the tables' places (dictionary images in HBM carry them)");
 __device__ __forceinline__ uint64_t lds_entry(uint32_t state_addr) { uint64_t v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(&S) + state_addr, 8); return v; }
 
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }

@@ -491,8 +491,8 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     di.huf_log = dd->huf_log; di.content = dd->content;
                     for (int t = 0; t < 3; t++) { di.al[t] = dd->al[t]; di.rep[t] = dd->rep[t]; }
                     if (di.formatted) { // (entries as the block pipeline keeps them: next-state offsets relative to the table -> LDS addresses)
-                        for (uint32_t i = lane; i < 512; i += 64) { L64(dict_off + kDLL + 8 * i) = dd->ll[i] + (dict_off + kDLL); L64(dict_off + kDML + 8 * i) = dd->ml[i] + (dict_off + kDML); }
-                        for (uint32_t i = lane; i < 256; i += 64) L64(dict_off + kDOF + 8 * i) = dd->of[i] + (dict_off + kDOF);
+                        for (uint32_t i = lane; i < 512; i += 64) { L64(dict_off + kDLL + 8 * i) = dd->ll[i] + (uint64_t)(int64_t)((int32_t)(dict_off + kDLL) - (int32_t)kBlkLdsLL); L64(dict_off + kDML + 8 * i) = dd->ml[i] + (uint64_t)(int64_t)((int32_t)(dict_off + kDML) - (int32_t)kBlkLdsML); } // (rebased: mzd_device.h)
+                        for (uint32_t i = lane; i < 256; i += 64) L64(dict_off + kDOF + 8 * i) = dd->of[i] + (uint64_t)(int64_t)((int32_t)(dict_off + kDOF) - (int32_t)kBlkLdsOF);
                         for (uint32_t i = lane; i < 1024; i += 64) L32(dict_off + kDHuf + 4 * i) = reinterpret_cast<const uint32_t*>(dd->huf)[i];
                     }
                 }
