@@ -121,8 +121,14 @@ __device__ __forceinline__ void walk_run_asm(uint32_t& A, uint32_t& Gm, uint32_t
     static_assert(kWalkGroup == 8 && kWalkLag == 32 && kWalkLag >= kWalkGroup + 2, "spelled out below");
     uint32_t av, sa, sb;
     const uint64_t l3 = 0x8888888888888888ull; // lane 3 of every quad: its record dword is the read head
+// The lanes that run the loop: all 64 (16 quads doing the same work) when the wavefront has its SIMD to itself -- few active lanes
+    // issue VALU work 2-4x slower there (tools/micro/exec_micro.hip) --, quad 0 alone when the launch fills the machine: with four
+    // wavefronts on the SIMD that penalty is gone, and the walkers' table reads no longer take a quarter of the CU's LDS bandwidth from
+    // the copiers (64 lanes x 8 bytes per read, twice a step, four walkers per CU).  Measured: cfg2 +2.8 %, one file alone -2.4 % -> by launch size.
+    const uint64_t lanes = gridDim.x > 512 ? 0xFull : ~0ull;
     asm volatile(
         "v_mov_b32_e32 v84, %[A]\n v_mov_b32_e32 v87, %[Gm]\n"
+        "s_mov_b64 exec, %[lanes]\n"
         "v_lshrrev_b32_e32 v71, 3, v87\n"
         "ds_read_b64 v[48:49], v84\n"
         "v_and_b32_e32 v71, 0x1ffc, v71\n"
@@ -146,10 +152,11 @@ __device__ __forceinline__ void walk_run_asm(uint32_t& A, uint32_t& Gm, uint32_t
         "s_cbranch_scc1 1b\n"
         "2:\n"
         "s_waitcnt lgkmcnt(0)\n" // (the reads issued by the last step: nothing may be in flight into v[48:55] past this block)
+        "s_mov_b64 exec, -1\n"
         "v_mov_b32_e32 %[A], v84\n v_mov_b32_e32 %[Gm], v87\n"
         : [A] "+v"(A), [Gm] "+v"(Gm), [woff] "+v"(woff), [slack] "+v"(slack), [av] "=&v"(av), [n] "+s"(n),
           [pv] "+v"(pv), [s0] "=&v"(startA), [s3] "=&v"(startG), [sa] "=&v"(sa), [sb] "=&v"(sb)
-        : [base] "s"(gwalk), [thresh] "s"(thresh), [prog] "v"(prog_lds), [l3] "s"(l3)
+        : [base] "s"(gwalk), [thresh] "s"(thresh), [prog] "v"(prog_lds), [l3] "s"(l3), [lanes] "s"(lanes)
         : "v48", "v49", "v54", "v55", "v64", "v65", "v66", "v67", "v69", "v70", "v71", "v84", "v87", "vcc", "scc", "memory");
 }
 
@@ -267,11 +274,12 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
             walk_run_asm(A, Gm, wl, slack, n, (int32_t)i - (int32_t)kWalkLag, startA, startG, thresh, prog_lds, gwalk);
             i += n0 - n;
             woff += 16 * (n0 - n);
+            Gm = (uint32_t)__builtin_amdgcn_readfirstlane((int)Gm); // (the loop may have run on quad 0 only)
             vL = __builtin_amdgcn_readlane(A, 0); vM = __builtin_amdgcn_readlane(A, 1); vO = __builtin_amdgcn_readlane(A, 2);
             WSTAT(2, 1);
             if (__builtin_amdgcn_ballot_w64(slack < 0) != 0) { // the last group is void: once more from its start, carefully
                 i -= kWalkGroup; woff -= 16 * kWalkGroup;
-                vL = __builtin_amdgcn_readlane(startA, 0); vM = __builtin_amdgcn_readlane(startA, 1); vO = __builtin_amdgcn_readlane(startA, 2); Gm = startG;
+                vL = __builtin_amdgcn_readlane(startA, 0); vM = __builtin_amdgcn_readlane(startA, 1); vO = __builtin_amdgcn_readlane(startA, 2); Gm = (uint32_t)__builtin_amdgcn_readfirstlane((int)startG);
                 // ... up to and including the first sequence that needed the wider window (what follows goes back to the hot form)
                 for (uint32_t k = 0; k < kWalkGroup; k++) { i++; if (careful_step()) break; }
                 WSTAT(4, 1);
