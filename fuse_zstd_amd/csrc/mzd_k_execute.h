@@ -578,6 +578,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
         const uint4 pe = pe_next; // loaded an iteration ago
+        if (lane == 0) flag_store(&S.c.copy_prog, chunk); // (how far this wavefront is: the walker yields when it is far ahead, mzd_k_walk.h)
         CSTAMP(1);
         bool cut = false; // the plan ends with this chunk (the block's output passes 128 KiB in it)
         if (chunk + 1 < nchunks) { // prefetch the next chunk's plan

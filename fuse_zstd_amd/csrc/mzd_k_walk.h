@@ -90,6 +90,10 @@ constexpr uint32_t kInRing = 0x80000000u;   // parse_seq_header: the staged head
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kWalkGroup = 8;
 constexpr uint32_t kWalkLag = 32;
+#ifndef MZD_WALK_YIELD
+#define MZD_WALK_YIELD 448
+#endif
+constexpr uint32_t kWalkYield = MZD_WALK_YIELD;
 #define MZD_SDWA_B1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
 #define MZD_DPP_ALL " row_mask:0xf bank_mask:0xf\n"
 #define MZD_WALK_STEP(SH, RECOFF, TAIL) \
@@ -253,6 +257,11 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
 #endif
     while (i < nupd) {
         WSTAT(6, 0);
+        // Where the copier cannot keep up (files of many short matches: its LDS rounds under a full machine), a walker further ahead only
+        // takes issue slots from the copiers it shares its SIMD with: it yields while its own file's copier is more than kWalkYield
+        // sequences behind (checked each time the assembly run returns: per KiB of bitstream).  Measured (thresholds 320 .. 2048, side by side): 400 .. 512 is best -- cfg2 +3.5 %, cfg2x8 +4 %, cfg3 +1 %; files
+        // whose copier keeps up (cfg3's sequence-heavy classes) keep the walker in front.
+        if (i > kWalkYield + 64 * flag_load_u(&S.c.copy_prog)) __builtin_amdgcn_s_setprio(MZD_PRIO_WALK_YIELD); else __builtin_amdgcn_s_setprio(MZD_PRIO_WALK);
         // keep the ring one group ahead of the read head
         while (st.lowest > 0 && (int32_t)Gm < st.lowest * (int32_t)(kChunk * 8) + kLook) {
             st.lowest--;
@@ -293,6 +302,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
 #if defined(MZD_STAMPS) && defined(MZD_EXP_WALKSTAT)
     if (lane == 0) for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = ws_[k_];
 #endif
+    __builtin_amdgcn_s_setprio(MZD_PRIO_WALK);
     G = Gm + 32;
     // last sequence: extra bits only
     {

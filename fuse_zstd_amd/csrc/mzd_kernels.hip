@@ -39,6 +39,9 @@
 #ifndef MZD_PRIO_WALK
 #define MZD_PRIO_WALK 3
 #endif
+#ifndef MZD_PRIO_WALK_YIELD
+#define MZD_PRIO_WALK_YIELD 1 // (a walker far ahead of its copier: mzd_k_walk.h)
+#endif
 #ifndef MZD_PRIO_COPY
 #define MZD_PRIO_COPY 2
 #endif
