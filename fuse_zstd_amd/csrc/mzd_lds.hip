@@ -81,6 +81,7 @@ DI void wsync() {
 // shared by the wavefront: code tables; the dictionary's image (DICT)
 constexpr uint32_t kShLL = 0;     // uint32 [36]: baseline | extra bits << 24
 constexpr uint32_t kShML = 144;   // uint32 [53]
+constexpr uint32_t kShWalkDummy = 360; // 8 bytes: {its own address, 0}: the entry the walk's fourth lane follows
 constexpr uint32_t kShDump = 384;  // 8 bytes per lane: where the stores of idle lanes go (select-style code: no branch around a store)
 constexpr uint32_t kShBytes = 896;
 constexpr uint32_t kDLL = 0, kDML = 4096, kDOF = 8192, kDHuf = 10240, kDictImg = 14336; // FSE entries of 8 bytes, Huffman entries of 2
@@ -345,50 +346,54 @@ __device__ __noinline__ void rare_match(uint32_t outo, uint32_t mp, uint32_t off
 // The state walk's hot form, hand-scheduled (mzd_k_walk.h's step with per-lane tables: an entry's low word is the LDS address of its
 // next-state base, so the new state's address is low + 8 * bits; bit positions are LDS bit addresses).  One call walks N sequences and
 // records each one's state {LL, ML, OF entry addresses, read head - 32} in the ring (16 bytes a sequence) before stepping over it.
-// Per step: the three entries (ds_read_b64) and the aligned dword pair that holds the read head (32..63 of its bits lie below the
-// head), issued together; then the bit budget from the entries' second bytes (SDWA), one 64-bit shift, three field extracts, three
-// shift-adds -- ~20 instructions against the compiler's 27, and the next step's reads are in flight before this step's record is
-// stored.  A step whose sequence is wider than the window leaves `slack` negative: the caller takes the whole step again with
-// the C++ form from the state it saved.  LDS addresses are spelled as they are: the dynamic LDS segment must start at 0 (checked).
+// The hot form of the walk (mzd_k_walk.h's, for per-file tables): the file's three states live in three LANES of its first quad
+// (lane 0 LL, 1 ML, 2 OF; lane 3 follows a dummy entry that consumes nothing and leads to itself), so a step is ONE table read, one
+// field extract and one address add; the other states' bit counts come through DPP quad permutes of the entry's high word as it was
+// loaded.  On a lone wavefront a step costs its instruction slots in front of the table read plus that read's round trip: 8 VALU
+// slots here against 12 + three reads with one lane per file.  Behind the read, in the shadow of its latency: the read head, the next
+// window's read, the record (lane k stores dword k of {LL, ML, OF state address, read head - 32}).  A step whose sequence is wider
+// than the window (32..63 bits below the head) leaves `slack` negative: the caller takes the whole call again with the C++ form
+// from the state it saved.  LDS addresses are spelled as they are: the dynamic LDS segment must start at 0 (checked).
 #define MZD_SDWA_B1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
-#define MZD_LW_READS \
-    "ds_read_b64 v[48:49], v86\n" \
-    "ds_read_b64 v[50:51], v85\n" \
-    "ds_read_b64 v[52:53], v84\n" \
-    "v_and_b32_e32 v71, 0x3fffc, v71\n" \
-    "ds_read2_b32 v[54:55], v71 offset1:1\n"
-#define MZD_LW_STEP(SH) \
-    "s_waitcnt lgkmcnt(0)\n" \
-    "v_add3_u32 v64, v49, v51, v53\n"                 /* nbBits sums | total bits << 8 */ \
-    "v_add_u32_e32 v65, v49, v51\n"                   /* bit offset of the LL field: nbO + nbM (low 5 bits) */ \
-    "v_sub_u32_sdwa " SH ", %[av], v64" MZD_SDWA_B1   /* window bits below what this sequence consumes */ \
-    "v_sub_u32_sdwa v87, v87, v64" MZD_SDWA_B1 \
-    "v_lshrrev_b64 v[66:67], " SH ", v[54:55]\n" \
+#define MZD_DPP_ALL " row_mask:0xf bank_mask:0xf\n"
+#define MZD_LW_SHADOW(RECOFF) \
     "v_lshrrev_b32_e32 v71, 3, v87\n" \
-    "v_bfe_u32 v64, v66, 0, v49\n" \
-    "v_bfe_u32 v69, v66, v49, v51\n" \
-    "v_bfe_u32 v70, v66, v65, v53\n" \
-    "v_lshl_add_u32 v86, v64, 3, v48\n" \
-    "v_lshl_add_u32 v85, v69, 3, v50\n" \
-    "v_lshl_add_u32 v84, v70, 3, v52\n"
-#define MZD_LW_NEXT(RECOFF) MZD_LW_READS "ds_write_b128 %[ring], v[84:87] offset:" RECOFF "\n" "v_and_or_b32 %[av], v87, 31, 32\n"
-#define MZD_LW_PAIR(R1, R2) MZD_LW_STEP("%[sa]") MZD_LW_NEXT(R1) MZD_LW_STEP("%[sb]") MZD_LW_NEXT(R2) "v_min3_i32 %[slack], %[slack], %[sa], %[sb]\n"
-#define MZD_LW_LAST(R1) MZD_LW_STEP("%[sa]") MZD_LW_NEXT(R1) MZD_LW_STEP("%[sb]") "v_min3_i32 %[slack], %[slack], %[sa], %[sb]\n"
+    "v_and_b32_e32 v71, 0x3fffc, v71\n" \
+    "ds_read2_b32 v[54:55], v71 offset1:1\n" \
+    "v_cndmask_b32_e64 v70, v84, v87, %[l3]\n" \
+    "ds_write_b32 %[ring], v70 offset:" RECOFF "\n"   /* the NEXT step's record: the state as it is now */ \
+    "v_and_or_b32 %[av], v87, 31, 32\n"
+#define MZD_LW_STEP(SH) \
+    "s_waitcnt lgkmcnt(2)\n"                                            /* the entry is there (behind it: the window, the record) */ \
+    "v_add_u32_dpp v64, v49, v49 quad_perm:[1,0,3,2]" MZD_DPP_ALL       /* pair sums of the high words */ \
+    "v_mov_b32_dpp v65, v49 quad_perm:[1,2,3,3]" MZD_DPP_ALL            /* the high word one lane up (lane 2: the dummy's, 0) */ \
+    "v_add_u32_dpp v65, v49, v65 quad_perm:[2,3,3,3]" MZD_DPP_ALL       /* + two lanes up: bit offset of the own field: nbO + nbM, nbO, 0 */ \
+    "v_add_u32_dpp v64, v64, v64 quad_perm:[2,3,0,1]" MZD_DPP_ALL       /* all four: nbBits sums | total bits << 8 (v64: written two slots ago) */ \
+    "v_sub_u32_sdwa " SH ", %[av], v64" MZD_SDWA_B1                     /* window bits below what this sequence consumes */ \
+    "s_waitcnt lgkmcnt(1)\n"                                            /* the window */ \
+    "v_lshrrev_b64 v[66:67], " SH ", v[54:55]\n" \
+    "v_bfe_u32 v69, v66, v65, v49\n"                                    /* the lane's fresh state bits */ \
+    "v_lshl_add_u32 v84, v69, 3, v48\n" \
+    "ds_read_b64 v[48:49], v84\n" \
+    "v_sub_u32_sdwa v87, v87, v64" MZD_SDWA_B1                          /* (behind the read from here on) the read head */
+#define MZD_LW_PAIR(R1, R2) MZD_LW_STEP("%[sa]") MZD_LW_SHADOW(R1) MZD_LW_STEP("%[sb]") MZD_LW_SHADOW(R2) "v_min3_i32 %[slack], %[slack], %[sa], %[sb]\n"
+#define MZD_LW_LAST(R1) MZD_LW_STEP("%[sa]") MZD_LW_SHADOW(R1) MZD_LW_STEP("%[sb]") "v_min3_i32 %[slack], %[slack], %[sa], %[sb]\n"
+// N steps.  A: the lane's state address (lane & 3: LL, ML, OF, the dummy); ring: the file's record ring + 4 * (lane & 3).
+// Runs on the first quad of every file that is walking (the caller's exec mask); everything stays inside the quad.
 template <int N>
-DI void walk_asm(uint32_t& aL, uint32_t& aM, uint32_t& aO, uint32_t& Gm, int32_t& slack, uint32_t ring) {
+DI void walk_asm(uint32_t& A, uint32_t& Gm, int32_t& slack, uint32_t ring) {
     uint32_t av, sa, sb;
+    const uint64_t l3 = 0x8888888888888888ull; // lane 3 of a quad: its record dword is the read head
 #define MZD_LW_HEAD \
-        "v_mov_b32_e32 v84, %[aL]\n v_mov_b32_e32 v85, %[aM]\n v_mov_b32_e32 v86, %[aO]\n v_mov_b32_e32 v87, %[Gm]\n" \
-        "v_lshrrev_b32_e32 v71, 3, v87\n" \
-        MZD_LW_READS \
-        "ds_write_b128 %[ring], v[84:87]\n" \
-        "v_and_or_b32 %[av], v87, 31, 32\n"
+        "v_mov_b32_e32 v84, %[A]\n v_mov_b32_e32 v87, %[Gm]\n" \
+        "ds_read_b64 v[48:49], v84\n" \
+        MZD_LW_SHADOW("0")
 #define MZD_LW_TAIL \
-        "v_mov_b32_e32 %[aL], v84\n v_mov_b32_e32 %[aM], v85\n v_mov_b32_e32 %[aO], v86\n v_mov_b32_e32 %[Gm], v87\n"
+        "s_waitcnt lgkmcnt(0)\n v_mov_b32_e32 %[A], v84\n v_mov_b32_e32 %[Gm], v87\n"
 #define MZD_LW_OPS \
-        : [aL] "+v"(aL), [aM] "+v"(aM), [aO] "+v"(aO), [Gm] "+v"(Gm), [slack] "+v"(slack), [av] "=&v"(av), [sa] "=&v"(sa), [sb] "=&v"(sb) \
-        : [ring] "v"(ring) \
-        : "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v69", "v70", "v71", "v84", "v85", "v86", "v87", "memory"
+        : [A] "+v"(A), [Gm] "+v"(Gm), [slack] "+v"(slack), [av] "=&v"(av), [sa] "=&v"(sa), [sb] "=&v"(sb) \
+        : [ring] "v"(ring), [l3] "s"(l3) \
+        : "v48", "v49", "v54", "v55", "v64", "v65", "v66", "v67", "v69", "v70", "v71", "v84", "v87", "memory"
     if constexpr (N == 16)
         asm volatile(MZD_LW_HEAD MZD_LW_PAIR("16", "32") MZD_LW_PAIR("48", "64") MZD_LW_PAIR("80", "96") MZD_LW_PAIR("112", "128")
                      MZD_LW_PAIR("144", "160") MZD_LW_PAIR("176", "192") MZD_LW_PAIR("208", "224") MZD_LW_LAST("240") MZD_LW_TAIL MZD_LW_OPS);
@@ -424,6 +429,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
 
     if (lane < 36) L32(kShLL + 4 * lane) = LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24);
     if (lane < 53) L32(kShML + 4 * lane) = ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24);
+    if (lane == 0) L64(kShWalkDummy) = (uint64_t)kShWalkDummy;
     wsync();
     DictInfo di;
     di.handle = 0; di.formatted = 0; di.dict_id = 0; di.content_len = 0; di.huf_log = 0; di.content = nullptr;
@@ -975,6 +981,20 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                 const bool act = c0 < nrun && !bad;
                 // ---- the walk
                 uint32_t wbad = 0;
+                bool done_asm = false;
+                if (lds_at_zero) { // the hot form, on the first quad of every file whose step is a full one (every sequence followed by a state update)
+                    if (act && sub < 4 && c0 + LPF < nrun) {
+                        auto quad = [](uint32_t v, auto ctrl_c) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl_c)::value, 0xF, 0xF, false); };
+                        const std::integral_constant<int, 0x00> q0{}; const std::integral_constant<int, 0x55> q1{}; const std::integral_constant<int, 0xAA> q2{};
+                        const uint32_t bL = quad(aL, q0), bM = quad(aM, q0), bO = quad(aO, q0), bG = quad(Gh, q0); // the leader's state
+                        uint32_t A = sel(m_eq(sub, 0), bL, sel(m_eq(sub, 1), bM, sel(m_eq(sub, 2), bO, kShWalkDummy)));
+                        uint32_t xG = bG - 32;
+                        int32_t slack = 64;
+                        walk_asm<(int)LPF>(A, xG, slack, ringo + 4 * sub);
+                        const uint32_t nM = quad(A, q1), nO = quad(A, q2);
+                        if (leader && slack >= 0) { aL = A; aM = nM; aO = nO; Gh = xG + 32; done_asm = true; } // (else: a sequence wider than 32..63 bits met the window's edge)
+                    }
+                }
                 if (act && leader) {
                     auto record = [&](uint32_t k) { *reinterpret_cast<uint4*>(lds + ringo + 16 * k) = make_uint4(aL, aM, aO, Gh - 32); };
                     auto step = [&]() {
@@ -993,13 +1013,6 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         Gh -= tot;
                     };
                     if (c0 + LPF < nrun) { // every sequence of the step is followed by a state update
-                        bool done_asm = false;
-                        if (lds_at_zero) {
-                            uint32_t xL = aL, xM = aM, xO = aO, xG = Gh - 32;
-                            int32_t slack = 64;
-                            walk_asm<(int)LPF>(xL, xM, xO, xG, slack, ringo);
-                            if (slack >= 0) { aL = xL; aM = xM; aO = xO; Gh = xG + 32; done_asm = true; } // (else: a sequence wider than 32..63 bits met the window's edge)
-                        }
                         if (!done_asm) {
 #pragma unroll
                             for (uint32_t k = 0; k < LPF; k++) { record(k); step(); }
