@@ -7,13 +7,13 @@
 #include <stdio.h>
 #define REP8(x) x x x x x x x x
 #define REP64(x) REP8(REP8(x))
-__global__ __launch_bounds__(1024) void k(uint32_t seed, int active, uint64_t* out, uint64_t* cyc, int iters) {
+__global__ __launch_bounds__(1024) void k(uint32_t seed, int active, uint64_t* out, uint64_t* cyc, int iters, uint64_t pattern) {
     __shared__ unsigned long long tmin, tmax;
     if (threadIdx.x == 0) { tmin = ~0ull; tmax = 0; }
     __syncthreads();
     uint32_t a = seed + threadIdx.x, b = seed * 3 + 1, c = seed ^ 0x55, d = seed + 77;
     uint64_t t0 = __builtin_readcyclecounter();
-    if ((int)(threadIdx.x & 63) < active) {
+    if (pattern ? ((pattern >> (threadIdx.x & 63)) & 1) != 0 : (int)(threadIdx.x & 63) < active) {
         for (int it = 0; it < iters; it++) {
             REP64(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));)
         }
@@ -30,12 +30,22 @@ int main() {
     const int iters = 100;
     for (int waves : {4, 16})
         for (int active : {64, 32, 16, 8, 1}) {
-            hipLaunchKernelGGL(k, dim3(1), dim3(64 * waves), 0, 0, 8u, active, d_out, d_cyc, iters);
+            hipLaunchKernelGGL(k, dim3(1), dim3(64 * waves), 0, 0, 8u, active, d_out, d_cyc, iters, (uint64_t)0);
             if (hipDeviceSynchronize() != hipSuccess) return 1;
             uint64_t c = 0;
             if (hipMemcpy(&c, d_cyc, 8, hipMemcpyDeviceToHost) != hipSuccess) return 1;
             printf("waves/WG %2d (=%d per SIMD), %2d active lanes: %6.2f cycles per VALU instruction per wavefront, %5.2f SIMD cycles per instruction\n",
                    waves, waves / 4, active, (double)c / (iters * 64.0 * 4), (double)c / (iters * 64.0 * 4) / (waves / 4));
+        }
+    // the same with the active lanes spread over the four 16-lane passes of the wavefront
+    struct { const char* what; uint64_t m; } pats[] = {{"lanes 0,16,32,48", 0x0001000100010001ull}, {"lanes 0-3 of every 16", 0x000F000F000F000Full}, {"lanes 0-7", 0xFFull}, {"lanes 0-3", 0xFull}, {"lanes 0-15", 0xFFFFull}, {"lanes 0-7 and 32-39", 0x000000FF000000FFull}};
+    for (int waves : {4, 8, 16})
+        for (auto& p : pats) {
+            hipLaunchKernelGGL(k, dim3(1), dim3(64 * waves), 0, 0, 8u, 0, d_out, d_cyc, iters, p.m);
+            if (hipDeviceSynchronize() != hipSuccess) return 1;
+            uint64_t c = 0;
+            if (hipMemcpy(&c, d_cyc, 8, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+            printf("waves/WG %2d (=%d per SIMD), %-22s: %6.2f cycles per VALU instruction per wavefront\n", waves, waves / 4, p.what, (double)c / (iters * 64.0 * 4));
         }
     return 0;
 }
