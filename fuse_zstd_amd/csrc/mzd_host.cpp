@@ -262,6 +262,7 @@ struct Plan {
     uint32_t big_tasks = 0;    // workgroups worth launching for the files that are not small
     uint64_t blocks = 0;       // block tasks of those files, estimated from their capacities
     uint32_t nmulti = 0;       // ... how many of them can have more than one block
+    bool lpt = false;          // the general driver takes its files through the big list, largest first (make_plan)
 };
 // lists: [0, njobs) small list (job indices sorted by dictionary), [njobs, 2 njobs) job list of the general driver
 Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_wg) {
@@ -272,7 +273,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
     uint32_t* big = lists + njobs;
     bool all_dict = true;
     uint64_t tasks = 0;
-    size_t maxcap = 0;
+    size_t maxcap = 0, maxbig = 0;
     // The small-file kernel pays off from about two thousand small files on: its launch lasts as long as one group of files
     // (~0.25 ms for 4 KiB files) however few they are, and runs before the general driver, while fewer files fill the general
     // driver's idle workgroup slots for less (profiles/r03_small_policy.txt: 4 KiB files, general driver / small-file kernel:
@@ -291,6 +292,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
         } else {
             big[p.nbig++] = (uint32_t)i;
             if (j.dst_cap > kBlockMax) { p.multi = true; p.nmulti++; }
+            maxbig = std::max<size_t>(maxbig, j.dst_cap);
             p.blocks += 1 + j.dst_cap / kBlockMax;
             if (tasks < max_wg) tasks += 1 + j.src_len / 2048;
         }
@@ -328,6 +330,24 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
             if (env_g == 4 || env_g == 8 || env_g == 16) p.lds_g = env_g;
             while (p.lds_g > 4 && lds_kernel_bytes(p.lds_g, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out) > 160u * 1024u) p.lds_g /= 2;
         }
+    }
+    // Multi-block files in a launch that fills the machine many times over: block tasks keep a workgroup slot waiting while a file's
+    // blocks are copied one after the other (the blocks of a 1 MiB file hold eight slots for the time of eight copies), so such a launch
+    // gives every file to ONE workgroup (driver 1 walks a file's blocks in order: tables and state stay in LDS, nothing is handed over)
+    // and hands the files out largest first, which keeps the launch's tail short.  Only when no file's chain is longer than a slot's
+    // fair share of the launch (else the longest file would be the launch: one 64 MiB file is 500 blocks).  cfg4lu (10 000 files,
+    // 4 KiB .. 1 MiB): 12.05 -> 9.96 ms; the same through driver 1 in the caller's order: 13.35 ms (tools/lpt_order.py).
+    if (p.multi && force == 0 && (uint64_t)(1 + maxbig / kBlockMax) * max_wg <= p.blocks) {
+        p.multi = false; p.lpt = true;
+        constexpr uint32_t kSizeBuckets = 4096; // capacity in steps of 4 KiB, everything from 16 MiB on in the last
+        static thread_local std::vector<uint32_t> cnt, tmp;
+        cnt.assign(kSizeBuckets + 1, 0);
+        auto key = [&](uint32_t i) -> uint32_t { return kSizeBuckets - 1 - (uint32_t)std::min<size_t>(jobs[i].dst_cap >> 12, kSizeBuckets - 1); };
+        for (uint32_t k = 0; k < p.nbig; k++) cnt[key(big[k]) + 1]++;
+        for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+        tmp.resize(p.nbig);
+        for (uint32_t k = 0; k < p.nbig; k++) tmp[cnt[key(big[k])]++] = big[k];
+        std::copy(tmp.begin(), tmp.end(), big);
     }
     if (force == 1) p.multi = false;
     if (force == 2 || force == 4 || force == 5) p.multi = true;
@@ -387,6 +407,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
     } else {
         grid = use_tasks ? std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(njobs, l.nwg)) : njobs;
+        if (p.lpt) { ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig; } // (largest first; nothing is appended: counter word 4 stays 0)
     }
     grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, l.nwg));
     // (the launch behind the small-file kernel is not optional even when nothing is handed on: its last workgroup zeroes the
@@ -432,7 +453,7 @@ int run_device_jobs(Device& d, mzd_job* jobs, size_t njobs, hipStream_t s) {
     const Plan p = make_plan(st->h_jobs, njobs, st->h_lists, d.max_wg);
     if (!s) s = d.whole.stream;
     HIPCHK(hipMemcpyAsync(st->d_jobs, st->h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice, s));
-    if (p.nsmall) HIPCHK(hipMemcpyAsync(st->d_lists, st->h_lists, njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (p.nsmall || p.lpt) HIPCHK(hipMemcpyAsync(st->d_lists, st->h_lists, njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     rc = enqueue(d, d.whole, s, st->d_jobs, p, st->d_lists, d.whole.ev0, d.whole.ev1);
     d.job0_counter = d.whole.counter;
     if (rc) { hipStreamSynchronize(s); return rc; }
@@ -690,14 +711,14 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
     bool any_small = false;
     for (size_t c = 0; c < nchunks; c++) {
         plans[c] = make_plan(st->h_jobs + cut[c], cut[c + 1] - cut[c], st->h_lists + 2 * cut[c], d.lane[0].nwg);
-        any_small = any_small || plans[c].nsmall != 0;
+        any_small = any_small || plans[c].nsmall != 0 || plans[c].lpt;
     }
     mark("plans");
     // One chunk with more block tasks than a lane has workgroup slots (a single big file): the whole device instead of a
     // quarter of it (the call then waits until no other launch is in flight, like a call on device pointers).
     constexpr int kWholeLane = -2;
     const bool use_whole = nchunks == 1 && plans[0].blocks > d.lane[0].nwg;
-    if (use_whole) { plans[0] = make_plan(st->h_jobs, n, st->h_lists, d.max_wg); any_small = plans[0].nsmall != 0; }
+    if (use_whole) { plans[0] = make_plan(st->h_jobs, n, st->h_lists, d.max_wg); any_small = plans[0].nsmall != 0 || plans[0].lpt; }
     {
         hipError_t e = hipMemcpyAsync(st->d_jobs, st->h_jobs, n * sizeof(DevJob), hipMemcpyHostToDevice, d.copy_in);
         if (e == hipSuccess && any_small) e = hipMemcpyAsync(st->d_lists, st->h_lists, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, d.copy_in);

@@ -97,13 +97,21 @@ def test_config4_log_uniform_mix_of_small_and_multi_block_files(mode):
 
 
 @needs_zstd
-def test_many_multi_block_files_resolve_only_where_the_predecessor_is_still_running():
-    """6 000 files of 1 KB .. 512 KiB: more than 8 block tasks per workgroup slot, so a task resolves its block ahead only when
-    its predecessor is still running as it starts (KernelArgs::resolve = 2); both kinds of task hand over to each other."""
+@pytest.mark.parametrize("mode", [0, 2])
+def test_many_multi_block_files_in_a_launch_that_fills_the_machine(mode):
+    """6 000 files of 1 KB .. 512 KiB, many times the machine's workgroup slots.  Mode 0, the library's choice: no file's chain of
+    blocks is longer than a slot's share of the launch, so every file goes to ONE workgroup (driver 1 walks its blocks in order) and
+    the files are handed out largest first (make_plan: lpt).  Mode 2 keeps the block tasks: more than 8 of them per slot, so a task
+    resolves its block ahead only when its predecessor is still running as it starts (KernelArgs::resolve = 2); both kinds of task
+    hand over to each other."""
     rng = np.random.RandomState(4321)
     sizes = [int(x) for x in np.exp(rng.uniform(np.log(1000), np.log(1 << 19), size=6000)).astype(np.int64)]
     cp = corpus.build_corpus("json", 14, sizes)
-    res, got, end = _device_resident(cp)
+    mzd.set_driver(mode)
+    try:
+        res, got, end = _device_resident(cp)
+    finally:
+        mzd.set_driver(0)
     _check_corpus(cp, res, got, end, sample=80)
 
 
