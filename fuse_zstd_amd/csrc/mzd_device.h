@@ -167,6 +167,7 @@ struct LdsArgs {
 void launch_lds(const LdsArgs& a, uint32_t grid, int g, int with_dict, void* stream);
 uint32_t lds_kernel_bytes(int g, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes);
 size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap);
+uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes);
 
 
 void launch_decode(const KernelArgs& a, uint32_t grid, void* stream);

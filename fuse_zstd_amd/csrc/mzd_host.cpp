@@ -319,9 +319,12 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
         // the LDS kernel's slots: sized for the launch's largest file.  Files that all name a dictionary bring no tables of their
         // own in the plain case (a file that does is handed on); else 2 KiB hold a 10-bit Huffman table, later 256 FSE entries
         // (three tables of <= 512 sequences), 4 KiB twice that
-        p.lds_tab = (p.with_dict && all_dict) ? 0u : (maxcap <= 5120 ? 2048u : 4096u);
         p.lds_comp = (uint32_t)align_up(maxsrc + 16, 16);
         p.lds_out = (uint32_t)align_up(maxcap + 16, 16);
+        // (all files name a dictionary: no table area of their own is paid for, but what the window leaves free beside the input is
+        //  one -- the few records that bring a predefined, RLE or described table then stay in this kernel: cfg5 handed 8 of 50 000
+        //  on, and the general driver's launch behind this kernel lasts 0.16 ms however few files it gets)
+        p.lds_tab = (p.with_dict && all_dict) ? lds_spare_table_bytes(p.lds_comp, p.lds_out) : (maxcap <= 5120 ? 2048u : 4096u);
         {   // files per wavefront: residency is set by LDS (and by registers: two wavefronts per SIMD), whatever G is; fewer files
             // per wavefront spread a launch's tail better and cost nothing but lane efficiency in the serial phases, which the
             // SIMDs have to spare (measured, cfg4: G = 4 0.52 ms, G = 8 0.64 ms)

@@ -1363,6 +1363,11 @@ uint32_t lds_kernel_bytes(int g, int with_dict, uint32_t tab_bytes, uint32_t com
     const uint32_t ent = tab_bytes + lw::kAux + comp_bytes;
     return lw::kShBytes + (with_dict ? lw::kDictImg : 0u) + (uint32_t)g * (ent > out_bytes ? ent : out_bytes);
 }
+// what a slot has left for tables beside its input when the output window, not the input, sets its size (multiple of 16, at most 4 KiB)
+uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes) {
+    const uint32_t used = lw::kAux + comp_bytes;
+    return out_bytes > used ? std::min<uint32_t>((out_bytes - used) & ~15u, 4096u) : 0u; // (the ring behind the tables holds 16-byte records)
+}
 size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap) { return (size_t)lit_stride + 8u * (size_t)seq_cap; }
 
 void launch_lds(const LdsArgs& a, uint32_t grid, int g, int with_dict, void* stream) {
