@@ -1,6 +1,6 @@
 """Diagnostic: random mutations (seed = argv[1]; 1..3 bytes each), truncations and too-small outputs of MULTI-BLOCK frames of four
 data classes, decoded by the block-task driver with blocks resolved ahead (driver 4), without (5) and by the library's own choice
-(0), and compared with the oracle (status, and bytes where both accept); exits non-zero on any mismatch.
+(0) and by driver 1 (a workgroup per file), and compared with the oracle (status, and bytes where both accept); exits non-zero on any mismatch.
 tests/test_gpu_parity.py::test_corrupted_multi_block_files_report_the_oracles_error is the committed, smaller form."""
 import sys, os
 sys.path.insert(0, os.getcwd())
@@ -26,7 +26,7 @@ for kind, size in (("json", 600000), ("text", 400000), ("xray", 300000), ("repea
         cases.append((good, size))
 want = [oracle.decode(c, cap=cap) for c, cap in cases]
 bad = 0
-for drv in (4, 5, 0):
+for drv in (4, 5, 0, 1):  # (1: a workgroup per file -- what a launch that fills the machine gets for multi-block files too)
     mzd.set_driver(drv)
     res = mzd.decode_batch([c for c, _ in cases], [cap for _, cap in cases])
     for i, ((st, out), (rc, ref)) in enumerate(zip(res, want)):
