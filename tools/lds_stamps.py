@@ -43,6 +43,7 @@ for rep in range(3):
     if rep == 2:
         print("%s G=%s: kernel %.3f ms; workgroup 0, first group: total %d cycles" % (wl, os.environ.get("MZD_LDS_G", "auto"), mzd.last_kernel_ms(0), t[9] - t[0]))
         print("    inside: walk %d, extract %d cycles" % (t[10], t[11]))
+        if t[13] and t[14] and t[15]: print("    Huffman weights: counts %d, their FSE table %d, the weights %d, validation + decode table %d cycles" % (t[13] - t[2], t[14] - t[13], t[15] - t[14], t[3] - t[15]))
         print("    execute: stage A %d, repeat offsets %d, literals %d, match rounds %d cycles (%d rounds)" % (t[18], t[19], t[20], t[21], t[22]))
         t = t[:8] + [t[17]] + t[8:10] + t[10:]  # (the execute stamp was added later: index 17)
         for k in range(10):
