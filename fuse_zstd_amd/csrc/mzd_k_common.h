@@ -25,6 +25,7 @@ struct Ctl {
     uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
     uint32_t next_stream, streams_done, streams_mask; // Huffman streams are handed out to whichever wavefront is free; mask: bit k = stream k decoded
     uint32_t tables_ready, plan_prog, copy_prog, plan_lit_used; // walker -> planner -> copier
+    uint32_t walk_g0;                               // (read head - 32) of the block's first walk record: records carry 16 bits of it
     uint32_t plan_out;      // output bytes of the block's sequences (the literals behind the last one not counted), once the plan is complete
     uint32_t plan_too_long; // 1: the plan ends with a chunk that cannot be executed (literals run out / output passes 128 KiB); 2: only the literals after
                             // the last sequence pass 128 KiB.  No error yet: the copier, which reports in stream order, gives the verdict

@@ -165,10 +165,17 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         return (pg & ~kWalkFin) >= need;
     };
     struct Win { uint32_t hL, hM, hO, G; uint64_t bO, bM, bL; }; // entry words + raw 8-byte windows of one sequence
-    auto load_rec = [&](uint32_t idx) -> uint4 { return idx < nseq ? cx.walk[idx] : make_uint4(0, 0, 0, 0); };
-    auto issue_bits = [&](uint4 w, bool live, Win& o) {
-        const uint32_t vL = w.x, vM = w.y, vO = w.z;
-        o.G = w.w + 32; // records carry the read head - 32
+    // records are 8 bytes (walk_record): three 16-bit state addresses and the low 16 bits of (read head - 32).  A chunk's positions are
+    // unwrapped against its first record's, and that one against the chunk before (64 sequences consume < 2^16 bits)
+    const uint2* const recs = reinterpret_cast<const uint2*>(cx.walk);
+    auto load_rec = [&](uint32_t idx) -> uint2 { return idx < nseq ? recs[idx] : make_uint2(0, 0); };
+    auto unwrap = [&](uint2 w, uint32_t first_full) -> uint32_t { // full (read head - 32) of a record of the chunk whose first record is at first_full
+        const uint32_t first16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w.y >> 16));
+        return first_full - ((first16 - (w.y >> 16)) & 0xFFFFu);
+    };
+    auto issue_bits = [&](uint2 w2, uint32_t first_full, bool live, Win& o) {
+        const uint32_t vL = w2.x & 0xFFFFu, vM = w2.x >> 16, vO = w2.y & 0xFFFFu;
+        o.G = unwrap(w2, first_full) + 32; // records carry the read head - 32
         o.hL = (uint32_t)(lds_entry(vL) >> 32); o.hM = (uint32_t)(lds_entry(vM) >> 32); o.hO = (uint32_t)(lds_entry(vO) >> 32); // (records hold state addresses)
         o.bO = 0; o.bM = 0; o.bL = 0;
         if (live) {
@@ -178,9 +185,14 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         }
     };
     if (!wait_walker(128)) return MZD_E_CORRUPT;
-    uint4 recA = load_rec((uint32_t)lane), recB = load_rec(64 + (uint32_t)lane); // chunks 0 and 1
+    uint2 recA = load_rec((uint32_t)lane), recB = load_rec(64 + (uint32_t)lane); // chunks 0 and 1
+    uint32_t gfirst = flag_load_u(&S.c.walk_g0); // full position of the current chunk's first record ...
+    auto next_first = [&](uint2 cur, uint2 nxt, uint32_t cur_full) -> uint32_t { // ... and of the next chunk's (lane 0 of each)
+        const uint32_t a16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur.y >> 16)), b16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nxt.y >> 16));
+        return cur_full - ((a16 - b16) & 0xFFFFu);
+    };
     Win win;
-    issue_bits(recA, (uint32_t)lane < nseq, win);
+    issue_bits(recA, gfirst, (uint32_t)lane < nseq, win);
     uint32_t chunk = 0;
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
@@ -192,9 +204,10 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         if (lane == 0) flag_store(&S.c.plan_prog, chunk);
         // stage 1: records of chunk k+2, bit windows of chunk k+1 (recB arrived an iteration ago)
         if (!wait_walker(base + 192)) return MZD_E_CORRUPT; // the walker failed (it posted the error) or never got there
-        const uint4 recC = load_rec(base + 128 + (uint32_t)lane);
+        const uint2 recC = load_rec(base + 128 + (uint32_t)lane);
         Win next;
-        issue_bits(recB, base + 64 + (uint32_t)lane < nseq, next);
+        const uint32_t gnext = base + 64 < nseq ? next_first(recA, recB, gfirst) : gfirst;
+        issue_bits(recB, gnext, base + 64 + (uint32_t)lane < nseq, next);
         // stage 2: fields of chunk k from the windows issued an iteration ago
         uint32_t ll = 0, ml = 0, ofv = 4;
         if (valid) {
@@ -208,7 +221,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
             ml = S.ml_base[cM] + vM;
             ll = S.ll_base[cL] + vL;
         }
-        win = next; recB = recC;
+        win = next; recA = recB; recB = recC; gfirst = gnext;
         // ---- repeat offsets
         uint32_t off;
         const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u); // (meaningful when ofv <= 3)

@@ -56,8 +56,6 @@ __device__ __forceinline__ uint64_t ring_read64(uint32_t e) {
     return v;
 }
 
-// walk record (uint4): LL, ML, OF state offsets, g-bit position - 32 -- the walker's state as it stands
-//   (state offsets are byte offsets into the tables: 8 * state)
 
 constexpr uint32_t kWalkFin = 0x80000000u;
 constexpr uint32_t kNoJob = 0xFFFFFFFFu;
@@ -88,6 +86,9 @@ constexpr uint32_t kInRing = 0x80000000u;   // parse_seq_header: the staged head
 // lane's state address, v87 the read head - 32.  Entries hold ABSOLUTE LDS addresses (pack_entry) and the ring's address is an
 // immediate: S must start at LDS address 0 (checked by the caller, which otherwise keeps the C++ form).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// walk record, 8 bytes: LL, ML, OF state addresses (LDS: < 2^16) and the low 16 bits of (read head - 32) -- a sequence consumes < 128 bits, so the
+// planner, which knows where the walk started (Ctl::walk_g0), unwraps the positions chunk by chunk (plan_wave)
+__device__ __forceinline__ uint64_t walk_record(uint32_t vL, uint32_t vM, uint32_t vO, uint32_t gm) { return (uint64_t)(vL | (vM << 16)) | ((uint64_t)(vO | (gm << 16)) << 32); }
 constexpr uint32_t kWalkGroup = 8;
 constexpr uint32_t kWalkLag = 32;
 #ifndef MZD_WALK_YIELD
@@ -113,7 +114,7 @@ constexpr uint32_t kWalkYield = MZD_WALK_YIELD;
     "v_and_b32_e32 v71, 0x1ffc, v71\n" \
     "ds_read2_b32 v[54:55], v71 offset1:1\n" \
     "v_cndmask_b32_e64 v70, v84, v87, %[l3]\n" \
-    "global_store_dword %[woff], v70, %[base] offset:" RECOFF "\n"       /* the NEXT step's record: the state as it is now */ \
+    "global_store_short %[woff], v70, %[base] offset:" RECOFF "\n"       /* the NEXT step's record: the state as it is now, 16 bits a field */ \
     "v_and_or_b32 %[av], v87, 31, 32\n" \
     TAIL
 #define MZD_WALK_SLACK "v_min3_i32 %[slack], %[slack], %[sa], %[sb]\n"
@@ -138,18 +139,18 @@ __device__ __forceinline__ void walk_run_asm(uint32_t& A, uint32_t& Gm, uint32_t
         "v_and_b32_e32 v71, 0x1ffc, v71\n"
         "ds_read2_b32 v[54:55], v71 offset1:1\n"
         "v_cndmask_b32_e64 v70, v84, v87, %[l3]\n"
-        "global_store_dword %[woff], v70, %[base]\n" // the first step's record
+        "global_store_short %[woff], v70, %[base]\n" // the first step's record
         "v_and_or_b32 %[av], v87, 31, 32\n"
         "1:\n"
         "v_mov_b32_e32 %[s0], v84\n v_mov_b32_e32 %[s3], v87\n" // the group's starting state (the reads are in flight)
-        MZD_WALK_STEP("%[sa]", "16", "")
-        MZD_WALK_STEP("%[sb]", "32", MZD_WALK_SLACK "s_waitcnt vmcnt(32)\n v_max_i32_e32 v69, 0, %[pv]\n ds_write_b32 %[prog], v69\n v_add_u32_e32 %[pv], 8, %[pv]\n") // publish
-        MZD_WALK_STEP("%[sa]", "48", "")
-        MZD_WALK_STEP("%[sb]", "64", MZD_WALK_SLACK)
-        MZD_WALK_STEP("%[sa]", "80", "")
-        MZD_WALK_STEP("%[sb]", "96", MZD_WALK_SLACK)
-        MZD_WALK_STEP("%[sa]", "112", "")
-        MZD_WALK_STEP("%[sb]", "128", MZD_WALK_SLACK "v_add_u32_e32 %[woff], 128, %[woff]\n v_subrev_u32_e32 v69, %[thresh], v87\n v_min_i32_e32 v69, v69, %[slack]\n v_cmp_gt_i32_e32 vcc, 0, v69\n")
+        MZD_WALK_STEP("%[sa]", "8", "")
+        MZD_WALK_STEP("%[sb]", "16", MZD_WALK_SLACK "s_waitcnt vmcnt(32)\n v_max_i32_e32 v69, 0, %[pv]\n ds_write_b32 %[prog], v69\n v_add_u32_e32 %[pv], 8, %[pv]\n") // publish
+        MZD_WALK_STEP("%[sa]", "24", "")
+        MZD_WALK_STEP("%[sb]", "32", MZD_WALK_SLACK)
+        MZD_WALK_STEP("%[sa]", "40", "")
+        MZD_WALK_STEP("%[sb]", "48", MZD_WALK_SLACK)
+        MZD_WALK_STEP("%[sa]", "56", "")
+        MZD_WALK_STEP("%[sb]", "64", MZD_WALK_SLACK "v_add_u32_e32 %[woff], 64, %[woff]\n v_subrev_u32_e32 v69, %[thresh], v87\n v_min_i32_e32 v69, v69, %[slack]\n v_cmp_gt_i32_e32 vcc, 0, v69\n")
         "s_sub_u32 %[n], %[n], 8\n"
         "s_cbranch_vccnz 2f\n"
         "s_cmp_lg_u32 %[n], 0\n"
@@ -211,6 +212,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
     const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)S.ring == 0; // (walk_run_asm spells LDS addresses out)
     const uint32_t prog_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)prog;
     uint32_t Gm = G - 32; // the loop carries the read head minus 32 (saves an add per sequence)
+    if (lane == 0) S.c.walk_g0 = Gm; // (the first record's full position: the planner reads it behind the first published progress)
     // One careful step of the chain: the window moves down a dword at a time until the sequence fits (long extra-bit
     // fields: about one sequence in hundreds).  The hot form (walk_run_asm) has no such branch -- a branch on freshly
     // loaded LDS data costs ~35 cycles per sequence on a lone wavefront -- it only notes that a group met such a sequence.
@@ -225,8 +227,8 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         uint32_t ra = (u >> 3) & (kRingBytes - 4);
         uint64_t X;
         __builtin_memcpy(&X, &S.ring[ra], 8);
-        *(__attribute__((address_space(1))) u32x4*)(gwalk + woff) = u32x4{vL, vM, vO, Gm};
-        woff += 16;
+        *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = walk_record(vL, vM, vO, Gm);
+        woff += 8;
         const uint32_t hL = (uint32_t)(eL >> 32), hM = (uint32_t)(eM >> 32), hO = (uint32_t)(eO >> 32);
         const uint32_t total = ((hL + hM + hO) >> 8) & 0xFF;
         uint32_t av = (u & 31) | 32; // bits of the window below the read head: 32..63
@@ -279,15 +281,15 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
             int32_t slack = 64; // minimum over a group of (window bits - bits needed)
             const uint32_t q = (uint32_t)lane & 3;
             uint32_t A = q == 0 ? vL : (q == 1 ? vM : (q == 2 ? vO : kLdsWalkDummy));
-            uint32_t wl = woff + 4 * q, startA, startG;
+            uint32_t wl = woff + 2 * q, startA, startG;
             walk_run_asm(A, Gm, wl, slack, n, (int32_t)i - (int32_t)kWalkLag, startA, startG, thresh, prog_lds, gwalk);
             i += n0 - n;
-            woff += 16 * (n0 - n);
+            woff += 8 * (n0 - n);
             Gm = (uint32_t)__builtin_amdgcn_readfirstlane((int)Gm); // (the loop may have run on quad 0 only)
             vL = __builtin_amdgcn_readlane(A, 0); vM = __builtin_amdgcn_readlane(A, 1); vO = __builtin_amdgcn_readlane(A, 2);
             WSTAT(2, 1);
             if (__builtin_amdgcn_ballot_w64(slack < 0) != 0) { // the last group is void: once more from its start, carefully
-                i -= kWalkGroup; woff -= 16 * kWalkGroup;
+                i -= kWalkGroup; woff -= 8 * kWalkGroup;
                 vL = __builtin_amdgcn_readlane(startA, 0); vM = __builtin_amdgcn_readlane(startA, 1); vO = __builtin_amdgcn_readlane(startA, 2); Gm = (uint32_t)__builtin_amdgcn_readfirstlane((int)startG);
                 // ... up to and including the first sequence that needed the wider window (what follows goes back to the hot form)
                 for (uint32_t k = 0; k < kWalkGroup; k++) { i++; if (careful_step()) break; }
@@ -310,7 +312,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         __builtin_memcpy(&eL, tL + vL, 8);
         __builtin_memcpy(&eM, tM + vM, 8);
         __builtin_memcpy(&eO, tO + vO, 8);
-        *(__attribute__((address_space(1))) u32x4*)(gwalk + woff) = u32x4{vL, vM, vO, G - 32};
+        *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = walk_record(vL, vM, vO, G - 32);
         uint32_t extra = (uint32_t)(eL >> 56) + (uint32_t)(eM >> 56) + (uint32_t)(eO >> 56);
         if (G - Gzero != extra) return MZD_E_CORRUPT; // the bitstream must be consumed exactly
     }
