@@ -202,7 +202,14 @@ __device__ __forceinline__ void clean_next_counters(const KernelArgs& a, int tid
 // ---- driver 1: one workgroup decodes a whole file, block after block.  Used when no file of the launch can have more
 // than one block (every output capacity <= 128 KiB): nothing is forked, nothing is published, the file's state
 // stays in registers and LDS.
-__global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) {
+// The launch's arguments are read where the runtime put them (the kernel-argument segment: constant memory), never through the
+// by-value parameter: the roles take them by reference, and a reference to the parameter makes the compiler keep a copy of it per
+// LANE in the private segment -- 116 bytes x 256 lanes of stores per workgroup before anything else happens.
+__device__ __forceinline__ const KernelArgs& launch_args() {
+    return *reinterpret_cast<const KernelArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+__global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs) {
+    const KernelArgs& a = launch_args();
     // A workgroup's first ticket is its own index: one past the queue's end has nothing to do -- the launch behind the small-file
     // kernel when that kernel handed nothing on.  Leaving at once keeps most of the kernel's private-segment stores out of HBM (1 200
     // bytes per lane: the roles' register spills, and a copy per lane of the launch's arguments, whose address the roles take): an idle
@@ -377,7 +384,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs a) 
 }
 
 // ---- driver 2: block tasks (the hand-over helpers are above, in front of the shared block pipeline)
-__global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs a) {
+__global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
+    const KernelArgs& a = launch_args();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t slot = a.wg0 + blockIdx.x; // this workgroup's place in the scratch arrays
     uint8_t* const lit_buf = a.lit_scratch + (size_t)slot * kLitStride;
