@@ -57,12 +57,13 @@ WORKLOADS = {
     # headline configurations measure one launch's latency (1 000 files on 1 024 workgroup slots; 10 000 small files: two rounds of groups)
     "cfg2x8": ("json", 2, 0, "8 000 x 128 KiB single-block JSON frames (cfg2's generator, eight times the files: the sustained single-block rate)"),
     "cfg4x4": ("json", 4, 0, "40 000 x 4 KiB JSON files (cfg4's generator, four times the files: the sustained small-file rate)"),
+    "cfg3x8": ("text", 3, 7, "8 000 x 128 KiB frames of cfg3's seven-class mix (eight times the files: chains of very different length, handed out longest first)"),
 }
-DEFAULT_FILES = {"cfg2": 1000, "cfg3": 1000, "cfg4": 10000, "cfg4lu": 10000, "cfg5": 50000, "cfg2x8": 8000, "cfg4x4": 40000}
+DEFAULT_FILES = {"cfg2": 1000, "cfg3": 1000, "cfg4": 10000, "cfg4lu": 10000, "cfg5": 50000, "cfg2x8": 8000, "cfg4x4": 40000, "cfg3x8": 8000}
 
 
 def file_sizes(workload, nfiles, rank, world):
-    if workload in ("cfg2", "cfg3", "cfg2x8"):
+    if workload in ("cfg2", "cfg3", "cfg2x8", "cfg3x8"):
         return [131072] * nfiles
     if workload in ("cfg4", "cfg4x4"):
         return [4096] * nfiles
@@ -532,11 +533,11 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_others:
             others = {}
-            for name in ("cfg3", "cfg4", "cfg4lu", "cfg5", "cfg2x8", "cfg4x4"):
+            for name in ("cfg3", "cfg4", "cfg4lu", "cfg5", "cfg2x8", "cfg4x4", "cfg3x8"):
                 if name == args.workload:
                     continue
                 ow = Workload(name, DEFAULT_FILES[name], 0, 1, args.level, dev, mzd, corpus)
-                steps = 10 if name not in ("cfg4lu", "cfg2x8") else 6
+                steps = 10 if name not in ("cfg4lu", "cfg2x8", "cfg3x8") else 6
                 el, kms = time_t1(ow, steps, 2, stream, local_fence)
                 ach = (ow.C + ow.U) / (kms * 1e-3) / 1e9
                 others[name] = {"workload": ow.desc, "files": ow.nfiles, "value": round(ow.U * steps / el / GIB, 3), "unit": "GiB/s",

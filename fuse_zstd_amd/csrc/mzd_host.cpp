@@ -273,7 +273,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
     uint32_t* big = lists + njobs;
     bool all_dict = true;
     uint64_t tasks = 0;
-    size_t maxcap = 0, maxbig = 0;
+    size_t maxcap = 0, maxbig = 0, maxbigsrc = 0, minbigsrc = ~(size_t)0;
     // The small-file kernel pays off from about two thousand small files on: its launch lasts as long as one group of files
     // (~0.25 ms for 4 KiB files) however few they are, and runs before the general driver, while fewer files fill the general
     // driver's idle workgroup slots for less (profiles/r03_small_policy.txt: 4 KiB files, general driver / small-file kernel:
@@ -293,6 +293,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
             big[p.nbig++] = (uint32_t)i;
             if (j.dst_cap > kBlockMax) { p.multi = true; p.nmulti++; }
             maxbig = std::max<size_t>(maxbig, j.dst_cap);
+            maxbigsrc = std::max<size_t>(maxbigsrc, j.src_len); minbigsrc = std::min<size_t>(minbigsrc, j.src_len);
             p.blocks += 1 + j.dst_cap / kBlockMax;
             if (tasks < max_wg) tasks += 1 + j.src_len / 2048;
         }
@@ -340,12 +341,17 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
     // and hands the files out largest first, which keeps the launch's tail short.  Only when no file's chain is longer than a slot's
     // fair share of the launch (else the longest file would be the launch: one 64 MiB file is 500 blocks).  cfg4lu (10 000 files,
     // 4 KiB .. 1 MiB): 12.05 -> 9.96 ms; the same through driver 1 in the caller's order: 13.35 ms (tools/lpt_order.py).
-    if (p.multi && force == 0 && (uint64_t)(1 + maxbig / kBlockMax) * max_wg <= p.blocks) {
+    // (Single-block files in such a launch -- at least two per slot -- are ordered too, by their COMPRESSED size: a block's time is
+    //  its sequence count, which the input's size follows more closely than the output's.  A mix of seven data classes, 8 000 x 128 KiB
+    //  (cfg3's mix at eight times its size): 148 -> 164 GiB/s.)
+    const bool lpt_multi = p.multi && force == 0 && (uint64_t)(1 + maxbig / kBlockMax) * max_wg <= p.blocks;
+    const bool lpt_single = !p.multi && force == 0 && p.nbig >= 2ull * max_wg && maxbigsrc > minbigsrc + minbigsrc / 2; // (files of like size: nothing to gain, cfg2x8 -1 %)
+    if (lpt_multi || lpt_single) {
         p.multi = false; p.lpt = true;
-        constexpr uint32_t kSizeBuckets = 4096; // capacity in steps of 4 KiB, everything from 16 MiB on in the last
+        constexpr uint32_t kSizeBuckets = 4096; // size in steps of 4 KiB (single-block launches: input size in steps of 64 bytes), the rest in the last
         static thread_local std::vector<uint32_t> cnt, tmp;
         cnt.assign(kSizeBuckets + 1, 0);
-        auto key = [&](uint32_t i) -> uint32_t { return kSizeBuckets - 1 - (uint32_t)std::min<size_t>(jobs[i].dst_cap >> 12, kSizeBuckets - 1); };
+        auto key = [&](uint32_t i) -> uint32_t { return kSizeBuckets - 1 - (uint32_t)std::min<size_t>(lpt_multi ? jobs[i].dst_cap >> 12 : jobs[i].src_len >> 6, kSizeBuckets - 1); };
         for (uint32_t k = 0; k < p.nbig; k++) cnt[key(big[k]) + 1]++;
         for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
         tmp.resize(p.nbig);

@@ -2,10 +2,11 @@
 # Round-3 profile set (on the GPU box, from the repo root): bash tools/r03_profiles.sh
 # Per workload: rocprofv3 kernel stats + FETCH_SIZE / WRITE_SIZE passes (tools/rocprof.sh), then instruction counters (tools/pmc.sh).
 export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8
-for w in cfg2 cfg4 cfg5 cfg3 cfg4lu cfg2x8 cfg4x4; do
+for w in cfg2 cfg4 cfg5 cfg3 cfg4lu cfg2x8 cfg4x4 cfg3x8; do
   extra=""
   [ "$w" = cfg4lu ] && extra="--steps 6 --warmup 2"
   [ "$w" = cfg2x8 ] && extra="--steps 6 --warmup 2"
+  [ "$w" = cfg3x8 ] && extra="--steps 6 --warmup 2"
   bash tools/rocprof.sh r03_$w --workload $w $extra > gpurun_out/r03_prof_$w.log 2>&1 || echo "rocprof.sh $w failed"
   echo "done $w"
 done
