@@ -98,6 +98,14 @@ constexpr uint32_t kLdsWalkDummy = (uint32_t)offsetof(Shared, walk_dummy);
 static_assert(kLdsLL == kBlkLdsLL && kLdsML == kBlkLdsML && kLdsOF == kBlkLdsOF, "mzd_device.h names the tables' places (dictionary images in HBM carry them)");
 __device__ __forceinline__ uint64_t lds_entry(uint32_t state_addr) { uint64_t v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(&S) + state_addr, 8); return v; }
 
+// The launch's arguments are read where the runtime put them (the kernel-argument segment: constant memory), never through the
+// by-value parameter: the roles take them by reference, and a reference to the parameter makes the compiler keep a copy of it per
+// LANE in the private segment -- 116 bytes x 256 lanes of stores per workgroup before anything else happens.
+// (In the KERNEL function only: inside a called function the intrinsic did not give the kernel's segment here -- the roles reach the arguments
+//  through BlockArgs::args.)
+__device__ __forceinline__ const KernelArgs& launch_args() {
+    return *reinterpret_cast<const KernelArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+}
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 __device__ __forceinline__ uint32_t ld24(const uint8_t* p) { return ld16(p) | ((uint32_t)p[2] << 16); }
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return ld16(p) | (ld16(p + 2) << 16); }

@@ -34,19 +34,22 @@ struct BlockArgs {
     uint32_t t; bool frame_first, is_final;
     FileState* fs; TableArea* ta;
     uint32_t job;
+    const KernelArgs* args = nullptr;     // the launch's arguments (set by compressed_block: the roles reach them through the block)
 };
 
 // What the roles of one block share (all values wave-uniform).  The roles are separate functions -- each wavefront calls
 // exactly one, so each gets a register allocation of its own instead of one allocation for all four roles' live values.
+// (At most 64 bytes: the roles take it by value, and a bigger struct travels through the private segment -- stores by every lane at
+//  every role call, loads in the callee.  What can be derived is: the launch's arguments, the thread index, the wavefront's LDS
+//  segment, the place of a literal-only block.)
 template <bool TASKS> struct BlockRun {
-    const KernelArgs& a;
     const BlockArgs& b;
-    int tid, lane, wave;
+    int lane, wave;
     uint32_t lit_type, nlit, streams, nseq, seq_len;
     uint64_t lit_off, seq_off;
     const uint8_t* lit;   // the block's literals: inside the input (raw) or the workgroup's literal buffer
-    uint8_t* hseg;        // this wavefront's 2 KiB Huffman segment in LDS
-    uint8_t* place;       // where a literal-only block is decoded in place
+    __device__ __forceinline__ uint8_t* hseg() const { return wave == 1 ? S.stage + 2064 : (wave == 2 ? S.hseg2 : (wave == 0 ? S.ring : S.ring + 4096)); } // this wavefront's 2 KiB Huffman segment in LDS
+    __device__ __forceinline__ uint8_t* place() const { return TASKS ? b.dst : b.dst + b.out0; } // where a literal-only block is decoded in place
 
     // nseq / seq_off / seq_len once the sequence header is parsed (by the walking wavefront); false: the block failed
     __device__ __forceinline__ bool get_seq() {
@@ -65,7 +68,7 @@ template <bool TASKS> struct BlockRun {
     __device__ __forceinline__ void huf_streams(uint32_t max_take) {
         Ctl& c = S.c;
         const uint32_t hl = c.huf_log;
-        uint8_t* const lbase = lit_in_place() ? place : b.lit_buf;
+        uint8_t* const lbase = lit_in_place() ? place() : b.lit_buf;
         for (uint32_t took = 0; took < max_take; took++) {
             // every lane takes part (lanes != 0 add 0): no divergent region around the returning atomic
             uint32_t st = __atomic_fetch_add(&c.next_stream, lane == 0 ? 1u : 0u, __ATOMIC_RELAXED);
@@ -73,7 +76,7 @@ template <bool TASKS> struct BlockRun {
             if (st >= streams || st >= 4) break;
             int r = 0;
             if (!__atomic_load_n(&c.err, __ATOMIC_RELAXED))
-                r = huf_stream_wave(b.blk + c.s_off[st], c.s_len[st], lbase + c.s_out[st], c.s_n[st], hl, hseg, lane);
+                r = huf_stream_wave(b.blk + c.s_off[st], c.s_len[st], lbase + c.s_out[st], c.s_n[st], hl, hseg(), lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) { post_err(&c.err, r); __atomic_fetch_or(&c.streams_mask, 1u << st, __ATOMIC_RELAXED); __atomic_fetch_add(&c.streams_done, 1u, __ATOMIC_RELAXED); }
         }
@@ -141,7 +144,7 @@ __device__ __noinline__ void role_walk(BlockRun<TASKS> r) {
     __builtin_amdgcn_s_setprio(0);
     r.huf_helper();
     if (!TASKS && b.last && b.pos0 + b.bsize + (b.hashing ? 4u : 0u) == b.n) { // this block closes the file: the next file's headers, meanwhile
-        __builtin_amdgcn_s_setprio(MZD_PRE_PRIO); pre_parse_next(r.a, lane); __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(MZD_PRE_PRIO); pre_parse_next(*r.b.args, lane); __builtin_amdgcn_s_setprio(0);
     }
 }
 
@@ -195,7 +198,7 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
         }
         TFIN(3);
     }
-    if (TASKS && r.a.resolve) { // resolving launches: the repeat offsets go on to the successor as soon as this block's transform is known
+    if (TASKS && r.b.args->resolve) { // resolving launches: the repeat offsets go on to the successor as soon as this block's transform is known
         if (lane == 0) S.res[3] = rep_hop(b.fs, b.t, b.frame_first, seq_ok && r.nseq != 0 && !__atomic_load_n(&c.err, __ATOMIC_RELAXED), S.res_rep) ? 1u : 0u;
     }
     r.huf_helper(); // the ring (its staging area) is free: the walker has finished before the planner does
@@ -207,8 +210,8 @@ template <bool TASKS>
 __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored, int phase) {
     Ctl& c = S.c;
     const BlockArgs& b = r.b;
-    const KernelArgs& a = r.a;
-    const int lane = r.lane, wave = r.wave, tid = r.tid;
+    const KernelArgs& a = *r.b.args;
+    const int lane = r.lane, wave = r.wave, tid = r.wave * 64 + r.lane;
     const uint32_t lit_type = r.lit_type, nlit = r.nlit, streams = r.streams, t = b.t;
     uint8_t* const dst = b.dst;
     const bool frame_first = b.frame_first;
@@ -283,7 +286,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
             if (c.pred_err) { rc = 0; run = false; } // the file has already failed: nothing to copy (the error travels on)
         }
         if (run && r.get_seq() && (lit_type != 1 || spin_ge(&c.lit_done, 2, &c.err))) { // RLE literals: both halves filled
-            CopyCtx cx{b.seqs, dst, fstart, c.dict_content, c.dict_content_len, r.lit_in_place() ? r.place : r.lit, nlit, b.cap, lit_type >= 2 ? streams : 0u,
+            CopyCtx cx{b.seqs, dst, fstart, c.dict_content, c.dict_content_len, r.lit_in_place() ? r.place() : r.lit, nlit, b.cap, lit_type >= 2 ? streams : 0u,
                        {r0, r1, r2}, (TASKS && a.debug) ? b.seqs : nullptr};
             TFIN(9);
             __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); // second on the critical path, behind the walker
@@ -297,7 +300,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
             flag_store(&c.exec_done, 1);
             if (a.debug) {
                 DebugSlot& ds = a.debug[a.wg0 + blockIdx.x];
-                ds.n_lit = nlit; ds.n_seq = r.nseq; ds.lit_is_raw = lit_type == 0 || r.lit_in_place(); ds.lit_raw_ptr = (uint64_t)(uintptr_t)(r.lit_in_place() ? r.place : r.lit);
+                ds.n_lit = nlit; ds.n_seq = r.nseq; ds.lit_is_raw = lit_type == 0 || r.lit_in_place(); ds.lit_raw_ptr = (uint64_t)(uintptr_t)(r.lit_in_place() ? r.place() : r.lit);
                 if (TASKS && b.job == 0) atomicMax(&a.counter[1], (t << 12) | (a.wg0 + blockIdx.x)); // the slot that ran the last compressed block of job 0
             }
         }
@@ -378,10 +381,9 @@ __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const Bloc
     // wavefront INSIDE the pipeline, so the literal side (Huffman tree, streams) starts at once.
     // 2 KiB of LDS per decoding wavefront, borrowed from buffers that are idle while literals decode: the copier's staging
     // buffers (wave 1); the walker's ring (waves 0, 3: they decode after the walk)
-    BlockRun<TASKS> r{a, b, tid, lane, wave, lit_type, nlit, streams, 0u, seq_len, lit_off, seq_off,
-                      lit_type == 0 ? b.src + lit_off : b.lit_buf,
-                      wave == 1 ? S.stage + 2064 : (wave == 2 ? S.hseg2 : (wave == 0 ? S.ring : S.ring + 4096)),
-                      TASKS ? b.dst : b.dst + b.out0};
+    BlockRun<TASKS> r{b, lane, wave, lit_type, nlit, streams, 0u, seq_len, lit_off, seq_off,
+                      lit_type == 0 ? b.src + lit_off : b.lit_buf};
+    static_assert(sizeof(BlockRun<TASKS>) <= 64, "passed in registers");
     if (wave == 0) role_walk<TASKS>(r);
     else if (wave == 3) role_plan<TASKS>(r);
     else role_literals_then_copy_or_hash<TASKS>(r, xv, xstripes, mirrored, defer_copy ? 1 : 3);
@@ -392,7 +394,7 @@ __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const Bloc
 __device__ __forceinline__ void compressed_block_copy(const KernelArgs& a, const BlockArgs& b, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored, int tid, int lane, int wave) {
     Ctl& c = S.c;
     if (wave != 1 && wave != 2) return;
-    BlockRun<true> r{a, b, tid, lane, wave, c.lit_type, c.nlit, c.streams, 0u, c.seq_len, c.lit_off, c.seq_off,
-                     c.lit_type == 0 ? b.src + c.lit_off : b.lit_buf, wave == 1 ? S.stage + 2064 : S.hseg2, b.dst};
+    BlockRun<true> r{b, lane, wave, c.lit_type, c.nlit, c.streams, 0u, c.seq_len, c.lit_off, c.seq_off,
+                     c.lit_type == 0 ? b.src + c.lit_off : b.lit_buf};
     role_literals_then_copy_or_hash<true>(r, xv, xstripes, mirrored, 2);
 }

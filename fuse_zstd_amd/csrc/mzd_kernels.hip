@@ -202,12 +202,6 @@ __device__ __forceinline__ void clean_next_counters(const KernelArgs& a, int tid
 // ---- driver 1: one workgroup decodes a whole file, block after block.  Used when no file of the launch can have more
 // than one block (every output capacity <= 128 KiB): nothing is forked, nothing is published, the file's state
 // stays in registers and LDS.
-// The launch's arguments are read where the runtime put them (the kernel-argument segment: constant memory), never through the
-// by-value parameter: the roles take them by reference, and a reference to the parameter makes the compiler keep a copy of it per
-// LANE in the private segment -- 116 bytes x 256 lanes of stores per workgroup before anything else happens.
-__device__ __forceinline__ const KernelArgs& launch_args() {
-    return *reinterpret_cast<const KernelArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
-}
 __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs) {
     const KernelArgs& a = launch_args();
     // A workgroup's first ticket is its own index: one past the queue's end has nothing to do -- the launch behind the small-file
@@ -327,6 +321,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs) {
                     }
                 } else {
                     BlockArgs ba{src, n, dst, cap, dst2, src + pos0, bsize, pos0, out0, lit_buf, seqs, walk, last, hashing, block_pre, 0u, false, true, nullptr, nullptr, j};
+                    ba.args = &a;
                     if (!compressed_block<false>(a, ba, xv, xstripes, mirrored, tid, lane, wave)) break;
                 }
                 if (btype == 2) { // the block's repeat-offset transform (the planner leaves it symbolic) -> the offsets after it
@@ -554,6 +549,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
             // one that can copy at once is better off with the streaming copier, which runs beside the walk.
             const bool resolving = a.resolve != 0 && t != 0 && !(a.resolve == 2 && pred_done);
             BlockArgs ba{src, n, dst, cap, dst2, src + pos0, bsize, pos0, 0, lit_buf, seqs, walk, last, hashing, false, t, frame_first, is_final, fs, ta, j};
+            ba.args = &a;
             const bool started = compressed_block<true>(a, ba, xv, xstripes, mirrored, tid, lane, wave, resolving);
             bool resolved = false;
             if (resolving && started) {
