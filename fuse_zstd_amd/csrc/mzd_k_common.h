@@ -48,6 +48,26 @@ struct Ctl {
     uint64_t pred_out, pred_frame_out0, pred_xstripes, pred_xxh[4];
 };
 
+// One block of one file, as the drivers hand it to the block pipeline (mzd_k_pipeline.h).  The roles take it by reference: the workgroup's
+// copy is S.ba (on the stack it would be a copy per lane in the private segment).
+struct BlockArgs {
+    const uint8_t* src; uint64_t n;       // the file
+    uint8_t* dst; uint64_t cap;
+    uint8_t* dst2;                        // mirror of the output in pinned host memory, or null
+    const uint8_t* blk; uint32_t bsize;   // the block's content
+    uint64_t pos0;                        // its offset in the file
+    uint64_t out0;                        // TASKS = false: output position at the block's start
+    uint8_t* lit_buf; uint4* seqs; uint4* walk; // the workgroup's HBM scratch
+    uint32_t last;
+    bool hashing;
+    bool block_pre;                       // TASKS = false: headers already parsed (pre_parse_next)
+    // TASKS = true: the task
+    uint32_t t; bool frame_first, is_final;
+    FileState* fs; TableArea* ta;
+    uint32_t job;
+    const KernelArgs* args;               // the launch's arguments (the roles reach them through the block: launch_args)
+};
+
 constexpr uint32_t kResSymMax = 30;
 struct __attribute__((aligned(16))) Shared {
     uint8_t ring[kRingBytes + 16]; // first: at LDS offset 0 the walker's window address needs no base add
@@ -72,6 +92,7 @@ struct __attribute__((aligned(16))) Shared {
                                     // copier's literal scratch (kLitScratch): the copying wavefront is the one that decodes the weights, earlier
     uint32_t wtab[64];  // sym | nb << 8 | base << 16
     uint8_t weights[256];
+    BlockArgs ba;        // the block being decoded (written by thread 0 before the pipeline starts)
     uint64_t walk_dummy; // {its own address, 0}: the entry the walker's fourth lane follows (mzd_k_walk.h); outside what mzd_k_resolve.h overlays
     Ctl c;
     // driver 1, files of one block: while the copier and the hasher finish file A, the idle walking wavefront takes the

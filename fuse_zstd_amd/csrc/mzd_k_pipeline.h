@@ -19,23 +19,7 @@
 #define MZD_MIRROR_MIN 2048 // bytes of finished output before the hashing wavefront turns to the host mirror
 #endif
 
-struct BlockArgs {
-    const uint8_t* src; uint64_t n;       // the file
-    uint8_t* dst; uint64_t cap;
-    uint8_t* dst2;                        // mirror of the output in pinned host memory, or null
-    const uint8_t* blk; uint32_t bsize;   // the block's content
-    uint64_t pos0;                        // its offset in the file
-    uint64_t out0;                        // TASKS = false: output position at the block's start
-    uint8_t* lit_buf; uint4* seqs; uint4* walk; // the workgroup's HBM scratch
-    uint32_t last;
-    bool hashing;
-    bool block_pre;                       // TASKS = false: headers already parsed (pre_parse_next)
-    // TASKS = true: the task
-    uint32_t t; bool frame_first, is_final;
-    FileState* fs; TableArea* ta;
-    uint32_t job;
-    const KernelArgs* args = nullptr;     // the launch's arguments (set by compressed_block: the roles reach them through the block)
-};
+// (BlockArgs: mzd_k_common.h -- the workgroup's copy lives in the LDS image)
 
 // What the roles of one block share (all values wave-uniform).  The roles are separate functions -- each wavefront calls
 // exactly one, so each gets a register allocation of its own instead of one allocation for all four roles' live values.

@@ -320,9 +320,10 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs) {
                         if (tid == 0) { c.out = out0 + bsize; c.pos = pos0 + 1; }
                     }
                 } else {
-                    BlockArgs ba{src, n, dst, cap, dst2, src + pos0, bsize, pos0, out0, lit_buf, seqs, walk, last, hashing, block_pre, 0u, false, true, nullptr, nullptr, j};
-                    ba.args = &a;
-                    if (!compressed_block<false>(a, ba, xv, xstripes, mirrored, tid, lane, wave)) break;
+                    // (the block's arguments live in LDS: the roles take them by reference, and on the stack they would be a copy per lane)
+                    if (tid == 0) { S.ba = BlockArgs{src, n, dst, cap, dst2, src + pos0, bsize, pos0, out0, lit_buf, seqs, walk, last, hashing, block_pre, 0u, false, true, nullptr, nullptr, j, &a}; }
+                    __syncthreads();
+                    if (!compressed_block<false>(a, S.ba, xv, xstripes, mirrored, tid, lane, wave)) break;
                 }
                 if (btype == 2) { // the block's repeat-offset transform (the planner leaves it symbolic) -> the offsets after it
                     __syncthreads();
@@ -548,8 +549,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
             // resolve == 2 (a launch with many tasks per workgroup slot): only a task whose predecessor is NOT done yet resolves ahead --
             // one that can copy at once is better off with the streaming copier, which runs beside the walk.
             const bool resolving = a.resolve != 0 && t != 0 && !(a.resolve == 2 && pred_done);
-            BlockArgs ba{src, n, dst, cap, dst2, src + pos0, bsize, pos0, 0, lit_buf, seqs, walk, last, hashing, false, t, frame_first, is_final, fs, ta, j};
-            ba.args = &a;
+            if (tid == 0) { S.ba = BlockArgs{src, n, dst, cap, dst2, src + pos0, bsize, pos0, 0, lit_buf, seqs, walk, last, hashing, false, t, frame_first, is_final, fs, ta, j, &a}; }
+            __syncthreads();
+            const BlockArgs& ba = S.ba; // (in LDS: see driver 1)
             const bool started = compressed_block<true>(a, ba, xv, xstripes, mirrored, tid, lane, wave, resolving);
             bool resolved = false;
             if (resolving && started) {
