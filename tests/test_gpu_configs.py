@@ -69,6 +69,44 @@ def test_config3_full_size():
 
 
 @needs_zstd
+@pytest.mark.parametrize("mode", [0, 1])
+def test_single_block_files_of_very_different_cost_in_a_launch_that_fills_the_machine(mode):
+    """2 600 single-block frames of 20 .. 128 KiB from seven data classes (more than two per workgroup slot, compressed sizes from
+    a few hundred bytes to the frame's own size): mode 0, the library's choice, hands them out by compressed size, largest first
+    (make_plan: lpt through the job list); mode 1 is the same driver in the caller's order.  Also a few error cases in the batch:
+    statuses must stay with their files whatever the order."""
+    rng = np.random.RandomState(99)
+    sizes = [int(x) for x in rng.randint(20000, 131073, size=2600)]
+    cp = corpus.build_corpus("text", 33, sizes, kind_mod=7)
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    comp_np = cp.comp.copy()
+    bad_files = [5, 1300, 2599]
+    for i in bad_files:  # break the magic number of three files
+        comp_np[int(cp.comp_offs[i])] ^= 0xFF
+    comp = torch.from_numpy(comp_np).to(dev)
+    end = int(cp.raw_offs[-1] + cp.raw_sizes[-1])
+    out = torch.zeros(end + 64, dtype=torch.uint8, device=dev)
+    jobs = mzd.api.make_jobs([comp.data_ptr() + int(o) for o in cp.comp_offs], cp.comp_sizes, [out.data_ptr() + int(o) for o in cp.raw_offs], cp.raw_sizes)
+    mzd.set_driver(mode)
+    try:
+        res = mzd.decode_batch_device(0, jobs)
+    finally:
+        mzd.set_driver(0)
+    got = out.cpu().numpy()
+    for i, (st, n) in enumerate(res):
+        if i in bad_files:
+            assert st == mzd.api.E_BADMAGIC, (i, st)
+            continue
+        assert st == 0 and n == int(cp.raw_sizes[i]), (i, st, n)
+    for i in range(0, cp.nfiles, 41):
+        if i in bad_files:
+            continue
+        o = int(cp.raw_offs[i])
+        assert bytes(got[o:o + int(cp.raw_sizes[i])]) == cp.raw_file(i).tobytes(), i
+
+
+@needs_zstd
 def test_config4_full_size_takes_the_small_file_kernel():
     """BASELINE configs[3] / the north_star's corpus: 10 000 x 4 KiB JSON files (parallel-files.fio shape) in one launch:
     the small-file kernel decodes all of them (nothing is handed on: counter word 4)."""
