@@ -162,7 +162,7 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
                 }
             }
             g_settle();
-            if (lane == 0) { g_store(&fs->tables_ver, b.t + 1); c.tables_published = 1; }
+            if (lane == 0) { g_publish(&fs->tables_ver, b.t + 1); c.tables_published = 1; }
         }
     }
     if (seq_ok && r.nseq) {

@@ -128,6 +128,11 @@ __device__ __forceinline__ void g_store(uint32_t* p, uint32_t v) { __hip_atomic_
 template <class T> __device__ __forceinline__ T g_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void g_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void g_settle() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// ... and that is NOT enough across XCDs: with the data stores merely waited for (vmcnt) a successor on another XCD saw the flag
+// before the data about once in a hundred runs of a 586-block file (the checksum chain's state: right bytes, wrong digest -- found
+// when this round's faster task start changed the timing; `tools/stress_handover.py`).  Every flag that publishes such data is
+// therefore stored behind an agent-scope RELEASE (L2 write-back + wait), like the one that publishes the output bytes.
+__device__ __forceinline__ void g_publish(uint32_t* flag, uint32_t v) { g_release(); g_store(flag, v); }
 // wait until *p >= want (bounded: a launch that lost a task must end, not hang); one lane calls this
 __device__ __noinline__ bool g_wait_ge(const uint32_t* p, uint32_t want) {
     for (uint32_t it = 0; it < (1u << 23); it++) {
@@ -184,7 +189,7 @@ __device__ __noinline__ bool rep_hop(FileState* fs, uint32_t t, bool frame_first
     else { Rf.s = 0 | (1 << 2) | (2 << 4); Rf.v0 = 0; Rf.v1 = 0; Rf.v2 = 0; }
     g_st(&fs->rep_e[0], rep_eval(Rf, 0, r0, r1, r2)); g_st(&fs->rep_e[1], rep_eval(Rf, 1, r0, r1, r2)); g_st(&fs->rep_e[2], rep_eval(Rf, 2, r0, r1, r2));
     g_settle();
-    g_store(&fs->rep_ver, t + 1);
+    g_publish(&fs->rep_ver, t + 1);
     return ok;
 }
 
@@ -508,6 +513,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                     g_st(&r->job, j); g_st(&r->task, t + 1); g_st(&r->pos, next_pos); g_st(&r->in_frame, last ? 0u : 1u); g_st(&r->with_dict, c.with_dict);
                     g_st(&r->has_fcs, c.has_fcs); g_st(&r->has_cksum, c.has_cksum); g_st(&r->block_max, c.block_max); g_st(&r->fcs, c.fcs);
                     g_settle();
+                    g_release(); // (see g_publish)
                     __hip_atomic_store(&r->seq, ((uint64_t)a.epoch << 32) | (uint64_t)(m + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -627,7 +633,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                                         if (herr_now) { g_st(&fs->herr_out, out0); g_st(&fs->herr, (int32_t)herr_now); }
                                     }
                                     g_settle();
-                                    if (lane == 0) g_store(&fs->hashed, t + 1);
+                                    if (lane == 0) g_publish(&fs->hashed, t + 1);
                                 }
                                 TFIN(2);
                             } else {
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                     }
                     g_settle();
                     __syncthreads();
-                    if (tid == 0) g_store(&fs->tables_ver, t + 1);
+                    if (tid == 0) g_publish(&fs->tables_ver, t + 1);
                 }
             }
             if (tid == 0) {

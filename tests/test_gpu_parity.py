@@ -172,6 +172,19 @@ def test_small_file_kernel_intermediates_match_cpu_twin():
     assert checked >= 6, (checked, skipped)
 
 
+def test_hand_over_between_block_tasks_holds_under_repetition():
+    """Every positive vector in one batch, 250 times, under the library's own choice of driver.  `window_log10` is 586 blocks of
+    1 KiB, each a task on another workgroup (often another XCD), resolved ahead of its predecessor, with the checksum chain's state
+    travelling from task to task behind its own flag: a hand-over flag stored without an agent-scope release in front of it let a
+    successor see the flag before the data about once in a hundred runs (right bytes, wrong digest; tools/stress_handover.py)."""
+    vs = [v for v in VECS if v.ok and v.dict is None]
+    comps, caps = [v.comp for v in vs], [v.out_len for v in vs]
+    for rep in range(250):
+        res = mzd.decode_batch(comps, caps)
+        bad = [(v.name, st) for v, (st, out) in zip(vs, res) if st != 0 or out != v.expected()]
+        assert not bad, (rep, bad)
+
+
 @pytest.mark.parametrize("driver", DRIVERS)
 def test_both_drivers_decode_every_vector(driver, force_driver):
     """The library has two kernel drivers: one workgroup per file (launches whose capacities are all <= 128 KiB) and
