@@ -150,13 +150,22 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
     // the literals are still being decoded).  Their latency is taken off this wavefront's critical path
     // by a two-stage software pipeline: while chunk k is planned, the records of chunk k+2 and the bit
     // windows of chunk k+1 are in flight.
-    const uint32_t bias = 16 + (uint32_t)((uintptr_t)cx.seq_sp & 15);
-    const uint8_t* const gbase = cx.seq_sp - bias;
+    // (the context lives in the caller's frame: what the loop uses is read once, into scalar registers; HBM is addressed through GLOBAL
+    //  pointers -- a flat access also counts on the LDS counter, so every wait for a table entry would wait for the records and bit
+    //  windows that are in flight for the chunks ahead)
+    auto u32_ = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto u64_ = [&](uint64_t v) -> uint64_t { return (uint64_t)u32_((uint32_t)v) | ((uint64_t)u32_((uint32_t)(v >> 32)) << 32); };
+    typedef __attribute__((address_space(1))) uint8_t* gptr;
+    const uint8_t* const seq_sp = (const uint8_t*)(uintptr_t)u64_((uint64_t)(uintptr_t)cx.seq_sp);
+    const uint32_t cx_nlit = u32_(cx.nlit);
+    uint4* const chunk_base = (uint4*)(uintptr_t)u64_((uint64_t)(uintptr_t)cx.chunk_base);
+    const uint32_t bias = 16 + (uint32_t)((uintptr_t)seq_sp & 15);
+    const uint8_t* const gbase = seq_sp - bias;
     auto wait_walker = [&](uint32_t need) -> bool { // true when sequences [0, need) are recorded
         if (need > nseq) need = nseq;
         uint32_t pg = 0, it = 0;
         for (; it < (1u << 24); it++) {
-            pg = flag_load_u(cx.prog);
+            pg = flag_load_u(&S.c.walk_prog); // (= cx.prog, spelled as the LDS word it is: through the generic pointer it was a flat load)
             if ((pg & ~kWalkFin) >= need || (pg & kWalkFin)) break;
             __builtin_amdgcn_s_sleep(4);
         }
@@ -167,8 +176,8 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
     struct Win { uint32_t hL, hM, hO, G; uint64_t bO, bM, bL; }; // entry words + raw 8-byte windows of one sequence
     // records are 8 bytes (walk_record): three 16-bit state addresses and the low 16 bits of (read head - 32).  A chunk's positions are
     // unwrapped against its first record's, and that one against the chunk before (64 sequences consume < 2^16 bits)
-    const uint2* const recs = reinterpret_cast<const uint2*>(cx.walk);
-    auto load_rec = [&](uint32_t idx) -> uint2 { return idx < nseq ? recs[idx] : make_uint2(0, 0); };
+    const uint2* const recs = reinterpret_cast<const uint2*>((uintptr_t)u64_((uint64_t)(uintptr_t)cx.walk));
+    auto load_rec = [&](uint32_t idx) -> uint2 { uint2 r = make_uint2(0, 0); if (idx < nseq) __builtin_memcpy(&r, (gcptr)(recs + idx), 8); return r; };
     auto unwrap = [&](uint2 w, uint32_t first_full) -> uint32_t { // full (read head - 32) of a record of the chunk whose first record is at first_full
         const uint32_t first16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w.y >> 16));
         return first_full - ((first16 - (w.y >> 16)) & 0xFFFFu);
@@ -181,7 +190,8 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         if (live) {
             const uint32_t xM = o.hM >> 24, xO = o.hO >> 24, xL = o.hL >> 24;
             const uint32_t tO = o.G - xO, tM = tO - xM, tL = tM - xL; // bottoms of the three fields
-            o.bO = ldu64(gbase + (tO >> 3)); o.bM = ldu64(gbase + (tM >> 3)); o.bL = ldu64(gbase + (tL >> 3));
+            const gcptr gb = (gcptr)gbase;
+            __builtin_memcpy(&o.bO, gb + (tO >> 3), 8); __builtin_memcpy(&o.bM, gb + (tM >> 3), 8); __builtin_memcpy(&o.bL, gb + (tL >> 3), 8);
         }
     };
     if (!wait_walker(128)) return MZD_E_CORRUPT;
@@ -198,7 +208,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
         const uint32_t i = base + (uint32_t)lane;
         const bool valid = (uint32_t)lane < cnt;
-        if (lane == 0) cx.chunk_base[chunk] = make_uint4(opos, lpos, 0, 0);
+        if (lane == 0) { const uint4 cb_ = make_uint4(opos, lpos, 0, 0); __builtin_memcpy((gptr)(uintptr_t)(chunk_base + chunk), &cb_, 16); }
         // everything this wavefront stored an iteration ago has landed: chunk k-1 of the plan is public
         wg_fence();
         if (lane == 0) flag_store(&S.c.plan_prog, chunk);
@@ -313,8 +323,8 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint32_t ex_t = incl_t - tot; // this sequence's output offset inside the 64-chunk
         // the plan of this sequence: {ll, ml, offset, output offset inside the chunk} -> HBM (unbounded, so the
         // planner never waits for the copier, which may still be decoding literals); also what mzd_debug_last_block shows
-        if (valid) seqs[i] = make_uint4(ll, ml, off, ex_t);
-        if (chunk_lit > cx.nlit - lpos || opos + chunk_tot > kBlockMax) {
+        if (valid) { const uint4 pe_ = make_uint4(ll, ml, off, ex_t); __builtin_memcpy((gptr)(uintptr_t)(seqs + i), &pe_, 16); }
+        if (chunk_lit > cx_nlit - lpos || opos + chunk_tot > kBlockMax) {
             // the literals run out, or the block's output passes 128 KiB, inside this chunk: it is still published -- the copier
             // finds the first offending sequence in stream order -- and it is the plan's last (the mark is set first)
             if (lane == 0) S.c.plan_too_long = 1;
@@ -325,7 +335,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         opos += chunk_tot;
         lpos += chunk_lit;
     }
-    const uint32_t rest = cx.nlit - lpos;
+    const uint32_t rest = cx_nlit - lpos;
     wg_fence();
     if (lane == 0) {
         S.c.rep_op[0] = R.s; S.c.rep_op[1] = (uint32_t)R.v0; S.c.rep_op[2] = (uint32_t)R.v1; S.c.rep_op[3] = (uint32_t)R.v2;
@@ -570,7 +580,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         wg_fence();
         CSTAMP(6);
         if (lane == 0) __atomic_store_n(&S.c.exec_pos, ri.run_pos, __ATOMIC_RELAXED); // everything before this run has landed
-        uint8_t* g = dst + ri.run_pos;
+        __attribute__((address_space(1))) uint8_t* const g = (__attribute__((address_space(1))) uint8_t*)(dst + ri.run_pos); // (global stores)
         for (uint32_t k = (uint32_t)lane * 16; k + 16 <= ri.T; k += 1024) {
             uint4 v = *reinterpret_cast<const uint4*>(sb + k);
             __builtin_memcpy(g + k, &v, 16);
@@ -583,7 +593,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     uint4 pe_next = make_uint4(0, 0, 0, 0);
     if (nseq) {
         if (!wait_plan(1)) return MZD_E_CORRUPT; // the planner failed and posted the error
-        if ((uint32_t)lane < nseq) pe_next = plan[lane];
+        if ((uint32_t)lane < nseq) __builtin_memcpy(&pe_next, (gcptr)(uintptr_t)(plan + lane), 16); // (global, not flat: see plan_wave)
     }
     uint32_t chunk = 0;
     uint32_t blk_room = kBlockMax; // bytes left under the block limit
@@ -598,7 +608,8 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             if (wait_plan(chunk + 2)) {
                 CSTAMP(0);
                 const uint32_t j = base + 64 + (uint32_t)lane;
-                pe_next = j < nseq ? plan[j] : make_uint4(0, 0, 0, 0);
+                pe_next = make_uint4(0, 0, 0, 0);
+                if (j < nseq) __builtin_memcpy(&pe_next, (gcptr)(uintptr_t)(plan + j), 16);
             } else if (flag_load_u(&S.c.plan_too_long) == 1) cut = true;
             else return MZD_E_CORRUPT;
         }
