@@ -37,7 +37,7 @@ class Job(C.Structure):  # mzd_job
 def build(force=False):
     """hipcc --offload-arch=gfx950 build of libmzd.so, in-tree (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("mzd_kernels.hip", "mzd_lds.hip", "mzd_host.cpp", "mzd_device.h", "mzd_tables.h") + tuple(f for f in os.listdir(src_dir) if f.startswith("mzd_k_"))]
+    srcs = [os.path.join(src_dir, f) for f in ("mzd_kernels.hip", "mzd_lds.hip", "mzd_host.cpp", "mzd_device.h", "mzd_tables.h") + tuple(f for f in os.listdir(src_dir) if f.startswith(("mzd_k_", "mzd_l_")))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mzd.h"))
     def stale():
         return force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
@@ -49,7 +49,7 @@ def build(force=False):
             fcntl.flock(lk, fcntl.LOCK_EX)
             try:
                 if stale():
-                    subprocess.check_call(["make", "-C", src_dir, "-s"])
+                    subprocess.check_call(["make", "-C", src_dir, "-s", "-j3"])
             finally:
                 fcntl.flock(lk, fcntl.LOCK_UN)
     return _SO

@@ -85,7 +85,8 @@ constexpr uint32_t kShWalkDummy = 360; // 8 bytes: {its own address, 0}: the ent
 constexpr uint32_t kShDump = 384;  // 8 bytes per lane: where the stores of idle lanes go (select-style code: no branch around a store)
 constexpr uint32_t kShBytes = 896;
 constexpr uint32_t kDLL = 0, kDML = 4096, kDOF = 8192, kDHuf = 10240, kDictImg = 14336; // FSE entries of 8 bytes, Huffman entries of 2
-constexpr uint32_t kAux = 256;    // per file: the normalized counts of the three sequence tables, later the walk records / the plan
+constexpr uint32_t kAuxCounts = 256; // per file: the normalized counts of the three sequence tables, later the walk records; behind them the table builders' work memory
+constexpr uint32_t kAux = kAuxCounts + 192; // (= kFseWork, mzd_l_tables.h)
 // scratch of the Huffman weights: their FSE table [64 x 8] | its counts
 constexpr uint32_t kWTab = 0, kWNorm = 512; // in the table area, which the Huffman table takes over once the weights are decoded; the weights themselves: the ring
 
@@ -153,6 +154,9 @@ template <int N, class F> DI void static_for(F&& f) {
 DI uint64_t fse_entry(uint32_t tab_off, uint32_t nbase, uint32_t nb, uint32_t sym, uint32_t extra) {
     return (uint64_t)(tab_off + nbase * 8u) | ((uint64_t)(nb | ((extra + nb) << 8) | (sym << 16) | (extra << 24)) << 32);
 }
+
+#include "mzd_l_tables.h"
+static_assert(kAux == kAuxCounts + kFseWork, "the table builders' work memory lies behind the counts");
 
 // ------------------------------------------------------------------------------------ bit readers over LDS bytes
 struct LBack { // backward (the Huffman weights' stream: <= 128 bytes), zero below the start
@@ -628,12 +632,26 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
         uint32_t huf_log = di.huf_log, huf_off = dict_off + kDHuf; // treeless: the dictionary's table
         if (live && lit_type == 2) {
             uint32_t good = 0, maxbits_l = 0, nw_l = 0;
+            const uint32_t wts = ringo, wtab = tabo + kWTab, wnorm = tabo + kWNorm;
+            const uint32_t tp = cmp + tree_off; // the tree description
+            const uint32_t hb = L8(tp);
+            // FSE-coded weights: their normalized counts (the file's first lane), then their decode table (all its lanes)
+            uint32_t w_nsym = 0, w_log = 0, w_hdr = 0;
+            if (leader && hb < 128) {
+                w_hdr = read_ncount_lane(tp + 1, hb, 6, 255, 16, wnorm, w_nsym, w_log);
+                if (w_hdr >= hb) w_hdr = 0;
+            }
+            {
+                const int ld = (int)(f * LPF);
+                w_hdr = (uint32_t)__shfl((int)w_hdr, ld); w_nsym = (uint32_t)__shfl((int)w_nsym, ld); w_log = (uint32_t)__shfl((int)w_log, ld);
+            }
+            wsync();
+            SSTAMP(13);
+            const bool w_tab = build_fse_file<3, (int)LPF>(w_hdr != 0, wtab, wnorm, w_nsym, w_log, ringo + kAuxCounts, sub);
+            SSTAMP(14);
             if (leader) {
-                const uint32_t wts = ringo, wtab = tabo + kWTab, wnorm = tabo + kWNorm;
                 uint32_t nw = 0;
                 do {
-                    const uint32_t tp = cmp + tree_off; // the tree description
-                    const uint32_t hb = L8(tp);
                     if (hb >= 128) { // direct: 4 bits per weight, high nibble first
                         nw = hb - 127;
                         for (uint32_t i = 0; i < nw; i++) {
@@ -641,12 +659,8 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                             L8(wts + i) = (uint8_t)((i & 1) ? (by & 15) : (by >> 4));
                         }
                     } else {
-                        uint32_t nsym = 0, log = 0;
-                        const uint32_t hdr = read_ncount_lane(tp + 1, hb, 6, 255, 16, wnorm, nsym, log);
-                        if (hdr == 0 || hdr >= hb) break;
-                        SSTAMP(13);
-                        if (!build_fse_lane(wtab, wnorm, nsym, log, 3)) break;
-                        SSTAMP(14);
+                        if (w_hdr == 0 || !w_tab) break;
+                        const uint32_t hdr = w_hdr, log = w_log;
                         // two interleaved states over a backward bitstream of <= 127 bytes; the stream's over-read ends it (A.4).  Both
                         // states' entries are fetched together (one round trip per two weights); the unread bits sit top-aligned in a
                         // 64-bit register, re-read from LDS once per pair (two fields of <= 6 bits).
@@ -703,7 +717,6 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
             // scanned into start positions (weight 1 = longest codes first), and every lane fills the entries of its own symbols in
             // ascending order -- no counter is read back from LDS.
             if (good) {
-                const uint32_t wts = ringo;
                 constexpr uint32_t NCL = (12 + LPF - 1) / LPF;
                 const uint32_t words = (nw_l + 8) / 8; // (covers index nw: the implied last weight is appended below)
                 auto eqflags = [&](uint32_t word, uint32_t v) -> uint32_t { // 0x80 in every byte of `word` that equals v (all bytes < 0x80)
@@ -896,7 +909,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                             if (p + 1 > seq_len) { tbad = true; break; }
                             rs = L8(sp + p); p++;
                             if (rs > (uint32_t)max_sym) { tbad = true; break; }
-                            tab = tabo + 8 * used_entries; used_entries += 1; al = 0;
+                            tab = tabo + 8 * used_entries; used_entries += 2; al = 0; // (two entries: every table starts 16-byte aligned)
                         } else if (m == 2) {
                             if (p >= seq_len) { tbad = true; break; }
                             const uint32_t used = read_ncount_lane(sp + p, seq_len - p, max_log, max_sym, max_sym + 1, noff, ns, al);
@@ -927,24 +940,25 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
         wsync();
         SSTAMP(5);
 
-        // =============================== FSE decode tables (lane = (file, table))
+        // =============================== FSE decode tables (every table by all the lanes of its file: mzd_l_tables.h)
         {
-            uint32_t tb_bad = 0;
-            if (live && nseq && sub < 3) {
+            const bool tables = live && nseq != 0;
+            const uint32_t mL = modes3 & 3, mO = (modes3 >> 2) & 3, mM = (modes3 >> 4) & 3;
+            if (tables && sub < 3) { // a table of one symbol (RLE mode)
                 const int t = (int)sub;
                 const uint32_t m = (modes3 >> (2 * t)) & 3;
-                const uint32_t tab = t == 0 ? tabL : (t == 1 ? tabO : tabM), al = t == 0 ? alL : (t == 1 ? alO : alM);
                 if (m == 1) {
+                    const uint32_t tab = t == 0 ? tabL : (t == 1 ? tabO : tabM);
                     const uint32_t s = (rle_syms >> (8 * t)) & 0xFF;
                     const uint32_t extra = t == 0 ? L32(kShLL + 4 * s) >> 24 : (t == 1 ? s : L32(kShML + 4 * s) >> 24);
                     L64(tab) = fse_entry(tab, 0, 0, s, extra);
-                } else if (m == 0 || m == 2) {
-                    const uint32_t noff = ringo + (t == 0 ? 0u : (t == 1 ? 72u : 136u));
-                    if (!build_fse_lane(tab, noff, (nsyms >> (8 * t)) & 0xFF, al, t)) tb_bad = 1;
                 }
             }
-            const uint64_t badm = __ballot(tb_bad != 0);
-            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) { ok = false; live = false; nseq = 0; why = 5; }
+            const uint32_t work = ringo + kAuxCounts;
+            bool tg = build_fse_file<0, (int)LPF>(tables && (mL == 0 || mL == 2), tabL, ringo, nsyms & 0xFF, alL, work, sub);
+            tg &= build_fse_file<1, (int)LPF>(tables && (mO == 0 || mO == 2), tabO, ringo + 72, (nsyms >> 8) & 0xFF, alO, work, sub);
+            tg &= build_fse_file<2, (int)LPF>(tables && (mM == 0 || mM == 2), tabM, ringo + 136, (nsyms >> 16) & 0xFF, alM, work, sub);
+            if (!tg) { ok = false; live = false; nseq = 0; why = 5; }
         }
         wsync();
         SSTAMP(6);
