@@ -55,7 +55,7 @@ DI bool build_fse_file(bool act, uint32_t tab, uint32_t norm_off, uint32_t nsym,
         if (c == -1) { // position size - 1 - (its index among the "less than one" symbols): taken out of the spread
             const uint32_t q = (mask - (before >> 16)) & mask;
             const uint32_t k = (q * inv) & mask;
-            __hip_atomic_fetch_or(static_cast<uint32_t*>(__builtin_assume_aligned(lds + skipo + 4 * (k >> 5), 4)), 1u << (k & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_or32(skipo + 4 * (k >> 5), 1u << (k & 31));
         }
     }
     const uint32_t nlow = carry >> 16, high = size - nlow;
@@ -115,7 +115,7 @@ DI bool build_fse_file(bool act, uint32_t tab, uint32_t norm_off, uint32_t nsym,
         const bool on = p < high;
         const uint32_t s = on ? L8(tab + 7 * size + p) : 0u;
         const uint32_t mo = lmo + 4 * (s >> 1), sh = 16 * (s & 1);
-        if (on) __hip_atomic_fetch_or(static_cast<uint32_t*>(__builtin_assume_aligned(lds + mo, 4)), (1u << sub) << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (on) lds_or32(mo, (1u << sub) << sh);
         wsync();
         if (on) {
             const uint32_t lm = (L32(mo) >> sh) & 0xFFFF;

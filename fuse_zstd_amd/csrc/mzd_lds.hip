@@ -55,20 +55,27 @@ DI int hibit32(uint32_t v) { return 31 - __builtin_clz(v); }
 DI uint32_t bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); } // (offset and width: low 5 bits)
 
 // ------------------------------------------------------------------------------------ LDS image (dynamic)
+// Offsets are LDS ADDRESSES: the dynamic segment is the kernel's only LDS object, so it starts at 0 (checked at kernel entry; a
+// launch where it does not hands every file on).  Spelled through the array's symbol, every access with a computed address
+// cost one more instruction (`v_add_u32 v, lds, v` with lds = 0, resolved only at link time).
 extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-DI uint32_t& L32(uint32_t off) { return *reinterpret_cast<uint32_t*>(lds + off); }
-DI uint16_t& L16(uint32_t off) { return *reinterpret_cast<uint16_t*>(lds + off); }
-DI int16_t& L16s(uint32_t off) { return *reinterpret_cast<int16_t*>(lds + off); }
-DI uint8_t& L8(uint32_t off) { return lds[off]; }
-DI uint64_t& L64(uint32_t off) { return *reinterpret_cast<uint64_t*>(lds + off); } // 8-byte aligned
-DI uint64_t lds_u64(uint32_t off) { uint64_t v; __builtin_memcpy(&v, lds + off, 8); return v; } // any alignment
-DI uint32_t lds_u32(uint32_t off) { uint32_t v; __builtin_memcpy(&v, lds + off, 4); return v; }
-DI V16 lds_v16(uint32_t off) { return *reinterpret_cast<const V16*>(lds + off); } // 16-byte aligned
-DI void lds_sv16(uint32_t off, const V16& v) { *reinterpret_cast<V16*>(lds + off) = v; }
+#define MZD_LDS_AS __attribute__((address_space(3)))
+template <class T> DI MZD_LDS_AS T* lptr(uint32_t off) { return (MZD_LDS_AS T*)(uintptr_t)off; }
+DI MZD_LDS_AS uint32_t& L32(uint32_t off) { return *lptr<uint32_t>(off); }
+DI MZD_LDS_AS uint16_t& L16(uint32_t off) { return *lptr<uint16_t>(off); }
+DI MZD_LDS_AS int16_t& L16s(uint32_t off) { return *lptr<int16_t>(off); }
+DI MZD_LDS_AS uint8_t& L8(uint32_t off) { return *lptr<uint8_t>(off); }
+DI MZD_LDS_AS uint64_t& L64(uint32_t off) { return *lptr<uint64_t>(off); } // 8-byte aligned
+DI uint64_t lds_u64(uint32_t off) { uint64_t v; __builtin_memcpy(&v, lptr<uint8_t>(off), 8); return v; } // any alignment
+DI uint32_t lds_u32(uint32_t off) { uint32_t v; __builtin_memcpy(&v, lptr<uint8_t>(off), 4); return v; }
+DI V16 lds_u128(uint32_t off) { V16 v; __builtin_memcpy(&v, lptr<uint8_t>(off), 16); return v; } // any alignment: ONE ds_read_b128 (two of them for 32 bytes ran faster than the ds_read2_b64 pairs the compiler makes of four 8-byte reads)
+DI V16 lds_v16(uint32_t off) { V16 v; __builtin_memcpy(&v, (MZD_LDS_AS uint8_t*)__builtin_assume_aligned(lptr<uint8_t>(off), 16), 16); return v; } // 16-byte aligned
+DI void lds_sv16(uint32_t off, const V16& v) { __builtin_memcpy((MZD_LDS_AS uint8_t*)__builtin_assume_aligned(lptr<uint8_t>(off), 16), &v, 16); }
 
-DI void lds_s64(uint32_t off, uint64_t v) { __builtin_memcpy(lds + off, &v, 8); } // any alignment
-DI void lds_s32(uint32_t off, uint32_t v) { __builtin_memcpy(lds + off, &v, 4); }
-DI void lds_s16(uint32_t off, uint32_t v) { const uint16_t w = (uint16_t)v; __builtin_memcpy(lds + off, &w, 2); }
+DI void lds_s64(uint32_t off, uint64_t v) { __builtin_memcpy(lptr<uint8_t>(off), &v, 8); } // any alignment
+DI void lds_s32(uint32_t off, uint32_t v) { __builtin_memcpy(lptr<uint8_t>(off), &v, 4); }
+DI void lds_s16(uint32_t off, uint32_t v) { const uint16_t w = (uint16_t)v; __builtin_memcpy(lptr<uint8_t>(off), &w, 2); }
+DI void lds_or32(uint32_t off, uint32_t v) { __hip_atomic_fetch_or(lptr<uint32_t>(off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // The lanes of a wavefront talk through LDS without a barrier: a wavefront's LDS operations execute in issue order, so a
 // read issued after another lane's write sees it.  What has to be kept is the ORDER OF ISSUE: no memory operation moves
@@ -88,7 +95,7 @@ constexpr uint32_t kDLL = 0, kDML = 4096, kDOF = 8192, kDHuf = 10240, kDictImg =
 constexpr uint32_t kAuxCounts = 256; // per file: the normalized counts of the three sequence tables, later the walk records; behind them the table builders' work memory
 constexpr uint32_t kAux = kAuxCounts + 192; // (= kFseWork, mzd_l_tables.h)
 // scratch of the Huffman weights: their FSE table [64 x 8] | its counts
-constexpr uint32_t kWTab = 0, kWNorm = 512; // in the table area, which the Huffman table takes over once the weights are decoded; the weights themselves: the ring
+constexpr uint32_t kWTab = 0, kWNorm = 512, kWStage = 576; // (the weights' bitstream behind 16 zero bytes: 576 .. 720) // in the table area, which the Huffman table takes over once the weights are decoded; the weights themselves: the ring
 
 // ---- the file's LPF lanes (LPF = 16, 8 or 4: inside one DPP row of 16 lanes)
 // the value of the lane N below, 0 for the file's first N lanes
@@ -167,7 +174,7 @@ struct LBack { // backward (the Huffman weights' stream: <= 128 bytes), zero bel
     DI bool init(uint32_t off, uint32_t sl) {
         base = off; cur = 0; avail = 0; h = 0;
         if (sl == 0) return false;
-        const uint32_t last = lds[off + sl - 1];
+        const uint32_t last = L8(off + sl - 1);
         if (last == 0) return false;
         h = (int32_t)((sl - 1) * 8) + hibit32(last);
         return true;
@@ -189,113 +196,51 @@ struct LBack { // backward (the Huffman weights' stream: <= 128 bytes), zero bel
     }
 };
 
-// Normalized counts (A.3) from LDS bytes (>= 8 readable bytes behind them) -> int16 norm[] in LDS at `norm_off`.  Returns bytes
-// used or 0 (give up).  sym_cap: symbols the caller has room for (<= max_sym + 1).  The description is read upwards through a
-// 64-bit register window, re-read from LDS when fewer than 16 of its bits are left (a lone lane pays a round trip per LDS read:
-// one per five or six symbols instead of one per symbol).  Bits past the description's end need no masking: a field that
-// touches them either leaves `bit` past the limit (rejected), or it is the short form of a value whose dropped bit was the only
-// one outside.
+// Normalized counts (A.3) from LDS bytes (>= 16 readable bytes behind them) -> int16 norm[] in LDS at `norm_off` (up to three
+// entries past the last symbol are written too: zeros).  Returns bytes used or 0 (give up).  sym_cap: symbols the caller has room
+// for (<= max_sym + 1).  One lane per file, the files of a group in lockstep, so a round is ONE straight piece of code whatever it
+// reads -- a count, a count of zero with the zero-run field behind it, or a zero-run field that continues a run (round 3's form
+// branched per case: four files in four different cases ran all of them, 90 instructions a symbol).  The description is read
+// upwards through a 64-bit register window; the window a round uses was requested by the round before it (a round consumes at
+// most 12 bits), so no round waits for LDS.  Bits past the description's end need no masking and no check per field: every field
+// is at least one bit wide, so a field that touches them leaves `bit` past the limit, which is checked once at the end; a
+// count that overshoots leaves `remaining` negative, which ends the loop and fails the same way.
 DI uint32_t read_ncount_lane(uint32_t src_off, uint32_t n, int max_log, int max_sym, int sym_cap, uint32_t norm_off, uint32_t& nsym_out, uint32_t& log_out) {
     if (n < 1) return 0;
     const int32_t limit = (int32_t)(n > 4096 ? 4096 : n) * 8;
-    uint64_t win = lds_u64(src_off);
-    int32_t wbase = 0; // win = description bits [wbase, wbase + 64)
-    auto bits = [&](int32_t bit) -> uint32_t { // >= 16 bits at `bit`
-        if (bit - wbase > 48) { wbase = bit & ~7; win = lds_u64(src_off + ((uint32_t)wbase >> 3)); }
-        return (uint32_t)(win >> (bit - wbase));
-    };
-    int32_t bit = 4;
-    const int al = 5 + (int)(bits(0) & 15);
+    uint64_t wc = lds_u64(src_off); // description bits [bc, bc + 64)
+    const int al = 5 + (int)((uint32_t)wc & 15);
     if (al > max_log) return 0;
-    int remaining = 1 << al, sym = 0;
-    bool bad = false;
-    while (remaining > 0 && sym <= max_sym && !bad) {
-        const int nb = hibit32((uint32_t)(remaining + 1)) + 1;
-        bad |= bit >= limit;
-        const int val = (int)(bits(bit) & ((1u << nb) - 1));
-        const int lower = (1 << (nb - 1)) - 1;
-        const int thr = (1 << nb) - 1 - (remaining + 1);
-        const bool small = (val & lower) < thr;
-        const int v2 = small ? (val & lower) : (val > lower ? val - thr : val);
-        bit += small ? nb - 1 : nb;
-        const int pr = v2 - 1;
-        remaining -= (pr < 0) ? 1 : pr;
-        bad |= (remaining < 0) | (sym >= sym_cap);
-        if (bad) break;
-        L16s(norm_off + 2 * (uint32_t)sym) = (int16_t)pr;
-        sym++;
-        if (pr == 0) { // runs of zero-probability symbols: 2 bits each, 3 = "and more"
-            for (;;) {
-                if (bit >= limit) { bad = true; break; }
-                const int r = (int)(bits(bit) & 3);
-                bit += 2;
-                if (sym + r > max_sym + 1 || sym + r > sym_cap) { bad = true; break; }
-                for (int i = 0; i < r; i++) L16s(norm_off + 2 * (uint32_t)(sym + i)) = 0;
-                sym += r;
-                if (r != 3) break;
-            }
-        }
+    const int32_t lim = max_sym + 1 < sym_cap ? max_sym + 1 : sym_cap;
+    int32_t bit = 4, bc = 0, remaining = 1 << al, sym = 0;
+    uint32_t rep = 0; // the next field continues a zero run
+    for (;;) {
+        if (!(sym <= lim && (rep != 0 || (remaining > 0 && sym < lim)))) break;
+        const int32_t bn = bit & ~7;
+        const uint64_t wn = lds_u64(src_off + ((uint32_t)bn >> 3));
+        const uint32_t x = (uint32_t)(wc >> (bit - bc));
+        const uint32_t rp1 = (uint32_t)remaining + 1;              // (>= 1)
+        const uint32_t nb = 32u - (uint32_t)__builtin_clz(rp1);
+        const uint32_t half = 1u << (nb - 1);
+        const uint32_t vlow = x & (half - 1), vfull = x & (2 * half - 1);
+        const uint32_t thr = 2 * half - 1 - rp1;
+        const bool small = vlow < thr;
+        const uint32_t v2 = small ? vlow : vfull - (vfull >= half ? thr : 0u);
+        const int32_t pr = (int32_t)v2 - 1;
+        const uint32_t adv = nb - (small ? 1u : 0u);
+        const bool zero = rep == 0 && pr == 0;
+        const uint32_t r = (rep ? x : x >> adv) & 3;              // the zero-run field this round consumes, if it does
+        lds_s64(norm_off + 2 * (uint32_t)sym, rep ? 0ull : (uint64_t)(uint16_t)pr);
+        bit += rep ? 2 : (int32_t)adv + (zero ? 2 : 0);
+        remaining -= rep ? 0 : (pr < 0 ? 1 : pr);
+        sym += rep ? (int32_t)r : 1 + (zero ? (int32_t)r : 0);
+        rep = ((((rep != 0) | zero) & (r == 3)) ? 1u : 0u);
+        wc = wn; bc = bn;
     }
-    if (bad || remaining != 0 || sym > max_sym + 1 || bit > limit) return 0;
+    if (remaining != 0 || sym > lim || bit > limit) return 0;
     nsym_out = (uint32_t)sym;
     log_out = (uint32_t)al;
     return (uint32_t)((bit + 7) >> 3);
-}
-
-// FSE decode table (A.3) by ONE lane: `tab_off` LDS offset of the 8-byte entries, norm[] in LDS (turned into the per-symbol
-// state counters on the way).  kind 0 LL, 1 OF, 2 ML, 3 Huffman weights (no extra bits).  Several tables are built side by side
-// in different lanes, so both passes are loops over TABLE POSITIONS -- the same trip count for every lane with the same table
-// log -- and never over a symbol's count (a loop whose trip count differs from lane to lane runs as long as its longest
-// instance, once per symbol: measured six times the cost of one table):
-//   pass 1, the spread: position after position in stride order takes the current symbol (its code | extra bits << 8);
-//   pass 2, the numbering: position after position in ascending order, four at a time -- the symbol is read back and its
-//           state counter is bumped by an LDS atomic that returns the old value (two 16-bit counters share a word: counts
-//           stay below 2^16, so an add to one half never carries into the other), both round trips shared by the four.
-DI bool build_fse_lane(uint32_t tab_off, uint32_t norm_off, uint32_t nsym, uint32_t log, int kind) {
-    const uint32_t size = 1u << log, mask = size - 1;
-    const uint32_t step = (size >> 1) + (size >> 3) + 3;
-    auto extra_of = [&](uint32_t s) -> uint32_t { return kind == 0 ? L32(kShLL + 4 * s) >> 24 : (kind == 1 ? s : (kind == 2 ? L32(kShML + 4 * s) >> 24 : 0u)); };
-    uint32_t high = size;
-    for (uint32_t s = 0; s < nsym; s++) // "less than one": a single state at the top, numbered 1 -> nbBits = log, next-state base 0
-        if (L16s(norm_off + 2 * s) == -1) { high--; L64(tab_off + 8 * high) = fse_entry(tab_off, 0, log, s, extra_of(s)); }
-    // pass 1 (the count of the symbol after the current one is always in flight: stepping to the next symbol waits for nothing)
-    {
-        uint32_t pos = 0, s = 0xFFFFFFFFu;
-        int32_t left = 0, ahead = nsym ? (int32_t)L16s(norm_off) : 0; // ahead = count of symbol s + 1
-        bool over = false;
-        for (uint32_t j = 0; j < high; j++) {
-            while (left <= 0 && !over) { // the next symbol that has states (at most nsym steps in all)
-                s++;
-                over = s >= nsym;
-                left = over ? 1 : ahead;
-                ahead = s + 1 < nsym ? (int32_t)L16s(norm_off + 2 * (s + 1)) : 0;
-            }
-            L32(tab_off + 8 * pos) = s;
-            left--;
-            do { pos = (pos + step) & mask; } while (pos >= high);
-        }
-        // every count is used up exactly when the positions are: the counts of the symbols with states sum to `high`
-        if (over || left != 0 || pos != 0) return false;
-        for (s++; s < nsym; s++) if (L16s(norm_off + 2 * s) > 0) return false;
-    }
-    // pass 2
-    auto number = [&](uint32_t i, uint32_t s, uint32_t old, uint32_t extra) {
-        const uint32_t d = (old >> (16 * (s & 1))) & 0xFFFF;
-        const uint32_t nb = log - (uint32_t)hibit32(d | 1u);
-        L64(tab_off + 8 * i) = fse_entry(tab_off, (d << nb) - size, nb, s, extra);
-    };
-    auto bump = [&](uint32_t s) -> uint32_t {
-        return __hip_atomic_fetch_add(static_cast<uint32_t*>(__builtin_assume_aligned(lds + norm_off + 2 * (s & ~1u), 4)), 1u << (16 * (s & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    uint32_t i = 0;
-    for (; i + 4 <= high; i += 4) {
-        const uint32_t v0 = L32(tab_off + 8 * i), v1 = L32(tab_off + 8 * i + 8), v2 = L32(tab_off + 8 * i + 16), v3 = L32(tab_off + 8 * i + 24);
-        const uint32_t o0 = bump(v0), o1 = bump(v1), o2 = bump(v2), o3 = bump(v3);
-        const uint32_t x0 = extra_of(v0), x1 = extra_of(v1), x2 = extra_of(v2), x3 = extra_of(v3);
-        number(i, v0, o0, x0); number(i + 1, v1, o1, x1); number(i + 2, v2, o2, x2); number(i + 3, v3, o3, x3);
-    }
-    for (; i < high; i++) { const uint32_t v = L32(tab_off + 8 * i); number(i, v, bump(v), extra_of(v)); }
-    return true;
 }
 
 // ------------------------------------------------------------------------------------ XXH64 pieces (A.6), over LDS bytes
@@ -439,7 +384,11 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
     di.handle = 0; di.formatted = 0; di.dict_id = 0; di.content_len = 0; di.huf_log = 0; di.content = nullptr;
     for (int t = 0; t < 3; t++) { di.al[t] = 0; di.rep[t] = 0; }
 
-    const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds == 0; // (walk_asm spells LDS addresses out)
+    const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds == 0; // (offsets are used as LDS addresses)
+    if (!lds_at_zero) { // cannot be (this kernel has no other LDS object); if it ever is, the general driver behind this launch decodes everything
+        for (uint32_t i = blockIdx.x * 64 + threadIdx.x; i < a.n; i += gridDim.x * 64) a.redo_list[atomicAdd(&a.counter[4], 1u)] = a.list[i];
+        return;
+    }
     const uint32_t ngroups = (a.n + G - 1) / G;
     bool first_group = true;
     (void)first_group;
@@ -503,7 +452,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     if (di.formatted) { // (entries as the block pipeline keeps them: next-state offsets relative to the table -> LDS addresses)
                         for (uint32_t i = lane; i < 512; i += 64) { L64(dict_off + kDLL + 8 * i) = dd->ll[i] + (uint64_t)(int64_t)((int32_t)(dict_off + kDLL) - (int32_t)kBlkLdsLL); L64(dict_off + kDML + 8 * i) = dd->ml[i] + (uint64_t)(int64_t)((int32_t)(dict_off + kDML) - (int32_t)kBlkLdsML); } // (rebased: mzd_device.h)
                         for (uint32_t i = lane; i < 256; i += 64) L64(dict_off + kDOF + 8 * i) = dd->of[i] + (uint64_t)(int64_t)((int32_t)(dict_off + kDOF) - (int32_t)kBlkLdsOF);
-                        for (uint32_t i = lane; i < 1024; i += 64) L32(dict_off + kDHuf + 4 * i) = reinterpret_cast<const uint32_t*>(dd->huf)[i];
+                        for (uint32_t i = lane; i < 1024; i += 64) L32(dict_off + kDHuf + 4 * i) = __builtin_amdgcn_perm(0u, reinterpret_cast<const uint32_t*>(dd->huf)[i], 0x02030001u); // (this kernel's entries: length | symbol << 8, the bytes of the block pipeline's swapped)
                     }
                 }
             }
@@ -648,6 +597,14 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
             wsync();
             SSTAMP(13);
             const bool w_tab = build_fse_file<3, (int)LPF>(w_hdr != 0, wtab, wnorm, w_nsym, w_log, ringo + kAuxCounts, sub);
+            // the weights' bitstream (<= 127 bytes, read backwards) is staged behind 16 zero bytes: fields that reach below the stream's
+            // start read zeros there (A.4) without a mask in the loop
+            const uint32_t wstage = tabo + kWStage;
+            if (w_hdr != 0) {
+                if (sub < 2) L64(wstage + 8 * sub) = 0;
+                for (uint32_t o = 8 * sub; o < 128; o += 8 * LPF) lds_s64(wstage + 16 + o, lds_u64(tp + 1 + w_hdr + o));
+            }
+            wsync();
             SSTAMP(14);
             if (leader) {
                 uint32_t nw = 0;
@@ -660,46 +617,42 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         }
                     } else {
                         if (w_hdr == 0 || !w_tab) break;
-                        const uint32_t hdr = w_hdr, log = w_log;
-                        // two interleaved states over a backward bitstream of <= 127 bytes; the stream's over-read ends it (A.4).  Both
-                        // states' entries are fetched together (one round trip per two weights); the unread bits sit top-aligned in a
-                        // 64-bit register, re-read from LDS once per pair (two fields of <= 6 bits).
-                        const uint32_t sb = tp + 1 + hdr, sl = hb - hdr;
-                        const uint32_t lastb = L8(sb + sl - 1);
+                        // Two interleaved states over the backward bitstream; the stream's over-read ends it (A.4).  A round decodes one weight
+                        // from each state: both entries are fetched together, both fields come out of one shift of the window, both weights
+                        // go out in one store.  Bit positions are LDS bit addresses (G: the read head, bits below it are unread); the window a
+                        // round uses was requested by the round before it (a round consumes <= 12 bits of the 56 a window holds below its head).
+                        const uint32_t log = w_log, sl = hb - w_hdr;
+                        const uint32_t lastb = L8(wstage + 16 + sl - 1);
                         if (lastb == 0) break;
-                        int32_t h = (int32_t)((sl - 1) * 8) + hibit32(lastb); // unread bits
-                        auto window = [&](int32_t hh) -> uint64_t { // the bits below the read head, top-aligned; zero below the stream's start
-                            if (hh <= 0) return 0ull;
-                            const int32_t bb = (hh - 1) >> 3;
-                            const uint64_t W = bb >= 7 ? lds_u64(sb + (uint32_t)(bb - 7)) : lds_u64(sb) << (8 * (7 - bb)); // (bytes before the stream are not its own)
-                            uint64_t c = W << (8 * (bb + 1) - hh);
-                            if (hh < 64) c &= ~0ull << (64 - hh);
-                            return c;
-                        };
-                        uint64_t cur = window(h);
-                        uint32_t s1 = wtab + 8 * (uint32_t)(cur >> (64 - log)); cur <<= log;
-                        uint32_t s2 = wtab + 8 * (uint32_t)(cur >> (64 - log));
-                        h -= 2 * (int32_t)log;
-                        bool fin = false;
-                        for (;;) {
-                            if (nw > 252) break;
-                            cur = window(h);
-                            const uint64_t e1 = L64(s1), e2 = L64(s2);
-                            const uint32_t h1 = (uint32_t)(e1 >> 32), h2 = (uint32_t)(e2 >> 32);
-                            const uint32_t n1 = h1 & 31, n2 = h2 & 31;
-                            const uint32_t b1 = n1 ? (uint32_t)(cur >> (64 - n1)) : 0u;
-                            L8(wts + nw) = (uint8_t)(h1 >> 16);
-                            s1 = (uint32_t)e1 + 8 * b1;
-                            h -= (int32_t)n1;
-                            if (h < 0) { L8(wts + nw + 1) = (uint8_t)(h2 >> 16); nw += 2; fin = true; break; }
-                            cur <<= n1;
-                            const uint32_t b2 = n2 ? (uint32_t)(cur >> (64 - n2)) : 0u;
-                            L8(wts + nw + 1) = (uint8_t)(h2 >> 16);
-                            s2 = (uint32_t)e2 + 8 * b2;
-                            h -= (int32_t)n2;
-                            nw += 2;
-                            if (h < 0) { L8(wts + nw) = (uint8_t)(L32(s1 + 4) >> 16); nw++; fin = true; break; }
+                        const uint32_t Gw0 = 8 * (wstage + 16);
+                        uint32_t Gw = Gw0 + (sl - 1) * 8 + (uint32_t)hibit32(lastb);
+                        uint32_t bc = 8 * ((Gw >> 3) - 7);
+                        uint64_t wc = lds_u64(bc >> 3);
+                        uint32_t s1, s2;
+                        {
+                            const uint32_t y = (uint32_t)(wc >> (Gw - 2 * log - bc)); // (a stream shorter than the two states: zeros from the pad, and the first round ends it)
+                            s2 = wtab + 8 * bfe(y, 0, log); s1 = wtab + 8 * bfe(y, log, log);
+                            Gw -= 2 * log;
                         }
+                        // (ONE exit from the loop, sorted out behind it: with an exit per case the exec-mask bookkeeping was longer than the round)
+                        bool over1, over2;
+                        do {
+                            const uint64_t e1 = L64(s1), e2 = L64(s2);
+                            const uint32_t bn = 8 * ((Gw >> 3) - 7);
+                            const uint64_t wn = lds_u64(bn >> 3);
+                            const uint32_t h1 = (uint32_t)(e1 >> 32), h2 = (uint32_t)(e2 >> 32);
+                            const uint32_t n1 = h1 & 0xFF, n2 = h2 & 0xFF;
+                            const uint32_t low = Gw - n1 - n2;
+                            const uint32_t y = (uint32_t)(wc >> (low - bc));
+                            L16(wts + nw) = (uint16_t)(((h1 >> 16) & 0xFF) | ((h2 >> 8) & 0xFF00));
+                            s1 = (uint32_t)e1 + 8 * bfe(y, n2, n1);
+                            s2 = (uint32_t)e2 + 8 * bfe(y, 0, n2);
+                            over1 = (int32_t)(Gw - n1 - Gw0) < 0; over2 = (int32_t)(low - Gw0) < 0;
+                            Gw = low; nw += 2;
+                            wc = wn; bc = bn;
+                        } while (!(over1 | over2) && nw <= 252);
+                        const bool fin = over1 | over2;
+                        if (!over1 && over2) { L8(wts + nw) = (uint8_t)(L32(s1 + 4) >> 16); nw++; }
                         if (!fin) break;
                     }
                     if (nw < 1 || nw > 255) break;
@@ -781,14 +734,14 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         const uint32_t v = sub + 1 + j * LPF;
                         if (v > maxbits) continue;
                         uint32_t pos = start[j];
-                        const uint32_t len8 = (maxbits + 1 - v) << 8, span = 1u << (v - 1);
+                        const uint32_t len0 = maxbits + 1 - v, span = 1u << (v - 1); // (an entry: code length | symbol << 8 -- the length is the window's shift count as it is loaded)
                         for (uint32_t wi = 0; wi < words; wi++) {
                             const uint64_t W8 = L64(wts + 8 * wi);
                             uint64_t z = (uint64_t)eqflags((uint32_t)W8, v) | ((uint64_t)eqflags((uint32_t)(W8 >> 32), v) << 32);
                             while (z) {
                                 const uint32_t sym = 8 * wi + ((uint32_t)__builtin_ctzll(z) >> 3);
                                 z &= z - 1;
-                                const uint32_t e = sym | len8, e2 = e | (e << 16);
+                                const uint32_t e = (sym << 8) | len0, e2 = e | (e << 16);
                                 const uint32_t at = tabo + 2 * pos;
                                 if (v == 1) L16(at) = (uint16_t)e;
                                 else if (v == 2) L32(at) = e2;
@@ -837,26 +790,36 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         const uint64_t keep = hh >= 64 ? ~0ull : (hh <= 0 ? 0ull : ~0ull << (64 - hh));
                         return w & keep;
                     };
-                    uint64_t cur = window(h);
                     uint32_t k = 0;
-                    const uint32_t shL = 64 - Lg;
-                    for (; k + 4 <= nsym; k += 4) { // four symbols (<= 44 bits) per window, one 4-byte store
-                        const uint32_t e0 = L16(tab + 2 * (uint32_t)(cur >> shL));
-                        cur <<= (e0 >> 8);
-                        const uint32_t e1 = L16(tab + 2 * (uint32_t)(cur >> shL));
-                        cur <<= (e1 >> 8);
-                        const uint32_t e2 = L16(tab + 2 * (uint32_t)(cur >> shL));
-                        cur <<= (e2 >> 8);
-                        const uint32_t e3 = L16(tab + 2 * (uint32_t)(cur >> shL));
-                        h -= (int32_t)((e0 >> 8) + (e1 >> 8) + (e2 >> 8) + (e3 >> 8));
-                        gs32(out + k, (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24));
+                    const uint32_t shH = 32 - Lg; // (Lg <= 11: a code's table index comes out of the window's high word)
+                    auto look = [&](uint64_t c) -> uint32_t { return L16(tab + 2 * ((uint32_t)(c >> 32) >> shH)); };
+                    // Four symbols (<= 44 bits) per window, one 4-byte store.  While at least 64 unread bits are left the window is a plain
+                    // unaligned read shifted into place; the entries' low bytes (the lengths) add up without carrying into the symbols.
+                    for (; k + 4 <= nsym && h >= 64; k += 4) {
+                        const uint32_t b = (uint32_t)(h - 1) >> 3;
+                        uint64_t cur = lds_u64(lbase + b - 7) << ((8 * (b + 1) - (uint32_t)h) & 63);
+                        const uint32_t e0 = look(cur); cur <<= (e0 & 63);
+                        const uint32_t e1 = look(cur); cur <<= (e1 & 63);
+                        const uint32_t e2 = look(cur); cur <<= (e2 & 63);
+                        const uint32_t e3 = look(cur);
+                        h -= (int32_t)((e0 + e1 + e2 + e3) & 0xFF);
+                        gs32(out + k, __builtin_amdgcn_perm(e1, e0, 0x0c0c0501u) | (__builtin_amdgcn_perm(e3, e2, 0x0c0c0501u) << 16));
+                    }
+                    uint64_t cur = window(h);
+                    for (; k + 4 <= nsym; k += 4) { // the stream's last bytes: the window is masked below the stream's start
+                        const uint32_t e0 = look(cur); cur <<= (e0 & 63);
+                        const uint32_t e1 = look(cur); cur <<= (e1 & 63);
+                        const uint32_t e2 = look(cur); cur <<= (e2 & 63);
+                        const uint32_t e3 = look(cur);
+                        h -= (int32_t)((e0 + e1 + e2 + e3) & 0xFF);
+                        gs32(out + k, (e0 >> 8) | (e1 & 0xFF00) | ((e2 & 0xFF00) << 8) | ((e3 & 0xFF00) << 16));
                         cur = window(h);
                     }
                     for (; k < nsym; k++) {
-                        const uint32_t e0 = L16(tab + 2 * (uint32_t)(cur >> shL));
-                        gs8(out + k, e0 & 0xFF);
-                        cur <<= (e0 >> 8);
-                        h -= (int32_t)(e0 >> 8);
+                        const uint32_t e0 = look(cur);
+                        gs8(out + k, e0 >> 8);
+                        cur <<= (e0 & 63);
+                        h -= (int32_t)(e0 & 0xFF);
                     }
                     good = h == 0; // consumed exactly
                 }
@@ -1010,7 +973,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     }
                 }
                 if (act && leader) {
-                    auto record = [&](uint32_t k) { *reinterpret_cast<uint4*>(lds + ringo + 16 * k) = make_uint4(aL, aM, aO, Gh - 32); };
+                    auto record = [&](uint32_t k) { lds_sv16(ringo + 16 * k, V16{(uint64_t)aL | ((uint64_t)aM << 32), (uint64_t)aO | ((uint64_t)(Gh - 32) << 32)}); };
                     auto step = [&]() {
                         const uint32_t e = (Gh + 7) >> 3;
                         const uint64_t X = lds_u64(e - 8); // the 57..64 bits below the read head
@@ -1042,7 +1005,8 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                 // ---- lane = sequence c0 + sub
                 uint32_t pbad = wbad;
                 if (act && c0 + sub < nrun) {
-                    const uint4 r = *reinterpret_cast<const uint4*>(lds + ringo + 16 * sub);
+                    const V16 r16 = lds_v16(ringo + 16 * sub);
+                    const struct { uint32_t x, y, z, w; } r = {(uint32_t)r16.a, (uint32_t)(r16.a >> 32), (uint32_t)r16.b, (uint32_t)(r16.b >> 32)};
                     const uint32_t hL = L32(r.x + 4), hM = L32(r.y + 4), hO = L32(r.z + 4);
                     const uint32_t xL = hL >> 24, xM = hM >> 24, xO = hO >> 24;
                     const uint32_t cL = (hL >> 16) & 0xFF, cM = (hM >> 16) & 0xFF, cO = (hO >> 16) & 0xFF;
@@ -1197,7 +1161,8 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         D0 = gv16(dp); D1 = gv16(dp + 16);
                     }
                     const uint32_t sa = lit_base + lp;
-                    const uint64_t A = lds_u64(sa), B = lds_u64(sa + 8), C = lds_u64(sa + 16), D = lds_u64(sa + 24);
+                    const V16 AB_ = lds_u128(sa), CD_ = lds_u128(sa + 16);
+                    const uint64_t A = AB_.a, B = AB_.b, C = CD_.a, D = CD_.b;
                     asm volatile("" ::: "memory");
                     // (this loop runs per file: the lanes of files that are through are not here)
                     uint32_t big = (uint32_t)(__ballot(ll >= 32) >> (f * LPF)) & ((1u << LPF) - 1);
@@ -1243,7 +1208,8 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         const bool ready = pending & simple & (send <= F);
                         {
                             const uint32_t ra = ready ? outo + mp - off : dump;
-                            const uint64_t A = lds_u64(ra), B = lds_u64(ra + 8), C = lds_u64(ra + 16), D = lds_u64(ra + 24);
+                            const V16 AB_ = lds_u128(ra), CD_ = lds_u128(ra + 16);
+                            const uint64_t A = AB_.a, B = AB_.b, C = CD_.a, D = CD_.b;
                             asm volatile("" ::: "memory");
                             store_exact31(outo + mp, ready ? m : 0u, (uint32_t)A, (uint32_t)(A >> 32), (uint32_t)B, (uint32_t)(B >> 32), (uint32_t)C, (uint32_t)(C >> 32), (uint32_t)D, (uint32_t)(D >> 32), dump);
                             asm volatile("" ::: "memory");
