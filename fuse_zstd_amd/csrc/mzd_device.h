@@ -164,8 +164,10 @@ struct LdsArgs {
     uint32_t seq_cap;           // >= the largest dst_cap of the launch / 3 + 2 (every match is >= 3 bytes)
     uint64_t* stamps;           // diagnostic build (-DMZD_SMALL_STAMPS), else unused
 };
-void launch_lds(const LdsArgs& a, uint32_t grid, int g, int with_dict, void* stream);
-uint32_t lds_kernel_bytes(int g, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes);
+int launch_lds(const LdsArgs& a, uint32_t grid, int g, int xg, int with_dict, void* stream); // g files per wavefront, executed xg at a time
+int lds_prepare_device();   // once per device, with that device current
+uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes);
+uint32_t lds_kernel_bytes_per_file(uint32_t tab_bytes, uint32_t comp_bytes);
 size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap);
 uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes);
 

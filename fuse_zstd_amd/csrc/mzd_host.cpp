@@ -47,6 +47,9 @@ constexpr uint32_t kMaxDicts = 64;
 constexpr size_t kMaxChunks = 16;               // ... and at most this many chunks per call
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
+std::atomic<int> g_small_g{0}, g_small_xg{0}, g_trace_t2{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
+std::atomic<unsigned> g_small_grid{0};               // mzd_debug_host_path 6: its grid (0: as many wavefronts as the device holds)
+constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 1280u; // (a workgroup's LDS is allocated in steps of 320 dwords: tools/micro/lds_granule_micro.hip -- five workgroups of 32 000 bytes share a CU, five of 32 640 do not, and the occupancy API says they do)
 std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic with the
                                     // small-file kernel for every eligible file however few,
                                     // 4 / 5 block tasks with / without blocks resolved ahead (mzd_k_resolve.h) whatever the launch's size
@@ -153,6 +156,7 @@ int init_device(Device& d, int hip_id, int index, const InitCfg& cfg) {
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_id));
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_kernel_ptr(0), kWG, 0));
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, (const void*)decode_kernel_ptr(1), kWG, 0));
+    { int lrc = lds_prepare_device(); if (lrc) return lrc; } // (the small-file kernels' dynamic-LDS limit: per device)
     per_cu = std::min(per_cu, per_cu2); // the block-task driver needs its whole grid resident
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
@@ -257,7 +261,7 @@ struct Plan {
     uint32_t njobs = 0, nsmall = 0, nbig = 0;
     bool with_dict = false, multi = false;
     uint32_t lit_stride = 0;   // literal scratch per small file: largest capacity + 64
-    int lds_g = 4;             // files per wavefront of the small-file kernel (mzd_lds.hip)
+    int lds_g = 4, lds_xg = 4; // files per wavefront of the small-file kernel (mzd_lds.hip), and how many of them it executes at a time
     uint32_t lds_tab = 0, lds_comp = 0, lds_out = 0; // its slot geometry (LdsArgs)
     uint32_t big_tasks = 0;    // workgroups worth launching for the files that are not small
     uint64_t blocks = 0;       // block tasks of those files, estimated from their capacities
@@ -265,7 +269,7 @@ struct Plan {
     bool lpt = false;          // the general driver takes its files through the big list, largest first (make_plan)
 };
 // lists: [0, njobs) small list (job indices sorted by dictionary), [njobs, 2 njobs) job list of the general driver
-Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_wg) {
+Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_wg, uint32_t cus) {
     Plan p;
     p.njobs = (uint32_t)njobs;
     const int force = g_force_driver.load(std::memory_order_relaxed);
@@ -329,10 +333,35 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
         {   // files per wavefront: residency is set by LDS (and by registers: two wavefronts per SIMD), whatever G is; fewer files
             // per wavefront spread a launch's tail better and cost nothing but lane efficiency in the serial phases, which the
             // SIMDs have to spare (measured, cfg4: G = 4 0.52 ms, G = 8 0.64 ms)
-            static const int env_g = getenv("MZD_LDS_G") ? atoi(getenv("MZD_LDS_G")) : 0;
             p.lds_g = (p.with_dict && all_dict) ? 8 : 4; // (one dictionary image per wavefront: worth more files per image; cfg5: G = 4 1.03 ms, 8 0.94, 16 1.25)
-            if (env_g == 4 || env_g == 8 || env_g == 16) p.lds_g = env_g;
-            while (p.lds_g > 4 && lds_kernel_bytes(p.lds_g, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out) > 160u * 1024u) p.lds_g /= 2;
+            p.lds_xg = p.lds_g;
+            // A launch of a little more than one round of groups (10 000 files of 4 KiB: 8 192 are resident at G = 4 -- a CU's LDS holds
+            // 39 windows of 4.1 KB and 40 would be needed) takes ONE round when the entropy phases run on eight files per wavefront
+            // and only four are executed at a time: eight entropy images fit where four windows do (mzd_lds.hip, XG).  The table area
+            // is cut to what lets W wavefronts of eight files share a CU (files whose tables need more are handed on); not below
+            // 1 792 bytes (a 9-bit Huffman table, 224 FSE entries).
+            auto waves_per_cu = [&](int g, int xg, uint32_t tab) -> uint32_t {
+                const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(g, xg, p.with_dict, tab, p.lds_comp, p.lds_out), kLdsGranule);
+                return lds > kLdsPerCu ? 0u : std::min<uint32_t>(8u, kLdsPerCu / lds); // (8: two wavefronts per SIMD, registers)
+            };
+            auto split_plan = [&](uint32_t& tab) -> bool { // G = 8, XG = 4 in one round?
+                if (p.with_dict || cus == 0) return false;
+                const uint32_t w = (uint32_t)((p.nsmall + 8ull * cus - 1) / (8ull * cus));
+                if (w < 1 || w > 8) return false;
+                const uint32_t budget = kLdsPerCu / w / kLdsGranule * kLdsGranule;
+                const uint32_t fixed = lds_kernel_bytes(8, 4, 0, 0, 0, 0) - 8 * lds_kernel_bytes_per_file(0, 0); // the wavefront's tables and the files' records
+                if (budget < fixed + 4 * p.lds_out) return false;
+                const uint32_t per_file = (budget - fixed) / 8;                       // tables + (counts, work, input)
+                const uint32_t rest = lds_kernel_bytes_per_file(0, p.lds_comp);      // (counts, work, input)
+                if (per_file < rest + 1792u) return false;
+                tab = std::min<uint32_t>(p.lds_tab, (per_file - rest) & ~15u);
+                return waves_per_cu(8, 4, tab) >= w;
+            };
+            uint32_t split_tab = 0;
+            if (p.nsmall > (uint64_t)cus * waves_per_cu(4, 4, p.lds_tab) * 4 && split_plan(split_tab)) { p.lds_g = 8; p.lds_xg = 4; p.lds_tab = split_tab; }
+            const int dbg_g = g_small_g.load(std::memory_order_relaxed), dbg_xg = g_small_xg.load(std::memory_order_relaxed); // (mzd_debug_host_path 4 / 5)
+            if (dbg_g == 4 || dbg_g == 8 || dbg_g == 16) { p.lds_g = dbg_g; p.lds_xg = (dbg_xg == 4 && dbg_g == 8 && !p.with_dict) ? 4 : dbg_g; }
+            while (p.lds_g > 4 && lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out) > kLdsPerCu) { p.lds_g /= 2; p.lds_xg = p.lds_g; }
         }
     }
     // Multi-block files in a launch that fills the machine many times over: block tasks keep a workgroup slot waiting while a file's
@@ -399,18 +428,18 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         la.tab_bytes = p.lds_tab; la.comp_bytes = p.lds_comp; la.out_bytes = p.lds_out;
         la.stamps = reinterpret_cast<uint64_t*>(d.debug); // (diagnostic builds: the first debug slot's first bytes; unused otherwise)
         const uint32_t ngroups = (p.nsmall + (uint32_t)p.lds_g - 1) / (uint32_t)p.lds_g;
-        const uint32_t lds = lds_kernel_bytes(p.lds_g, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out);
+        const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out), kLdsGranule);
         // one wavefront per workgroup; as many as the whole device holds, also for a launch on one of the host path's lanes: this
         // kernel uses none of the per-workgroup scratch the lanes divide, and a chunk of small files that gets a quarter of the wave
         // slots takes four rounds of groups where one would do (cfg4 host -> host: 1.5 -> ms)
-        const uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(12u, (160u * 1024u) / lds));
+        const uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(8u, kLdsPerCu / lds)); // (8: two wavefronts per SIMD, registers)
         la.lit_stride = p.lit_stride; la.seq_cap = (p.lit_stride - 64) / 3 + 2;
         la.scratch = l.small_lit;
         if (&l == &d.whole) { d.last_lds_lit_stride = la.lit_stride; d.last_lds_seq_cap = la.seq_cap; }
         const size_t per_wave = (size_t)p.lds_g * lds_scratch_per_file(la.lit_stride, la.seq_cap);
         const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / per_wave);
-        static const uint32_t env_grid = getenv("MZD_LDS_GRID") ? (uint32_t)atoi(getenv("MZD_LDS_GRID")) : 0u; // (experiments: fewer resident wavefronts)
-        launch_lds(la, std::min(ngroups, std::min(env_grid ? env_grid : resident, by_scratch)), p.lds_g, p.with_dict ? 1 : 0, s);
+        const uint32_t dbg_grid = g_small_grid.load(std::memory_order_relaxed); // (mzd_debug_host_path 6: experiments with fewer resident wavefronts)
+        { int lrc = launch_lds(la, std::min(ngroups, std::min(dbg_grid ? dbg_grid : resident, by_scratch)), p.lds_g, p.lds_xg, p.with_dict ? 1 : 0, s); if (lrc) return lrc; }
         HIPCHK(hipGetLastError());
         ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig;
         grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
@@ -459,7 +488,7 @@ int run_device_jobs(Device& d, mzd_job* jobs, size_t njobs, hipStream_t s) {
     int rc = ensure_staging_jobs(*st, njobs);
     if (rc) return rc;
     for (size_t i = 0; i < njobs; i++) fill_devjob(st->h_jobs[i], jobs[i].src, jobs[i].src_len, jobs[i].dst, jobs[i].dst_cap, jobs[i].dict_id, d);
-    const Plan p = make_plan(st->h_jobs, njobs, st->h_lists, d.max_wg);
+    const Plan p = make_plan(st->h_jobs, njobs, st->h_lists, d.max_wg, d.cus);
     if (!s) s = d.whole.stream;
     HIPCHK(hipMemcpyAsync(st->d_jobs, st->h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice, s));
     if (p.nsmall || p.lpt) HIPCHK(hipMemcpyAsync(st->d_lists, st->h_lists, njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -608,7 +637,7 @@ Layout make_layout(const mzd_job* jobs, const std::vector<size_t>& idx, bool inp
 // HOST-pointer jobs `idx` on one device, as a pipeline of chunks: while chunk k decodes, chunk k+1 crosses the link one way
 // and chunk k-1 the other (kSlots launches in flight, each on its own stream and its own share of the scratch).
 int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
-    static const bool trace = getenv("MZD_T2_TRACE") != nullptr; // diagnostic: where a call's wall time goes, to stderr
+    const bool trace = g_trace_t2.load(std::memory_order_relaxed) != 0; // diagnostic (mzd_debug_host_path 7): where a call's wall time goes, to stderr
     const auto t_start = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) { if (trace) fprintf(stderr, "[mzd t2] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count()); };
     HIPCHK(hipSetDevice(d.hip_id));
@@ -719,7 +748,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
     std::vector<Plan> plans(nchunks);
     bool any_small = false;
     for (size_t c = 0; c < nchunks; c++) {
-        plans[c] = make_plan(st->h_jobs + cut[c], cut[c + 1] - cut[c], st->h_lists + 2 * cut[c], d.lane[0].nwg);
+        plans[c] = make_plan(st->h_jobs + cut[c], cut[c + 1] - cut[c], st->h_lists + 2 * cut[c], d.lane[0].nwg, d.cus);
         any_small = any_small || plans[c].nsmall != 0 || plans[c].lpt;
     }
     mark("plans");
@@ -727,7 +756,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
     // quarter of it (the call then waits until no other launch is in flight, like a call on device pointers).
     constexpr int kWholeLane = -2;
     const bool use_whole = nchunks == 1 && plans[0].blocks > d.lane[0].nwg;
-    if (use_whole) { plans[0] = make_plan(st->h_jobs, n, st->h_lists, d.max_wg); any_small = plans[0].nsmall != 0 || plans[0].lpt; }
+    if (use_whole) { plans[0] = make_plan(st->h_jobs, n, st->h_lists, d.max_wg, d.cus); any_small = plans[0].nsmall != 0 || plans[0].lpt; }
     {
         hipError_t e = hipMemcpyAsync(st->d_jobs, st->h_jobs, n * sizeof(DevJob), hipMemcpyHostToDevice, d.copy_in);
         if (e == hipSuccess && any_small) e = hipMemcpyAsync(st->d_lists, st->h_lists, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, d.copy_in);
@@ -913,6 +942,10 @@ int mzd_debug_host_path(int device, int what, int value) {
     (void)device;
     if (what == 2) { g_direct_chunks.store(value < 1 ? 1 : value); return MZD_OK; }
     if (what == 3) { g_copy_threads.store(value < 1 ? 1u : (unsigned)value); return MZD_OK; }
+    if (what == 4) { g_small_g.store(value); return MZD_OK; }
+    if (what == 5) { g_small_xg.store(value); return MZD_OK; }
+    if (what == 6) { g_small_grid.store(value < 0 ? 0u : (unsigned)value); return MZD_OK; }
+    if (what == 7) { g_trace_t2.store(value); return MZD_OK; }
     return MZD_E_PARAM;
 }
 void* mzd_host_alloc(size_t n) {
@@ -1021,7 +1054,7 @@ int mzd_batch_prepare(int device, const mzd_job* jobs, size_t njobs, mzd_batch**
         hipFree(b->d_jobs); hipFree(b->d_lists); delete b; return MZD_E_DEVICE;
     }
     for (size_t i = 0; i < njobs; i++) fill_devjob(b->h_jobs[i], jobs[i].src, jobs[i].src_len, jobs[i].dst, jobs[i].dst_cap, jobs[i].dict_id, *d);
-    b->plan = make_plan(b->h_jobs, njobs, lists.data(), d->max_wg);
+    b->plan = make_plan(b->h_jobs, njobs, lists.data(), d->max_wg, d->cus);
     if (hipMemcpy(b->d_jobs, b->h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(b->d_lists, lists.data(), njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
         hipFree(b->d_jobs); hipFree(b->d_lists); hipHostFree(b->h_jobs); delete b; return MZD_E_DEVICE;

@@ -14,11 +14,10 @@
 //                            symbol's counter (norm[], bumped once per round by the symbol's first lane) + the number of lower lanes
 //                            of the round with the same symbol (a 16-bit lane mask per symbol, OR-ed together in LDS);
 //   step 5:                  the "less than one" entries (their places overlap S).
-// Work memory: R = the table's own first half (dwords), S = its top eighth (bytes), and kFseWork bytes per file: the skip mask
-// (<= 512 bits) and the lane masks (53 symbols x 16 bits).  Entries as everywhere (fse_entry).
+// Work memory: none beyond the table's own place and the file's share of the wavefront's dump area (which only the execution
+// uses): R = the table's first half (dwords), the skip mask (size / 8 bytes) behind it, S = its top eighth (bytes); the lane masks
+// (53 symbols x LPF bits, packed) = 8 * LPF bytes at `lmo`.  Entries as everywhere (fse_entry).
 #pragma once
-
-constexpr uint32_t kFseWork = 64 + 128; // per file: skip mask | lane masks
 
 // step^-1 mod size, step = size/2 + size/8 + 3, for table logs 5..9
 DI uint32_t fse_step_inv(uint32_t log) { return log == 5 ? 7u : (log == 6 ? 3u : (log == 7 ? 91u : (log == 8 ? 11u : 363u))); }
@@ -27,16 +26,17 @@ DI uint32_t fse_step_inv(uint32_t log) { return log == 5 ? 7u : (log == 6 ? 3u :
 // files that do not run along with stores aimed at `dumpq` (8 bytes of their own).  Returns false when the counts are not a
 // distribution over the table (uniform in the file).  5 <= log <= 9, nsym <= 64.
 template <int KIND, int LPF>
-DI bool build_fse_file(bool act, uint32_t tab, uint32_t norm_off, uint32_t nsym, uint32_t log, uint32_t work, uint32_t sub) {
+DI bool build_fse_file(bool act, uint32_t tab, uint32_t norm_off, uint32_t nsym, uint32_t log, uint32_t lmo, uint32_t sub) {
     if (!act) return true;
     const uint32_t size = 1u << log, mask = size - 1;
     const uint32_t inv = fse_step_inv(log);
-    const uint32_t skipo = work, lmo = work + 64;
+    const uint32_t skipo = tab + 4 * size; // (size / 8 bytes of the 3 * size between R and S)
     auto extra_of = [&](uint32_t s) -> uint32_t { return KIND == 0 ? L32(kShLL + 4 * s) >> 24 : (KIND == 1 ? s : (KIND == 2 ? L32(kShML + 4 * s) >> 24 : 0u)); };
     // ---- clear: the marks (dwords [0, size)), the skip mask, the lane masks
     if (act) {
         for (uint32_t o = 16 * sub; o < 4 * size; o += 16 * LPF) lds_sv16(tab + o, V16{0, 0});
-        for (uint32_t o = 8 * sub; o < kFseWork; o += 8 * LPF) L64(work + o) = 0;
+        for (uint32_t o = 8 * sub; o < (size > 64 ? size >> 3 : 8u); o += 8 * LPF) L64(skipo + o) = 0;
+        L64(lmo + 8 * sub) = 0;
     }
     wsync();
     // ---- step 1
@@ -114,11 +114,11 @@ DI bool build_fse_file(bool act, uint32_t tab, uint32_t norm_off, uint32_t nsym,
         const uint32_t p = p0 + sub;
         const bool on = p < high;
         const uint32_t s = on ? L8(tab + 7 * size + p) : 0u;
-        const uint32_t mo = lmo + 4 * (s >> 1), sh = 16 * (s & 1);
+        const uint32_t mo = lmo + 4 * ((s * LPF) >> 5), sh = (s * LPF) & 31;
         if (on) lds_or32(mo, (1u << sub) << sh);
         wsync();
         if (on) {
-            const uint32_t lm = (L32(mo) >> sh) & 0xFFFF;
+            const uint32_t lm = (L32(mo) >> sh) & ((1u << LPF) - 1);
             const uint32_t old = L16(norm_off + 2 * s);
             const uint32_t lower = (uint32_t)__builtin_popcount(lm & ((1u << sub) - 1));
             const uint32_t d = old + lower;
@@ -126,7 +126,8 @@ DI bool build_fse_file(bool act, uint32_t tab, uint32_t norm_off, uint32_t nsym,
             const uint64_t e = fse_entry(tab, ((d << nb) - size) & mask, nb, s, extra_of(s));
             asm volatile("" ::: "memory");
             L64(tab + 8 * p) = e;
-            if (lower == 0) { L16(norm_off + 2 * s) = (uint16_t)(old + (uint32_t)__builtin_popcount(lm)); L16(mo + (sh >> 3)) = 0; }
+            if (lower == 0) L16(norm_off + 2 * s) = (uint16_t)(old + (uint32_t)__builtin_popcount(lm));
+            lds_xor32(mo, (1u << sub) << sh); // (the mask is clean again for the next round)
         }
         wsync();
     }

@@ -75,6 +75,7 @@ DI void lds_sv16(uint32_t off, const V16& v) { __builtin_memcpy((MZD_LDS_AS uint
 DI void lds_s64(uint32_t off, uint64_t v) { __builtin_memcpy(lptr<uint8_t>(off), &v, 8); } // any alignment
 DI void lds_s32(uint32_t off, uint32_t v) { __builtin_memcpy(lptr<uint8_t>(off), &v, 4); }
 DI void lds_s16(uint32_t off, uint32_t v) { const uint16_t w = (uint16_t)v; __builtin_memcpy(lptr<uint8_t>(off), &w, 2); }
+DI void lds_xor32(uint32_t off, uint32_t v) { __hip_atomic_fetch_xor(lptr<uint32_t>(off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DI void lds_or32(uint32_t off, uint32_t v) { __hip_atomic_fetch_or(lptr<uint32_t>(off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // The lanes of a wavefront talk through LDS without a barrier: a wavefront's LDS operations execute in issue order, so a
@@ -92,8 +93,7 @@ constexpr uint32_t kShWalkDummy = 360; // 8 bytes: {its own address, 0}: the ent
 constexpr uint32_t kShDump = 384;  // 8 bytes per lane: where the stores of idle lanes go (select-style code: no branch around a store)
 constexpr uint32_t kShBytes = 896;
 constexpr uint32_t kDLL = 0, kDML = 4096, kDOF = 8192, kDHuf = 10240, kDictImg = 14336; // FSE entries of 8 bytes, Huffman entries of 2
-constexpr uint32_t kAuxCounts = 256; // per file: the normalized counts of the three sequence tables, later the walk records; behind them the table builders' work memory
-constexpr uint32_t kAux = kAuxCounts + 192; // (= kFseWork, mzd_l_tables.h)
+constexpr uint32_t kAux = 256;    // per file: the normalized counts of the three sequence tables, later the walk records
 // scratch of the Huffman weights: their FSE table [64 x 8] | its counts
 constexpr uint32_t kWTab = 0, kWNorm = 512, kWStage = 576; // (the weights' bitstream behind 16 zero bytes: 576 .. 720) // in the table area, which the Huffman table takes over once the weights are decoded; the weights themselves: the ring
 
@@ -163,7 +163,6 @@ DI uint64_t fse_entry(uint32_t tab_off, uint32_t nbase, uint32_t nb, uint32_t sy
 }
 
 #include "mzd_l_tables.h"
-static_assert(kAux == kAuxCounts + kFseWork, "the table builders' work memory lies behind the counts");
 
 // ------------------------------------------------------------------------------------ bit readers over LDS bytes
 struct LBack { // backward (the Huffman weights' stream: <= 128 bytes), zero below the start
@@ -360,18 +359,27 @@ struct DictInfo { // the dictionary whose image sits in LDS (wave-uniform)
 
 // ------------------------------------------------------------------------------------ the kernel
 // One wavefront per workgroup; a persistent loop over groups of G files.
-template <int G, bool DICT>
+// XG: files EXECUTED at a time (XG divides G).  The entropy phases take all G files of a group through in lockstep (64 / G lanes a
+// file: their serial chains cost the same for eight files as for four), then the group's files are executed XG at a time with
+// 64 / XG lanes each.  XG < G is for launches that would otherwise need two rounds of groups: the entropy images of G = 8 files of
+// 4 KiB (3.9 KB each) fit where only four windows (4.1 KB each) do, so five wavefronts per CU hold 40 files -- 10 240 on the
+// device -- instead of 32.  What an execution pass needs to know about a file crosses over in a 32-byte record in LDS.
+template <int G, bool DICT, int XG>
 __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
-    constexpr uint32_t LPF = 64 / G; // lanes per file = sequences per plan step
-    static_assert(LPF >= 4, "four Huffman streams, four XXH64 accumulators");
+    constexpr uint32_t LPF = 64 / G; // lanes per file in the entropy phases
+    constexpr uint32_t XLPF = 64 / XG, NX = G / XG; // lanes per file = sequences per plan step in the execution; passes
+    static_assert(LPF >= 4, "four Huffman streams");
+    static_assert(XLPF >= 4 && XLPF <= 16 && G % XG == 0, "four XXH64 accumulators; a file's lanes inside one DPP row");
     const uint32_t lane = threadIdx.x;
     const uint32_t f = lane / LPF, sub = lane % LPF;
     const bool leader = sub == 0;
-    const uint32_t dict_off = kShBytes;
+    constexpr uint32_t kShRec = kShBytes, kShAll = kShBytes + 32 * G; // the files' records behind the wavefront's tables
+    const uint32_t dict_off = kShAll;
     const uint32_t ent = a.tab_bytes + kAux + a.comp_bytes;                // the entropy phase's image of a file ...
-    const uint32_t stride = ent > a.out_bytes ? ent : a.out_bytes;         // ... and its output window share the slot
-    const uint32_t tabo = kShBytes + (DICT ? kDictImg : 0u) + f * stride;  // the file's slot
-    const uint32_t ringo = tabo + a.tab_bytes, cmp = ringo + kAux, outo = tabo;
+    const uint32_t stride = G != XG ? ent : (ent > a.out_bytes ? ent : a.out_bytes); // ... and (XG == G) its output window share the slot
+    const uint32_t slots0 = kShAll + (DICT ? kDictImg : 0u);
+    const uint32_t tabo = slots0 + f * stride;                             // the file's slot
+    const uint32_t ringo = tabo + a.tab_bytes, cmp = ringo + kAux;
     // the file's share of the scratch in HBM: literals, then the sequences (8 bytes each)
     uint8_t* const lit_g = a.scratch + (size_t)(blockIdx.x * G + f) * ((size_t)a.lit_stride + 8u * (size_t)a.seq_cap);
     uint8_t* const seq_g = lit_g + a.lit_stride;
@@ -419,6 +427,12 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
     for (;;) {
         SSTAMP(0);
         if (g >= ngroups) break;
+        // (what the trips for the next group leave behind outlives the entropy phases' scope)
+        const bool early = g + gridDim.x < ngroups;
+        uint32_t g_next = 0xFFFFFFFFu;
+        JobRegs Jn;
+        V16 pfn[kPF];
+      { // ---- the entropy phases: G files, LPF lanes each
 
         // =============================== the group's files: the compressed bytes -> LDS
         const uint32_t fidx = g * G + f;
@@ -437,8 +451,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
         }
         // (trip 1 for the next group -- only while at least a grid's worth of groups is left behind this one: a wavefront that books its
         //  next group early takes it from one that would have been free sooner, which matters when a launch has about a group per wavefront)
-        const bool early = g + gridDim.x < ngroups;
-        uint32_t g_next = early ? ticket() : 0xFFFFFFFFu;
+        if (early) g_next = ticket();
         // the group's dictionary: the first one named (the host sorts the list by dictionary)
         if (DICT) {
             const uint64_t named = __ballot(have && jdict != 0 && jdict <= a.ndicts);
@@ -465,7 +478,6 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
         (void)why;
         bool ok = have && fits; // still on the fast path
         bool done = false;      // finished without a block to decode (empty file, raw / RLE block)
-        uint32_t out_len = 0, res_off = outo; // the decoded file: out_len bytes at LDS offset res_off
         uint32_t has_fcs = 0, has_ck = 0, fcs = 0, btype = 0, bsize = 0, b0 = 0;
         uint32_t lit_type = 0, nlit = 0, streams = 0, lit_off = 0, tree_off = 0, tree_len = 0;
         uint32_t s_len0 = 0, s_len1 = 0, s_len2 = 0, s_len3 = 0, s_base = 0;
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                 b0 = hs + 3;
                 if (btype < 2) {
                     if (bsize > cap || (has_fcs && fcs != bsize)) break;
-                    out_len = bsize; done = true; ok = true;
+                    done = true; ok = true; // (the content is bsize bytes)
                     break;
                 }
                 if (bsize < 2) break;
@@ -567,13 +579,8 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
         (void)tree_len;
         if (have && !ok) why = 1;
         bool live = ok && !done; // a compressed block to decode
-        const uint32_t stored_ck = (ok && has_ck && n >= 4) ? lds_u32(cmp + n - 4) : 0u; // (read now: the window will lie over the input)
-        // raw / RLE blocks: the content is the block's bytes where they lie / the window filled with the byte
-        if (ok && done && n != 0) {
-            if (btype == 0) res_off = cmp + b0;
-            else { const uint32_t v = L8(cmp + b0); asm volatile("" ::: "memory"); for (uint32_t k = sub; k < bsize; k += LPF) L8(outo + k) = (uint8_t)v; }
-        }
-        const uint8_t* const lit_p = lit_type == 0 ? src + lit_off : lit_g; // the literals: raw where the input has them (HBM), else the scratch
+        const uint32_t stored_ck = (ok && has_ck && n >= 4) ? lds_u32(cmp + n - 4) : 0u; // (read now: the windows will lie over the input)
+        const uint32_t rle_byte = (ok && done && n != 0 && btype == 1) ? L8(cmp + b0) : 0u; // (an RLE block's byte; a raw block's bytes are taken from the input in HBM when the file's pass comes)
         const uint32_t job_next = early ? list_entry(g_next) : 0xFFFFFFFFu; // (trip 2)
         SSTAMP(2);
 
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
             }
             wsync();
             SSTAMP(13);
-            const bool w_tab = build_fse_file<3, (int)LPF>(w_hdr != 0, wtab, wnorm, w_nsym, w_log, ringo + kAuxCounts, sub);
+            const bool w_tab = build_fse_file<3, (int)LPF>(w_hdr != 0, wtab, wnorm, w_nsym, w_log, kShDump + 8 * LPF * f, sub);
             // the weights' bitstream (<= 127 bytes, read backwards) is staged behind 16 zero bytes: fields that reach below the stream's
             // start read zeros there (A.4) without a mask in the loop
             const uint32_t wstage = tabo + kWStage;
@@ -760,7 +767,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
             if (!good) { ok = false; live = false; why = 2; }
         }
         wsync();
-        JobRegs Jn = job_entry(job_next); // (trip 3)
+        Jn = job_entry(job_next); // (trip 3)
         SSTAMP(3);
 
         // =============================== Huffman streams -> the literal scratch (lane = (file, stream))
@@ -831,7 +838,6 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
             if (live && lit_type == 1) { const uint32_t v = L8(cmp + lit_off) * 0x01010101u; for (uint32_t k = 4 * sub; k < nlit; k += 4 * LPF) gs32(lit_g + k, v); } // (slack past nlit)
         }
         wsync();
-        V16 pfn[kPF];
         prefetch(Jn, pfn); // (trip 4: in flight from here to the next group's start)
         SSTAMP(4);
 
@@ -917,7 +923,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                     L64(tab) = fse_entry(tab, 0, 0, s, extra);
                 }
             }
-            const uint32_t work = ringo + kAuxCounts;
+            const uint32_t work = kShDump + 8 * LPF * f; // (the lane masks: the file's share of the dump area, idle until the execution)
             bool tg = build_fse_file<0, (int)LPF>(tables && (mL == 0 || mL == 2), tabL, ringo, nsyms & 0xFF, alL, work, sub);
             tg &= build_fse_file<1, (int)LPF>(tables && (mO == 0 || mO == 2), tabO, ringo + 72, (nsyms >> 8) & 0xFF, alO, work, sub);
             tg &= build_fse_file<2, (int)LPF>(tables && (mM == 0 || mM == 2), tabM, ringo + 136, (nsyms >> 16) & 0xFF, alM, work, sub);
@@ -1043,8 +1049,49 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
 #else
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #endif
+        // =============================== what the execution needs of a file: its record
+        if (leader) {
+            const uint32_t fl = (have ? 1u : 0u) | (ok ? 2u : 0u) | (live ? 4u : 0u) | (done ? 8u : 0u) | (btype << 4) | (lit_type << 6) | (has_fcs << 8) | (has_ck << 9) |
+                                (with_d ? 1u << 10 : 0u) | (n != 0 ? 1u << 11 : 0u) | (why << 16);
+            const uint32_t ro = kShRec + 32 * f;
+            lds_sv16(ro, V16{(uint64_t)fl | ((uint64_t)job << 32), (uint64_t)nlit | ((uint64_t)nrun << 32)});
+            lds_sv16(ro + 16, V16{(uint64_t)fcs | ((uint64_t)stored_ck << 32), (uint64_t)((bsize & 0xFFFF) | (b0 << 16)) | ((uint64_t)((lit_off & 0xFFFF) | (rle_byte << 16)) << 32)});
+        }
         wsync();
         SSTAMP(7);
+      }
+      for (uint32_t pass = 0; pass < NX; pass++) {
+        // =============================== an execution pass: XG of the group's files, XLPF lanes each (the names of the entropy phases, for this pass's files)
+        constexpr uint32_t LPF = XLPF;
+        const uint32_t f = lane / LPF, sub = lane % LPF;
+        const bool leader = sub == 0;
+        const uint32_t gfile = pass * XG + f; // the file's place in its group
+        const uint32_t fidx = g * G + gfile;
+        (void)fidx;
+        const V16 r0_ = lds_v16(kShRec + 32 * gfile), r1_ = lds_v16(kShRec + 32 * gfile + 16);
+        const uint32_t rfl = (uint32_t)r0_.a, job = (uint32_t)(r0_.a >> 32), nlit = (uint32_t)r0_.b;
+        uint32_t nrun = (uint32_t)(r0_.b >> 32);
+        const uint32_t fcs = (uint32_t)r1_.a, stored_ck = (uint32_t)(r1_.a >> 32);
+        const uint32_t bsize = (uint32_t)r1_.b & 0xFFFF, b0 = ((uint32_t)r1_.b >> 16) & 0xFFFF, lit_off = (uint32_t)(r1_.b >> 32) & 0xFFFF, rle_byte = (uint32_t)(r1_.b >> 48);
+        const bool have = (rfl & 1) != 0, done = (rfl & 8) != 0, with_d = DICT && (rfl & (1u << 10)) != 0;
+        bool ok = (rfl & 2) != 0, live = (rfl & 4) != 0;
+        const uint32_t btype = (rfl >> 4) & 3, lit_type = (rfl >> 6) & 3, has_fcs = (rfl >> 8) & 1, has_ck = (rfl >> 9) & 1, n = (rfl >> 11) & 1; // (n: the file is not empty)
+        uint32_t why = rfl >> 16;
+        (void)why;
+        const uint8_t* src = nullptr; uint8_t* dst = nullptr; uint8_t* dst2 = nullptr; uint32_t cap = 0;
+        if (have) { const DevJob& dj = a.jobs[job]; src = dj.src; dst = dj.dst; dst2 = dj.dst2; cap = (uint32_t)dj.dst_cap; } // (L2: the entropy phases read the entry)
+        const uint32_t outo = slots0 + f * (G != XG ? a.out_bytes : stride); // the file's output window
+        uint8_t* const lit_g = a.scratch + (size_t)(blockIdx.x * G + gfile) * ((size_t)a.lit_stride + 8u * (size_t)a.seq_cap);
+        uint8_t* const seq_g = lit_g + a.lit_stride;
+        const uint8_t* const lit_p = lit_type == 0 ? src + lit_off : lit_g; // the literals: raw where the input has them (HBM), else the scratch
+        uint32_t out_len = (ok && done && n != 0) ? bsize : 0u; // the decoded file: out_len bytes at LDS offset res_off
+        const uint32_t res_off = outo;
+        // raw / RLE blocks: the window takes the block's bytes from the input (HBM: its image in LDS may lie under another file's window) / is filled with the byte
+        if (ok && done && n != 0) {
+            if (btype == 0) { for (uint32_t k = 16 * sub; k < bsize; k += 16 * LPF) { const V16 v = gv16(src + b0 + k); lds_sv16(outo + k, v); } } // (inputs are readable 16 bytes past their end; the window has 16 bytes of slack)
+            else { const uint32_t v = rle_byte * 0x01010101u; for (uint32_t k = 4 * sub; k < bsize; k += 4 * LPF) L32(outo + k) = v; }
+        }
+        wsync();
 
         // =============================== execution: the slot is the file's output window now, LPF sequences at a time, lane = sequence.
         // Software pipeline over the steps: the sequences of step c + 2 and the literals of step c + 1 are in flight (HBM scratch, L2)
@@ -1327,6 +1374,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
 #endif
             }
         }
+      } // pass
         SSTAMP(9);
         first_group = false;
         if (!early) { g_next = ticket(); Jn = job_entry(list_entry(g_next)); prefetch(Jn, pfn); } // (wave-uniform)
@@ -1339,9 +1387,11 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
 
 } // namespace lw
 
-uint32_t lds_kernel_bytes(int g, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes) {
+uint32_t lds_kernel_bytes_per_file(uint32_t tab_bytes, uint32_t comp_bytes) { return tab_bytes + lw::kAux + comp_bytes; } // a file's entropy image
+uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes) {
     const uint32_t ent = tab_bytes + lw::kAux + comp_bytes;
-    return lw::kShBytes + (with_dict ? lw::kDictImg : 0u) + (uint32_t)g * (ent > out_bytes ? ent : out_bytes);
+    const uint32_t files = g != xg ? std::max<uint32_t>((uint32_t)g * ent, (uint32_t)xg * out_bytes) : (uint32_t)g * std::max(ent, out_bytes);
+    return lw::kShBytes + 32u * (uint32_t)g + (with_dict ? lw::kDictImg : 0u) + files;
 }
 // what a slot has left for tables beside its input when the output window, not the input, sets its size (multiple of 16, at most 4 KiB)
 uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes) {
@@ -1350,16 +1400,23 @@ uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes) {
 }
 size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap) { return (size_t)lit_stride + 8u * (size_t)seq_cap; }
 
-void launch_lds(const LdsArgs& a, uint32_t grid, int g, int with_dict, void* stream) {
-    const uint32_t bytes = lds_kernel_bytes(g, with_dict, a.tab_bytes, a.comp_bytes, a.out_bytes);
+// every instantiation the host can ask for: (files per wavefront, with a dictionary image, files executed at a time)
+#define MZD_LDS_VARIANTS(X) X(4, false, 4) X(8, false, 8) X(16, false, 16) X(8, false, 4) X(4, true, 4) X(8, true, 8) X(16, true, 16)
+// The kernels ask for up to 160 KiB of dynamic LDS (the default limit is 64 KiB): the attribute belongs to the CURRENT device's
+// function object, so it is raised once per device, from init_device (mzd_host.cpp), for every instantiation.
+int lds_prepare_device() {
+#define X(GG, DD, XX) if (hipFuncSetAttribute((const void*)lw::mzd_lds_kernel<GG, DD, XX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return MZD_E_DEVICE; }
+    MZD_LDS_VARIANTS(X)
+#undef X
+    return MZD_OK;
+}
+int launch_lds(const LdsArgs& a, uint32_t grid, int g, int xg, int with_dict, void* stream) {
+    const uint32_t bytes = lds_kernel_bytes(g, xg, with_dict, a.tab_bytes, a.comp_bytes, a.out_bytes);
     hipStream_t s = (hipStream_t)stream;
-#define MZD_LDS_LAUNCH(GG, DD) do { \
-        static bool attr_set = false; \
-        if (!attr_set) { hipFuncSetAttribute((const void*)lw::mzd_lds_kernel<GG, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
-        hipLaunchKernelGGL((lw::mzd_lds_kernel<GG, DD>), dim3(grid), dim3(64), bytes, s, a); } while (0)
-    if (with_dict) { if (g == 4) MZD_LDS_LAUNCH(4, true); else if (g == 8) MZD_LDS_LAUNCH(8, true); else MZD_LDS_LAUNCH(16, true); }
-    else { if (g == 4) MZD_LDS_LAUNCH(4, false); else if (g == 8) MZD_LDS_LAUNCH(8, false); else MZD_LDS_LAUNCH(16, false); }
-#undef MZD_LDS_LAUNCH
+#define X(GG, DD, XX) if (g == GG && xg == XX && (with_dict != 0) == DD) { hipLaunchKernelGGL((lw::mzd_lds_kernel<GG, DD, XX>), dim3(grid), dim3(64), bytes, s, a); return MZD_OK; }
+    MZD_LDS_VARIANTS(X)
+#undef X
+    return MZD_E_PARAM;
 }
 
 } // namespace mzd

@@ -1,6 +1,6 @@
 """Diagnostic: what dictionary content resident in LDS could save, and what it would cost, measured with the shipped
 kernel: (a) a build that skips the trips to the content in L2 (-DMZD_EXP_NODICTFETCH: bytes wrong, time an upper bound of the saving);
-(b) the shipped build with only as many wavefronts resident as would fit beside 112 KB of content (MZD_LDS_GRID).  python tools/dict_lds_bound.py"""
+(b) the shipped build with only as many wavefronts resident as would fit beside 112 KB of content (GRID).  python tools/dict_lds_bound.py"""
 import os, sys, subprocess
 CH = r'''
 import os, sys
@@ -10,6 +10,8 @@ import fuse_zstd_amd.api as api
 api._SO = os.path.join(os.path.dirname(api._SO), sys.argv[1])
 import corpus, fuse_zstd_amd as mzd
 mzd.init()
+if os.environ.get('G'): api.lib().mzd_debug_host_path(0, 4, int(os.environ['G']))
+if os.environ.get('GRID'): api.lib().mzd_debug_host_path(0, 6, int(os.environ['GRID']))
 dev = torch.device("cuda:0")
 rs = np.random.RandomState(55).randint(300, 3001, size=50000)
 d = corpus.train_dict("json", 5, [int(x) for x in rs[:4000]], cap=112640)
@@ -22,7 +24,7 @@ jobs = api.make_jobs([comp.data_ptr() + int(o) for o in cp.comp_offs], cp.comp_s
 ts = []
 for _ in range(7):
     res = mzd.decode_batch_device(0, jobs); ts.append(mzd.last_kernel_ms(0))
-print("%-16s G=%s grid=%s: cfg5 kernel best %.3f ms, median %.3f ms" % (sys.argv[1], os.environ.get("MZD_LDS_G", "auto(8)"), os.environ.get("MZD_LDS_GRID", "all"), min(ts), sorted(ts)[3]), flush=True)
+print("%-16s G=%s grid=%s: cfg5 kernel best %.3f ms, median %.3f ms" % (sys.argv[1], os.environ.get("G", "auto(8)"), os.environ.get("GRID", "all"), min(ts), sorted(ts)[3]), flush=True)
 '''
-for so, env in [("libmzd.so", {}), ("libmzd_exp.so", {}), ("libmzd.so", {"MZD_LDS_GRID": "256"}), ("libmzd.so", {"MZD_LDS_GRID": "256", "MZD_LDS_G": "4"}), ("libmzd.so", {"MZD_LDS_GRID": "512", "MZD_LDS_G": "4"}), ("libmzd_exp.so", {"MZD_LDS_GRID": "256"}), ("libmzd.so", {})]:
+for so, env in [("libmzd.so", {}), ("libmzd_exp.so", {}), ("libmzd.so", {"GRID": "256"}), ("libmzd.so", {"GRID": "256", "G": "4"}), ("libmzd.so", {"GRID": "512", "G": "4"}), ("libmzd_exp.so", {"GRID": "256"}), ("libmzd.so", {})]:
     subprocess.run([sys.executable, "-c", CH, so], env=dict(os.environ, **env))

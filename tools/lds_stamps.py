@@ -1,6 +1,6 @@
 """Diagnostic: phase times of the LDS small-file kernel (mzd_lds.hip), from a library built with `make sstamps`:
 cycles between the phase boundaries of workgroup 0's first group, and the kernel time of the launch.
-  python tools/lds_stamps.py [cfg4|cfg5] [files]      (MZD_LDS_G=4|8|16 picks the files per wavefront)"""
+  python tools/lds_stamps.py [cfg4|cfg5] [files]      (G=4|8|16 [XG=4] in the environment of THIS tool pick the files per wavefront / executed at a time: mzd_debug_host_path 4 / 5)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -29,6 +29,8 @@ torch.cuda.synchronize()
 names = ["take group, job entries, input -> LDS", "headers", "Huffman weights + table", "Huffman streams", "sequence header, counts",
          "FSE tables", "walk + extract -> scratch", "execute (window)", "XXH64", "flush + results"]
 mzd.set_driver(3)
+if os.environ.get('G'): api.lib().mzd_debug_host_path(0, 4, int(os.environ['G']))
+if os.environ.get('XG'): api.lib().mzd_debug_host_path(0, 5, int(os.environ['XG']))
 for rep in range(3):
     res = mzd.decode_batch_device(0, jobs)
     assert all(st == 0 for st, _ in res)
@@ -41,7 +43,7 @@ for rep in range(3):
         json.dump([(x >> 32, x & 0xFFFFFFFF) for x in t[65:65 + min(t[64], 960)]], open("gpurun_out/lds_failed.json", "w"))
     if any(t[32:48]): print("    left the fast path, by reason 0..15:", t[32:48], "last (file, group<<8|lane):", [(x >> 32, hex(x & 0xFFFFFFFF)) for x in t[48:64] if x])
     if rep == 2:
-        print("%s G=%s: kernel %.3f ms; workgroup 0, first group: total %d cycles" % (wl, os.environ.get("MZD_LDS_G", "auto"), mzd.last_kernel_ms(0), t[9] - t[0]))
+        print("%s G=%s: kernel %.3f ms; workgroup 0, first group: total %d cycles" % (wl, os.environ.get("G", "auto") + "/" + os.environ.get("XG", "-"), mzd.last_kernel_ms(0), t[9] - t[0]))
         print("    inside: walk %d, extract %d cycles" % (t[10], t[11]))
         if t[13] and t[14] and t[15]: print("    Huffman weights: counts %d, their FSE table %d, the weights %d, validation + decode table %d cycles" % (t[13] - t[2], t[14] - t[13], t[15] - t[14], t[3] - t[15]))
         print("    execute: stage A %d, repeat offsets %d, literals %d, match rounds %d cycles (%d rounds)" % (t[18], t[19], t[20], t[21], t[22]))
