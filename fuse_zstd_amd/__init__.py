@@ -8,8 +8,8 @@ handle table src/file.rs).  There is no CPU fallback: without the built library 
 every call raises / returns MZD_E_DEVICE.
 """
 from .api import (  # noqa: F401
-    MzdError, Batch, ZstdFS, build, lib, init, shutdown, device_count, content_size, copy_decode,
-    decode, decode_batch, decode_batch_device, load_dict, unload_dict, set_driver, debug_counters, HostBuffer, last_kernel_ms, debug_last_block, strerror,
+    MzdError, Batch, ZstdFS, build, lib, init, shutdown, device_count, content_size, content_bound, copy_decode,
+    decode, decode_batch, decode_batch_device, load_dict, unload_dict, set_driver, debug_counters, HostBuffer, last_kernel_ms, last_kernel_name, debug_last_block, strerror,
     OK, E_CORRUPT, E_TRUNCATED, E_CHECKSUM, E_DSTSIZE, E_UNSUPPORTED, E_DEVICE, E_BADMAGIC, E_DICT, E_PARAM,
     SRC_PADDING, CONTENTSIZE_UNKNOWN, CONTENTSIZE_ERROR, EXPORTS,
 )

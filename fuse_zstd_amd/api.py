@@ -15,10 +15,10 @@ CONTENTSIZE_ERROR = 2**64 - 2
 
 # every symbol include/mzd.h declares
 EXPORTS = [
-    "mzd_init", "mzd_init_ex", "mzd_shutdown", "mzd_device_count", "mzd_content_size", "mzd_decode", "mzd_decode_batch",
+    "mzd_init", "mzd_init_ex", "mzd_shutdown", "mzd_device_count", "mzd_content_size", "mzd_content_bound", "mzd_decode", "mzd_decode_batch",
     "mzd_decode_batch_device", "mzd_batch_prepare", "mzd_batch_launch", "mzd_batch_collect", "mzd_batch_free",
     "mzd_load_dict", "mzd_unload_dict", "mzd_debug_last_block", "mzd_debug_set_driver", "mzd_debug_counters", "mzd_debug_host_path", "mzd_debug_stamps", "mzd_debug_small_stamps", "mzd_debug_small_scratch", "mzd_debug_tfin_all", "mzd_debug_lazy_plan",
-    "mzd_host_alloc", "mzd_host_free", "mzd_last_kernel_ms", "mzd_strerror", "mzd_version",
+    "mzd_host_alloc", "mzd_host_free", "mzd_last_kernel_ms", "mzd_last_kernel_name", "mzd_strerror", "mzd_version",
     "mzd_fs_new", "mzd_fs_free", "mzd_fs_open", "mzd_fs_open_lazy", "mzd_fs_read", "mzd_fs_release", "mzd_fs_decode_count", "mzd_fs_decoded_bytes",
 ]
 
@@ -88,6 +88,8 @@ def lib():
         L.mzd_init.argtypes = [C.POINTER(C.c_int), C.c_int]
         L.mzd_content_size.restype = C.c_uint64
         L.mzd_content_size.argtypes = [C.c_char_p, C.c_size_t]
+        L.mzd_content_bound.restype = C.c_uint64
+        L.mzd_content_bound.argtypes = [C.c_char_p, C.c_size_t]
         L.mzd_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mzd_decode_batch.argtypes = [C.POINTER(Job), C.c_size_t]
         L.mzd_decode_batch_device.argtypes = [C.c_int, C.POINTER(Job), C.c_size_t, C.c_void_p]
@@ -106,6 +108,8 @@ def lib():
         L.mzd_debug_last_block.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_size_t)]
         L.mzd_last_kernel_ms.argtypes = [C.c_int, C.POINTER(C.c_float)]
+        L.mzd_last_kernel_name.restype = C.c_char_p
+        L.mzd_last_kernel_name.argtypes = [C.c_int]
         L.mzd_strerror.restype = C.c_char_p
         L.mzd_strerror.argtypes = [C.c_int]
         L.mzd_version.restype = C.c_char_p
@@ -167,6 +171,13 @@ def content_size(src):
     return lib().mzd_content_size(src, len(src))
 
 
+def content_bound(src):
+    """A capacity certain to hold the decoded file (mzd_content_bound): the content size where the frames state it, else what
+    their block headers allow at most."""
+    src = bytes(src)
+    return lib().mzd_content_bound(src, len(src))
+
+
 def decode(src, cap=None, dict_id=0):
     """Whole-file decode of host bytes.  Returns (status, bytes)."""
     src = bytes(src)
@@ -185,13 +196,12 @@ def copy_decode(source, destination):
     cs = content_size(data)
     if cs == CONTENTSIZE_ERROR:
         raise OSError(errno.EFAULT, "zstd decode failed")
-    cap = cs if cs != CONTENTSIZE_UNKNOWN else max(8 * len(data), 1 << 20)
-    for _ in range(8):
-        rc, out = decode(data, cap)
-        if rc == E_DSTSIZE and cs == CONTENTSIZE_UNKNOWN:
-            cap *= 4
-            continue
-        break
+    # frames without a content size: a guess first, then what the block headers allow at most (mzd_content_bound): two decodes at most
+    bound = content_bound(data)
+    cap = cs if cs != CONTENTSIZE_UNKNOWN else min(max(8 * len(data), 1 << 20), bound)
+    rc, out = decode(data, cap)
+    if rc == E_DSTSIZE and cs == CONTENTSIZE_UNKNOWN and bound < CONTENTSIZE_ERROR and bound > cap:
+        rc, out = decode(data, bound)
     if rc != OK:
         raise OSError(errno.EFAULT, "zstd decode failed: %s" % strerror(rc))
     destination.write(out)
@@ -315,6 +325,11 @@ def last_kernel_ms(device=0):
     ms = C.c_float(0)
     lib().mzd_last_kernel_ms(device, C.byref(ms))
     return ms.value
+
+
+def last_kernel_name(device=0):
+    """What the most recent device-pointer launch ran (dominant kernel first)."""
+    return lib().mzd_last_kernel_name(device).decode()
 
 
 def debug_last_block(device=0):

@@ -106,6 +106,7 @@ struct Device {
     bool dict_used[kMaxDicts] = {};
     void* dict_bufs[kMaxDicts] = {};
     float last_ms = 0.f;
+    char last_kernels[96] = "";           // what the most recent whole-device launch ran, dominant kernel first (mzd_last_kernel_name)
     uint32_t* job0_counter = nullptr;      // counter block of the launch that decoded job 0 of the most recent call (mzd_debug_last_block)
     std::atomic<bool> whole_used{false};   // a whole-device launch may still be running on a caller's stream: lanes wait for its end event
     // resources: lanes and stagings are handed out under `mu`
@@ -440,11 +441,19 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / per_wave);
         const uint32_t dbg_grid = g_small_grid.load(std::memory_order_relaxed); // (mzd_debug_host_path 6: experiments with fewer resident wavefronts)
         { int lrc = launch_lds(la, std::min(ngroups, std::min(dbg_grid ? dbg_grid : resident, by_scratch)), p.lds_g, p.lds_xg, p.with_dict ? 1 : 0, s); if (lrc) return lrc; }
+        if (&l == &d.whole) {
+            char small[48];
+            snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg);
+            const char* big = use_tasks ? "mzd_decode_kernel_tasks" : "mzd_decode_kernel_files";
+            if (p.nbig > p.nsmall) snprintf(d.last_kernels, sizeof d.last_kernels, "%s+%s", big, small);
+            else snprintf(d.last_kernels, sizeof d.last_kernels, "%s+%s", small, big); // (the general driver's launch behind it takes what was handed on: usually nothing)
+        }
         HIPCHK(hipGetLastError());
         ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig;
         grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
     } else {
         grid = use_tasks ? std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(njobs, l.nwg)) : njobs;
+        if (&l == &d.whole) snprintf(d.last_kernels, sizeof d.last_kernels, "%s", use_tasks ? "mzd_decode_kernel_tasks" : "mzd_decode_kernel_files");
         if (p.lpt) { ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig; } // (largest first; nothing is appended: counter word 4 stays 0)
     }
     grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, l.nwg));
@@ -961,7 +970,9 @@ void mzd_host_free(void* p) {
 }
 
 // Frame header walk (RFC 8878 3.1.1): no entropy decoding, so it stays on the host.
-uint64_t mzd_content_size(const uint8_t* src, size_t n) {
+// bound: instead of "unknown" for a frame without a content size, what its blocks can regenerate at most -- a raw or RLE block
+// its stated size, a compressed block min(128 KiB, the frame's window)
+static uint64_t content_walk(const uint8_t* src, size_t n, bool bound) {
     size_t pos = 0;
     uint64_t total = 0;
     bool unknown = false;
@@ -982,10 +993,16 @@ uint64_t mzd_content_size(const uint8_t* src, size_t n) {
         size_t hs = 5 + (single ? 0 : 1) + (did == 3 ? 4 : did) + (fcsf == 0 ? single : (1u << fcsf));
         if (n - pos < hs) return MZD_CONTENTSIZE_ERROR;
         const uint8_t* q = src + pos + hs - (fcsf == 0 ? single : (1u << fcsf));
-        if (fcsf == 0) { if (single) total += *q; else unknown = true; }
-        else if (fcsf == 1) total += (uint64_t)rd16(q) + 256;
-        else if (fcsf == 2) total += rd32(q);
-        else total += rd64(q);
+        bool has_fcs = true;
+        uint64_t fcs = 0;
+        if (fcsf == 0) { if (single) fcs = *q; else has_fcs = false; }
+        else if (fcsf == 1) fcs = (uint64_t)rd16(q) + 256;
+        else if (fcsf == 2) fcs = rd32(q);
+        else fcs = rd64(q);
+        uint64_t window = fcs;
+        if (!single) { const uint32_t wb = src[pos + 5]; const uint32_t wl = 10 + (wb >> 3); window = (1ull << wl) + ((1ull << wl) >> 3) * (wb & 7); }
+        const uint64_t block_max = std::min<uint64_t>(window, kBlockMax);
+        uint64_t by_blocks = 0;
         size_t p = pos + hs;
         for (;;) { // block chain
             if (n - p < 3) return MZD_CONTENTSIZE_ERROR;
@@ -995,14 +1012,18 @@ uint64_t mzd_content_size(const uint8_t* src, size_t n) {
             if (type == 3) return MZD_CONTENTSIZE_ERROR;
             size_t adv = type == 1 ? 1 : bs;
             if (n - p < adv) return MZD_CONTENTSIZE_ERROR;
+            by_blocks += type == 2 ? block_max : bs;
             p += adv;
             if (bh & 1) break;
         }
         if (fhd & 4) { if (n - p < 4) return MZD_CONTENTSIZE_ERROR; p += 4; }
+        if (has_fcs) total += fcs; else if (bound) total += by_blocks; else unknown = true;
         pos = p;
     }
     return unknown ? MZD_CONTENTSIZE_UNKNOWN : total;
 }
+uint64_t mzd_content_size(const uint8_t* src, size_t n) { return content_walk(src, n, false); }
+uint64_t mzd_content_bound(const uint8_t* src, size_t n) { return content_walk(src, n, true); }
 
 int mzd_decode_batch(mzd_job* jobs, size_t njobs) {
     std::vector<std::shared_ptr<Device>> devs;
@@ -1023,6 +1044,12 @@ int mzd_decode_batch(mzd_job* jobs, size_t njobs) {
         for (auto& t : th) t.join();
     }
     for (int rc : rcs) if (rc) return rc;
+    // a destination that was too small: out_len says what would have sufficed (host buffers: the headers can be walked here)
+    for (size_t i = 0; i < njobs; i++)
+        if (jobs[i].status == MZD_E_DSTSIZE && jobs[i].src) {
+            const uint64_t need = mzd_content_bound(jobs[i].src, jobs[i].src_len);
+            jobs[i].out_len = need < MZD_CONTENTSIZE_ERROR && need > jobs[i].dst_cap ? (size_t)need : 0;
+        }
     return MZD_OK;
 }
 
@@ -1268,6 +1295,11 @@ int mzd_last_kernel_ms(int device, float* ms) {
     return MZD_OK;
 }
 
+const char* mzd_last_kernel_name(int device) {
+    auto d = get_device(device);
+    return d ? d->last_kernels : "";
+}
+
 const char* mzd_strerror(int code) {
     switch (code) {
     case MZD_OK: return "ok";
@@ -1359,14 +1391,16 @@ int64_t mzd_fs_open(mzd_fs* fs, uint64_t ino, int32_t flags, const uint8_t* zst,
     uint64_t want = mzd_content_size(zst, zst_len);
     if (want == MZD_CONTENTSIZE_ERROR) return -EFAULT;
     if (want != MZD_CONTENTSIZE_UNKNOWN && want > max_regenerated(zst_len)) return -EFAULT; // (a header that promises more than its blocks can hold)
-    size_t cap = want == MZD_CONTENTSIZE_UNKNOWN ? std::max<size_t>(zst_len * 8, 1 << 20) : (size_t)want;
-    for (int attempt = 0; attempt < 8; attempt++) { // frames without a content size: grow until it fits
+    // frames without a content size: a guess first (eight times the input, at least 1 MiB); if that is too small, the decode
+    // reports what the block headers allow at most (mzd_content_bound) and the second attempt cannot fail for size
+    size_t cap = want == MZD_CONTENTSIZE_UNKNOWN ? (size_t)std::min<uint64_t>(std::max<size_t>(zst_len * 8, 1 << 20), mzd_content_bound(zst, zst_len)) : (size_t)want;
+    for (int attempt = 0; attempt < 2; attempt++) {
         try { file->bytes.resize(cap); } catch (const std::exception&) { return -ENOMEM; }
         size_t out_len = 0;
         int rc = mzd_decode(zst, zst_len, file->bytes.data(), cap, &out_len);
         fs->decodes++;
         if (rc == MZD_OK) { file->bytes.resize(out_len); fs->decoded_bytes += out_len; break; }
-        if (rc == MZD_E_DSTSIZE && want == MZD_CONTENTSIZE_UNKNOWN && attempt < 7) { cap *= 4; continue; }
+        if (rc == MZD_E_DSTSIZE && want == MZD_CONTENTSIZE_UNKNOWN && attempt == 0 && out_len > cap) { cap = out_len; continue; }
         return -EFAULT;
     }
     uint64_t fh;

@@ -57,7 +57,8 @@ typedef struct mzd_job {
     size_t src_len;
     uint8_t* dst;       /* decoded bytes */
     size_t dst_cap;
-    size_t out_len;     /* OUT: decoded length (what open_wrapper stores in user.real_size, :473-482) */
+    size_t out_len;     /* OUT: decoded length (what open_wrapper stores in user.real_size, :473-482); with status MZD_E_DSTSIZE on host
+                           pointers: the capacity that would have sufficed (mzd_content_bound) */
     int32_t status;     /* OUT: MZD_OK or MZD_E_* */
     uint32_t dict_id;   /* 0 = none, else a handle from mzd_load_dict */
     int32_t device;     /* OUT: index (into mzd_init's list) of the GPU that decoded the job; -1 if none did */
@@ -101,6 +102,13 @@ void mzd_host_free(void* p);
  * MZD_CONTENTSIZE_UNKNOWN if some frame omits the field, MZD_CONTENTSIZE_ERROR if the
  * headers are malformed.  Frames written by the reference always carry it (src/main.rs:785-788). */
 uint64_t mzd_content_size(const uint8_t* src, size_t n);
+/* A capacity that is certain to hold the decoded file: frames that state their content size count with it (so the result is
+ * mzd_content_size's whenever that is known), the others with what their block headers allow at most -- a raw or RLE block
+ * its stated size, a compressed block min(128 KiB, window).  Host-side header walk, no GPU.  MZD_CONTENTSIZE_ERROR if the
+ * headers are malformed.  SURVEY.md 8(b) "Ownership": a destination that was too small comes back as MZD_E_DSTSIZE with this
+ * value in out_len (host-pointer entry points; 0 when the headers cannot be walked), so a file without content sizes costs at
+ * most two decodes (mzd_fs_open: a guess, then this). */
+uint64_t mzd_content_bound(const uint8_t* src, size_t n);
 
 /* copy_decode on host buffers: stages src to the GPU, decodes, copies the result back.
  * Single call site shape of reference src/main.rs:463.  Thread-compatible with the
@@ -171,6 +179,10 @@ int mzd_debug_lazy_plan(const uint8_t* zst, size_t n, uint32_t frame, uint32_t n
 /* Milliseconds the decode kernel of the last launch on `device` took (hipEvents on the
  * launch stream).  Valid after the launch has been collected. */
 int mzd_last_kernel_ms(int device, float* ms);
+/* The kernels the most recent launch on device pointers ran on `device`, the one that did most of the work first, '+' between
+ * them: "mzd_lds_kernel<8,false,4>+mzd_decode_kernel_files", "mzd_decode_kernel_tasks", ... (the library's own record of what
+ * make_plan chose; benchmarks quote it instead of guessing).  Valid until the next launch on that device. */
+const char* mzd_last_kernel_name(int device);
 
 const char* mzd_strerror(int code);
 const char* mzd_version(void);

@@ -51,6 +51,25 @@ def test_content_size_malformed(lib):
     assert mzd.content_size(good[:-5]) == mzd.CONTENTSIZE_ERROR  # truncated inside the frame
 
 
+@pytest.mark.parametrize("v", [v for v in VECS if v.ok and v.dict is None], ids=lambda v: v.name)
+def test_content_bound_is_the_size_where_stated_and_never_below_it(lib, v):
+    """mzd_content_bound: SURVEY.md 8(b) "Ownership" -- the capacity a too-small destination is told to retry with."""
+    bound, size = mzd.content_bound(v.comp), mzd.content_size(v.comp)
+    assert bound < mzd.CONTENTSIZE_ERROR and bound >= v.out_len
+    if size != mzd.CONTENTSIZE_UNKNOWN:
+        assert bound == size == v.out_len
+    else:  # what the block headers allow at most: 128 KiB per compressed block, the stated size of raw / RLE blocks
+        rc, out, blocks = oracle.decode(v.comp, cap=v.out_len, want_trace=True)
+        assert rc == 0 and bound <= sum(b["regen"] if b["block_type"] < 2 else 131072 for b in blocks)
+
+
+def test_content_bound_malformed(lib):
+    assert mzd.content_bound(b"\x01\x02\x03\x04\x05\x06") == mzd.CONTENTSIZE_ERROR
+    assert mzd.content_bound(b"") == 0
+    good = next(x for x in VECS if x.name == "nofcs_stream_300k").comp
+    assert mzd.content_bound(good[:-5]) == mzd.CONTENTSIZE_ERROR
+
+
 def test_error_strings_and_codes(lib):
     for code in range(0, -10, -1):
         assert mzd.strerror(code) and mzd.strerror(code) != "unknown error"

@@ -83,6 +83,29 @@ def test_dst_too_small_and_empty():
     assert mzd.decode(b"", 16) == (0, b"")
 
 
+def test_dst_too_small_reports_the_capacity_that_suffices():
+    """SURVEY.md 8(b) "Ownership": MZD_E_DSTSIZE comes with the required size, also for frames without a content size -- a second
+    decode with it succeeds; the open() mirror needs at most two decodes for such a file."""
+    import ctypes as C
+    L = mzd.lib()
+    for name in ("nofcs_stream_300k", "json_128k", "multi_frame_skippable"):
+        v = next(x for x in VECS if x.name == name)
+        buf = C.create_string_buffer(max(v.out_len, 1))
+        n = C.c_size_t(0)
+        assert L.mzd_decode(v.comp, len(v.comp), buf, 100, C.byref(n)) == mzd.E_DSTSIZE
+        assert n.value == mzd.content_bound(v.comp) >= v.out_len
+        big = C.create_string_buffer(n.value)
+        assert L.mzd_decode(v.comp, len(v.comp), big, n.value, C.byref(n)) == 0 and n.value == v.out_len
+        rc, want = oracle.decode(v.comp, cap=v.out_len)
+        assert rc == 0 and big.raw[:n.value] == want
+    v = next(x for x in VECS if x.name == "nofcs_stream_300k")  # 300 KB from ~50 KB of input: the first guess (1 MiB) holds it
+    fs = mzd.ZstdFS()
+    fh, size = fs.open(7, 0, v.comp)
+    assert size == v.out_len and fs.decode_count <= 2 and fs.read(fh, 0, v.out_len) == oracle.decode(v.comp, cap=v.out_len)[1]
+    fs.release(fh)
+    fs.close()
+
+
 def test_dst_too_small_every_vector_matches_oracle():
     """Every positive vector (raw, RLE, literal-only, Huffman+sequences, multi-block, multi-frame) into a buffer that is
     one byte short / half size / one byte long, interleaved with full-size neighbours: same status class as the CPU
