@@ -4,12 +4,13 @@
 A "step" is one pass of the hot path (the whole-file decode fuse-zstd runs on open(), reference
 src/main.rs:463-467) over one batch of synthetic .zst files already resident in HBM: the timed
 region contains only kernel launches (device-resident compressed bytes in, decompressed bytes
-left in HBM).  Workload at N=1 = BASELINE.json configs[1]: 1 000 independent 128 KiB
-single-block JSON frames written like the reference's writer (level 3, checksum, pledged size;
-src/main.rs:781-791).  With N GPUs every rank takes files r, r+N, r+2N, ... of an N x 1000-file
-corpus (file i -> GPU i mod N, no collective; weak scaling).
+left in HBM).  Workload at N=1 = the corpus BASELINE.json's north_star names as the target ("decompressed GiB/s on a
+10 000-file synthetic-JSON .zst corpus"; configs[3], the reference's own benchmarks/parallel-files.fio:3-7 shape): 10 000
+independent 4 KiB JSON files written like the reference's writer (level 3, checksum, pledged size; src/main.rs:781-791);
+configs[1] (1 000 x 128 KiB single-block frames: `cfg2`) is the first of `other_workloads`.  With N GPUs every rank takes
+files r, r+N, r+2N, ... of an N x 10 000-file corpus (file i -> GPU i mod N, no collective; weak scaling).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg4lu|cfg5] [--files F]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg3|cfg4lu|cfg5|big1m|...] [--files F]
                   [--no-others] [--no-t2] [--no-cpu-baseline]
 
 ONE JSON line (rank 0).  `value` is T1 of SURVEY.md 8d: inputs in HBM when the timed region starts, outputs left in
@@ -21,9 +22,10 @@ HBM (several buffer sets are rotated so that the working set exceeds the 256 MiB
                    cores on the same files, repeated to ~10 s of CPU work.
   t2_end_to_end    T2: the path open() takes -- host buffers -> mzd_decode_batch -> host buffers, PCIe included
                    (the "through FUSE read path" half of BASELINE's metric; never `value`).
-  other_workloads  the remaining BASELINE configurations (cfg3 Silesia-proxy, cfg4 10 000 x 4 KiB = the north_star's
-                   corpus, cfg4lu log-uniform sizes, cfg5 shared dictionary), each T1 with value / kernel_ms /
-                   roofline.frac / byte-exact flag (no CPU baselines: the default run must stay within minutes).
+  other_workloads  the remaining BASELINE configurations (cfg2 1 000 x 128 KiB with its own T2, cfg3 Silesia-proxy, cfg4lu
+                   log-uniform sizes, cfg5 shared dictionary, big1m 400 x 1 MiB multi-block files = the block-task driver),
+                   each T1 with value / kernel_ms / roofline.frac / the kernels the library says it ran / byte-exact flag
+                   (CPU baselines only for the small-file corpora: the default run must stay within minutes).
   single_file      one 1 MiB JSON file (BASELINE configs[0] shape): kernel ms, host-path ms, CPU streaming ms.
   per_rank         N > 1: every rank's own value and roofline.frac.
 """
@@ -58,8 +60,10 @@ WORKLOADS = {
     "cfg2x8": ("json", 2, 0, "8 000 x 128 KiB single-block JSON frames (cfg2's generator, eight times the files: the sustained single-block rate)"),
     "cfg4x4": ("json", 4, 0, "40 000 x 4 KiB JSON files (cfg4's generator, four times the files: the sustained small-file rate)"),
     "cfg3x8": ("text", 3, 7, "8 000 x 128 KiB frames of cfg3's seven-class mix (eight times the files: chains of very different length, handed out longest first)"),
+    # few big files: every file's blocks on different workgroups (the block-task driver)
+    "big1m": ("json", 1, 0, "400 x 1 MiB JSON files of eight blocks each, level 3, checksum (BASELINE configs[0]'s file, 400 of them: block tasks)"),
 }
-DEFAULT_FILES = {"cfg2": 1000, "cfg3": 1000, "cfg4": 10000, "cfg4lu": 10000, "cfg5": 50000, "cfg2x8": 8000, "cfg4x4": 40000, "cfg3x8": 8000}
+DEFAULT_FILES = {"cfg2": 1000, "cfg3": 1000, "cfg4": 10000, "cfg4lu": 10000, "cfg5": 50000, "cfg2x8": 8000, "cfg4x4": 40000, "cfg3x8": 8000, "big1m": 400}
 
 
 def file_sizes(workload, nfiles, rank, world):
@@ -67,6 +71,8 @@ def file_sizes(workload, nfiles, rank, world):
         return [131072] * nfiles
     if workload in ("cfg4", "cfg4x4"):
         return [4096] * nfiles
+    if workload == "big1m":
+        return [1 << 20] * nfiles
     if workload == "cfg5":
         rng = np.random.RandomState(55)
         allsz = rng.randint(300, 3001, size=nfiles * world)
@@ -233,14 +239,6 @@ def traffic_recorded_at():
         return None
 
 
-def kernel_name(cp):
-    """The dominant kernel of a launch over this corpus (mzd_host.cpp: make_plan)."""
-    mx = int(cp.raw_sizes.max())
-    if int((cp.raw_sizes <= 8192).sum()) >= 2048 and mx <= 8192:  # (fewer small files than that go to a general driver)
-        return "mzd_lds_kernel"
-    return "mzd_decode_kernel_tasks" if mx > 131072 else "mzd_decode_kernel_files"
-
-
 class Workload:
     """One corpus, device-resident, with enough rotating buffer sets to exceed the Infinity Cache."""
 
@@ -319,6 +317,7 @@ def time_t1(w, steps, warmup, stream, fence):
     fence()
     t1 = time.perf_counter()
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(steps, 1)
+    w.kernels = w.mzd.last_kernel_name(0)  # what the library launched (mzd_last_kernel_name), dominant kernel first
     if steps >= w.nsets:
         w.check(sp, "after the timed region")  # every status again, and the bytes the timed launches wrote
     return t1 - t0, kernel_ms
@@ -430,8 +429,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--files", type=int, default=0, help="files per GPU (default 1000; 10000 for cfg4/cfg4lu; 50000 for cfg5)")
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--files", type=int, default=0, help="files per GPU (default: 10000 for cfg4/cfg4lu; 1000 for cfg2/cfg3; 50000 for cfg5; 400 for big1m)")
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the other_workloads / single_file objects")
@@ -516,7 +515,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
                          "traffic": recorded_traffic(args.workload), "traffic_recorded_at": traffic_recorded_at(),
-                         "kernel": kernel_name(w.cp), "kernel_ms_avg": round(kernel_ms, 4),
+                         "kernel": w.kernels, "kernel_ms_avg": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": w.C + w.U},
         }
         if per_rank:
@@ -533,18 +532,18 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_others:
             others = {}
-            for name in ("cfg3", "cfg4", "cfg4lu", "cfg5", "cfg2x8", "cfg4x4", "cfg3x8"):
+            for name in ("cfg2", "cfg4", "cfg3", "cfg4lu", "cfg5", "big1m", "cfg2x8", "cfg4x4", "cfg3x8"):
                 if name == args.workload:
                     continue
                 ow = Workload(name, DEFAULT_FILES[name], 0, 1, args.level, dev, mzd, corpus)
-                steps = 10 if name not in ("cfg4lu", "cfg2x8", "cfg3x8") else 6
+                steps = 10 if name not in ("cfg4lu", "cfg2x8", "cfg3x8", "big1m") else 6
                 el, kms = time_t1(ow, steps, 2, stream, local_fence)
                 ach = (ow.C + ow.U) / (kms * 1e-3) / 1e9
                 others[name] = {"workload": ow.desc, "files": ow.nfiles, "value": round(ow.U * steps / el / GIB, 3), "unit": "GiB/s",
                                 "files_per_s": round(ow.nfiles * steps / el), "ms_per_step": round(el / steps * 1e3, 4), "kernel_ms": round(kms, 4),
-                                "kernel": kernel_name(ow.cp), "roofline_frac": round(ach / HBM_PEAK_GBS, 5), "achieved_GBps": round(ach, 2),
+                                "kernel": ow.kernels, "roofline_frac": round(ach / HBM_PEAK_GBS, 5), "achieved_GBps": round(ach, 2),
                                 "algorithmic_bytes_per_launch": ow.C + ow.U, "traffic": recorded_traffic(name), "buffer_sets_rotated": ow.nsets, "byte_exact": True, "steps": steps}
-                if name == "cfg4" and not args.no_t2:
+                if name in ("cfg4", "cfg2") and not args.no_t2:
                     others[name]["t2_end_to_end"] = t2_end_to_end(ow, mzd, reps=3)
                 if name in ("cfg4", "cfg5") and not args.no_cpu_baseline:  # the north_star's many-small-files corpora: the CPU beside them (short samples)
                     others[name]["cpu_baseline"] = cpu_baseline(ow.cp, 2.0) if ow.dictionary is None else cpu_baseline_dict(ow.cp, ow.dictionary, 3.0)
