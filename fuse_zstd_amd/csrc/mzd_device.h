@@ -10,6 +10,11 @@ constexpr uint32_t kBlockMax = 128u * 1024u; // Block_Maximum_Size upper bound (
 constexpr uint32_t kMaxSeq = 43691u;         // a block regenerates <= 128 KiB and every match is >= 3 bytes
 constexpr uint32_t kLitStride = kBlockMax + 64;
 constexpr uint32_t kResMapStride = kBlockMax + 64; // words per workgroup slot of the resolve map (mzd_k_resolve.h)
+// A Huffman decode table: 2 048 entries (symbol | length << 8) indexed by the next 11 bits of the stream, or -- a tree of depth 12,
+// which libzstd accepts (HUF_TABLELOG_MAX) although no encoder emits one -- indexed by the top 11 of the next 12 bits: an entry then
+// stands for two neighbouring 12-bit codes; where those are two codes of length 12 (two symbols of weight 1: they come in pairs), the
+// entry holds the even one's symbol and the odd one's sits in the 128 bytes behind the table (byte k for entry k).
+constexpr uint32_t kHufEntries = 2048 + 64, kHufWords = kHufEntries / 2;
 constexpr uint32_t kSeqStride = kMaxSeq + 21; // uint4 entries per workgroup (multiple of 64 keeps 16-B alignment)
 
 // One file.  Device mirror of mzd_job (include/mzd.h).
@@ -33,7 +38,7 @@ struct DevDict {
     uint64_t ll[512];
     uint64_t ml[512];
     uint64_t of[256];
-    uint16_t huf[2048];
+    uint16_t huf[kHufEntries];
     uint32_t al[3];
     uint32_t huf_log;
     uint32_t rep[3];
@@ -94,7 +99,7 @@ struct TableArea { // the entropy tables in force after the file's most recently
     uint64_t ll[512];
     uint64_t ml[512];
     uint64_t of[256];
-    uint16_t huf[2048];
+    uint16_t huf[kHufEntries];
 };
 
 struct ContRecord { // one pushed task: where it starts and the frame it belongs to

@@ -85,7 +85,7 @@ struct __attribute__((aligned(16))) Shared {
 #if defined(MZD_STAMPS) || defined(MZD_TFIN)
     uint64_t ttask, tstart, tabs, tfin[12]; // block start; finish of walker / copier / hasher / planner; literals ready; tables ready
 #endif
-    uint16_t huf[2048]; // sym | len << 8
+    uint16_t huf[kHufEntries]; // sym | len << 8 (mzd_device.h: kHufEntries)
     int16_t norm[3][64];
     uint16_t next[3][64];
     alignas(16) int16_t wnorm[256]; // FSE table of the Huffman weights.  wnorm + wtab + weights (1 KiB, contiguous) double as the

@@ -18,7 +18,10 @@ constexpr int32_t kSegBits = 64 * 248; // 31 bytes per lane: lane windows fall i
 #ifndef MZD_HUF_MINC
 #define MZD_HUF_MINC 16
 #endif
-__device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int lane) {
+// BIG: a tree of depth 12 (L == 12), which libzstd accepts and no encoder emits: the table is indexed by the top 11 of the next 12
+// bits and two codes of length 12 share an entry (mzd_device.h: kHufEntries); four symbols per window instead of five (4 * 12 <= 57).
+template <bool BIG>
+__device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int lane) {
     if (sl == 0) return MZD_E_CORRUPT;
     uint32_t last = sp[sl - 1];
     if (last == 0) return MZD_E_CORRUPT;
@@ -59,10 +62,12 @@ __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint
                 __builtin_memcpy(&W, seg + (uint32_t)(bi + seg_bias), 8);
                 int32_t h = rem - bi * 8;           // read point inside the window
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
+                for (int k = 0; k < (BIG ? 4 : 5); k++) {
                     const bool act = rem > lim;
-                    const uint32_t e = tab[(uint32_t)(W >> (uint32_t)(h - (int32_t)L)) & mask];
+                    const uint32_t v = (uint32_t)(W >> (uint32_t)(h - (int32_t)L)) & mask;
+                    uint32_t e = tab[BIG ? v >> 1 : v];
                     uint32_t l = e >> 8;
+                    if (BIG && l == 12 && (v & 1)) e = reinterpret_cast<const uint8_t*>(&S.huf[2048])[v >> 1]; // the odd one of two codes of length 12
                     l = l ? l : 1u;
                     if (dst && act) {
                         acc |= (uint64_t)(e & 0xFF) << ((c & 7) * 8);
@@ -131,4 +136,6 @@ __device__ __noinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint
     if (done != nsym) return MZD_E_CORRUPT; // pos == nbits here: the stream was consumed exactly
     return 0;
 }
-
+__device__ __forceinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int lane) {
+    return L == 12 ? huf_stream_wave_t<true>(sp, sl, out, nsym, L, seg, lane) : huf_stream_wave_t<false>(sp, sl, out, nsym, L, seg, lane);
+}

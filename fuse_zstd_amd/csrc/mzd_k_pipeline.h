@@ -153,7 +153,7 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
                     for (int i = lane; i < 512; i += 64) { g_st(&ta->ll[i], S.ll[i]); g_st(&ta->ml[i], S.ml[i]); }
                     for (int i = lane; i < 256; i += 64) g_st(&ta->of[i], S.of[i]);
                 }
-                if (huf_new) for (int i = lane; i < 1024; i += 64) g_st(&reinterpret_cast<uint32_t*>(ta->huf)[i], reinterpret_cast<const uint32_t*>(S.huf)[i]);
+                if (huf_new) for (int i = lane; i < (int)kHufWords; i += 64) g_st(&reinterpret_cast<uint32_t*>(ta->huf)[i], reinterpret_cast<const uint32_t*>(S.huf)[i]);
                 if (lane == 0) {
                     if (fse_new) { g_st(&fs->al[0], c.al[0]); g_st(&fs->al[1], c.al[1]); g_st(&fs->al[2], c.al[2]); g_st(&fs->fse_valid, 1u); }
                     else if (b.frame_first) g_st(&fs->fse_valid, 0u);
@@ -221,7 +221,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
                 if (!r.wait_tables()) hr = MZD_E_DEVICE;
                 else if (!g_ld(&fs->huf_valid)) hr = MZD_E_CORRUPT;
                 else {
-                    for (int i = lane; i < 1024; i += 64) reinterpret_cast<uint32_t*>(S.huf)[i] = g_ld(&reinterpret_cast<const uint32_t*>(ta->huf)[i]);
+                    for (int i = lane; i < (int)kHufWords; i += 64) reinterpret_cast<uint32_t*>(S.huf)[i] = g_ld(&reinterpret_cast<const uint32_t*>(ta->huf)[i]);
                     if (lane == 0) c.huf_log = g_ld(&fs->huf_log);
                 }
             }

@@ -254,7 +254,7 @@ __device__ __noinline__ int finish_huf_table_wave(int lane) {
     const uint32_t total = __builtin_amdgcn_readlane(wave_incl_scan(tot, lane), 63);
     if (total == 0) return MZD_E_CORRUPT;
     const uint32_t maxbits = (uint32_t)hibit(total) + 1;
-    if (maxbits > 11) return MZD_E_CORRUPT;
+    if (maxbits > 12) return MZD_E_CORRUPT; // (libzstd's limit, HUF_TABLELOG_MAX; the format's text says 11)
     const uint32_t left = (1u << maxbits) - total;
     if (left & (left - 1)) return MZD_E_CORRUPT;
     const uint32_t wl = (uint32_t)hibit(left) + 1;
@@ -275,20 +275,26 @@ __device__ __noinline__ int finish_huf_table_wave(int lane) {
         p2 += cnt_r << (r - 1);
     }
     if (p2 != (1u << maxbits)) return MZD_E_CORRUPT; // also catches weights above maxbits
+    // A tree of depth 12 fills the 2 048 entries as pairs of neighbouring codes (mzd_device.h: kHufEntries): every position and count
+    // below is halved, and two codes of length 12 that share an entry put the odd one's symbol behind the table.  (A class starts at a
+    // multiple of its symbols' share: the classes behind it are multiples of it and so is their total, a power of two.)
+    const uint32_t sh = maxbits == 12 ? 1u : 0u;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const uint32_t sym = (uint32_t)g * 64 + (uint32_t)lane;
-        const uint32_t cnt = w[g] ? 1u << (w[g] - 1) : 0u;
+        const uint32_t cnt1 = w[g] ? 1u << (w[g] - 1) : 0u;
+        const uint32_t cnt = cnt1 >> sh, a2 = at[g] >> sh;
         const uint32_t e = sym | ((maxbits + 1 - w[g]) << 8);
-        if (cnt == 1) S.huf[at[g]] = (uint16_t)e;
+        if (sh && cnt1 == 1) { if (at[g] & 1) reinterpret_cast<uint8_t*>(&S.huf[2048])[a2] = (uint8_t)sym; else S.huf[a2] = (uint16_t)e; }
+        else if (cnt == 1) S.huf[a2] = (uint16_t)e;
         else if (cnt && cnt < 64) { // aligned to cnt (>= 2): pairs
-            uint32_t* q = reinterpret_cast<uint32_t*>(&S.huf[at[g]]);
+            uint32_t* q = reinterpret_cast<uint32_t*>(&S.huf[a2]);
             for (uint32_t i = 0; i < cnt / 2; i++) q[i] = e | (e << 16);
         }
         uint64_t big = __ballot(cnt >= 64); // few symbols own most of the table: all 64 lanes fill those together
         while (big) {
             const int src = __builtin_ctzll(big);
-            const uint32_t a0 = __builtin_amdgcn_readlane(at[g], src), c0 = __builtin_amdgcn_readlane(cnt, src), e0 = __builtin_amdgcn_readlane(e, src);
+            const uint32_t a0 = __builtin_amdgcn_readlane(a2, src), c0 = __builtin_amdgcn_readlane(cnt, src), e0 = __builtin_amdgcn_readlane(e, src);
             uint32_t* q = reinterpret_cast<uint32_t*>(&S.huf[a0]);
             for (uint32_t i = (uint32_t)lane; i < c0 / 2; i += 64) q[i] = e0 | (e0 << 16);
             big &= big - 1;

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs) {
                         for (int i = tid; i < 512; i += kWG) { S.ll[i] = dd->ll[i]; S.ml[i] = dd->ml[i]; }
                         for (int i = tid; i < 256; i += kWG) S.of[i] = dd->of[i];
                     }
-                    if (!have_huf) for (int i = tid; i < 2048; i += kWG) S.huf[i] = dd->huf[i];
+                    if (!have_huf) for (int i = tid; i < (int)kHufEntries; i += kWG) S.huf[i] = dd->huf[i];
                     if (tid == 0) {
                         c.lds_dict_fse = job_dict; c.lds_dict_huf = job_dict;
                         // (a prepared first block has its sequence header parsed already: only repeat-mode tables take the dictionary's log)
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                 if (dd->formatted) {
                     for (int i = tid; i < 512; i += kWG) { S.ll[i] = dd->ll[i]; S.ml[i] = dd->ml[i]; }
                     for (int i = tid; i < 256; i += kWG) S.of[i] = dd->of[i];
-                    for (int i = tid; i < 2048; i += kWG) S.huf[i] = dd->huf[i];
+                    for (int i = tid; i < (int)kHufEntries; i += kWG) S.huf[i] = dd->huf[i];
                     if (tid == 0) {
                         c.al[0] = dd->al[0]; c.al[1] = dd->al[1]; c.al[2] = dd->al[2];
                         c.huf_log = dd->huf_log; c.huf_valid = 1; c.fse_valid = 1;
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                             for (int i = tid; i < 512; i += kWG) { g_st(&ta->ll[i], S.ll[i]); g_st(&ta->ml[i], S.ml[i]); }
                             for (int i = tid; i < 256; i += kWG) g_st(&ta->of[i], S.of[i]);
                         }
-                        if (hv) for (int i = tid; i < 1024; i += kWG) g_st(&reinterpret_cast<uint32_t*>(ta->huf)[i], reinterpret_cast<const uint32_t*>(S.huf)[i]);
+                        if (hv) for (int i = tid; i < (int)kHufWords; i += kWG) g_st(&reinterpret_cast<uint32_t*>(ta->huf)[i], reinterpret_cast<const uint32_t*>(S.huf)[i]);
                         if (tid == 0) {
                             g_st(&fs->fse_valid, fv); g_st(&fs->huf_valid, hv); g_st(&fs->huf_log, c.huf_log);
                             g_st(&fs->al[0], c.al[0]); g_st(&fs->al[1], c.al[1]); g_st(&fs->al[2], c.al[2]);
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(kWG) void mzd_dict_kernel(const uint8_t* dict, uint
     __syncthreads();
     for (int i = tid; i < 512; i += kWG) { out->ll[i] = S.ll[i]; out->ml[i] = S.ml[i]; }
     for (int i = tid; i < 256; i += kWG) out->of[i] = S.of[i];
-    for (int i = tid; i < 2048; i += kWG) out->huf[i] = S.huf[i];
+    for (int i = tid; i < (int)kHufEntries; i += kWG) out->huf[i] = S.huf[i];
     if (tid == 0) {
         const uint8_t* p = dict + pos_after_tables;
         uint32_t content = n - pos_after_tables - 12;

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
                         if (tl > rem || (hb < 128 && hb < 1)) break;
                         tree_off = p_off; tree_len = tl;
                         p_off += tl; rem -= tl;
-                    } else if (!(with_d && di.formatted)) break; // treeless without a table to reuse
+                    } else if (!(with_d && di.formatted) || di.huf_log > 11) break; // treeless without a table to reuse (a dictionary's tree of depth 12 -- libzstd takes one, no encoder makes one -- lives in the general path's pair table)
                     if (streams == 1) { s_base = p_off; s_len0 = rem; if (rem == 0) break; }
                     else {
                         if (rem < 10) break;

@@ -198,6 +198,47 @@ def hand_direct_weights():
     return out_frames
 
 
+def hand_huffman_depth(maxbits, streams, nlit, seed=5, treeless_second=0):
+    """A Huffman tree of depth `maxbits` given as direct weights 1, 1, 2, 3, ..., maxbits (the sum of 2^(w-1) is 2^maxbits; the last
+    weight is implied), literals drawn mostly from the short codes but with every symbol present, nbSeq = 0.  Depth 12 is libzstd's
+    limit (HUF_TABLELOG_MAX: 1.4.8 and 1.5.7 decode these frames), depth 13 is refused.  treeless_second: a second block of that many
+    literals whose literals section reuses the first block's tree (Treeless_Literals_Block)."""
+    import random
+    ws = [1, 1] + list(range(2, maxbits + 1))
+    nsym = len(ws)
+    order = sorted(range(nsym), key=lambda s: (ws[s], s))
+    pos, code = 0, {}
+    for s in order:  # canonical: weight 1 (the longest codes) first, symbols ascending within a weight
+        w = ws[s]
+        code[s] = format(pos >> (w - 1), "0%db" % (maxbits + 1 - w))
+        pos += 1 << (w - 1)
+    assert pos == 1 << maxbits
+    rnd = random.Random(seed)
+    pop = [nsym - 1] * 40 + [nsym - 2] * 20 + [nsym - 3] * 10 + list(range(nsym)) * 2
+    ex = ws[:-1] + ([0] if (len(ws) - 1) % 2 else [])
+    tree = bytes([127 + len(ws) - 1]) + bytes((ex[i] << 4) | ex[i + 1] for i in range(0, len(ex), 2))
+
+    def section(lit, ltype, with_tree):
+        n = len(lit)
+        if streams == 1:
+            comp = (tree if with_tree else b"") + backward_stream("".join(code[c] for c in lit))
+            return (ltype | (0 << 2) | (n << 4) | (len(comp) << 14)).to_bytes(3, "little") + comp
+        seg = (n + 3) // 4
+        ss = [backward_stream("".join(code[c] for c in lit[k * seg:(k + 1) * seg if k < 3 else n])) for k in range(4)]
+        comp = (tree if with_tree else b"") + b"".join(len(x).to_bytes(2, "little") for x in ss[:3]) + b"".join(ss)
+        if n < 16384 and len(comp) < 16384:
+            return (ltype | (2 << 2) | (n << 4) | (len(comp) << 18)).to_bytes(4, "little") + comp
+        return (ltype | (3 << 2) | (n << 4) | (len(comp) << 22)).to_bytes(5, "little") + comp
+
+    lit = bytes(rnd.choice(pop) for _ in range(nlit))
+    body = section(lit, 2, True) + nbseq_bytes(0)
+    if not treeless_second:
+        return frame(block_header(1, 2, len(body)) + body, lit), lit
+    lit2 = bytes(rnd.choice(pop) for _ in range(treeless_second))
+    body2 = section(lit2, 3, False) + nbseq_bytes(0)
+    return frame(block_header(0, 2, len(body)) + body + block_header(1, 2, len(body2)) + body2, lit + lit2), lit + lit2
+
+
 def main():
     assert Z.available(), "make_golden.py needs a libzstd shared object"
     manifest["libzstd"] = Z.version()
@@ -244,6 +285,12 @@ def main():
     add("hand_long_nbseq", f, out, note="nbSeq >= 0x7F00 (3-byte form), raw block as history")
     for (f, out), nm in zip(hand_direct_weights(), ("hand_direct_weights_1s", "hand_direct_weights_4s")):
         add(nm, f, out, note="Huffman tree as direct 4-bit weights")
+
+    # a Huffman tree of depth 12: libzstd's own limit (accepted by 1.4.8 here and by 1.5.x: tests/test_oracle.py), one past the format text's 11
+    for nm, (streams, nlit, tl) in (("hand_huf12_1s", (1, 300, 0)), ("hand_huf12_4s", (4, 1021, 0)), ("hand_huf12_4s_60k", (4, 60000, 0)),
+                                    ("hand_huf12_treeless", (4, 5000, 3000)), ("hand_huf11_4s_60k", (4, 60000, 0))):
+        f, out = hand_huffman_depth(11 if "huf11" in nm else 12, streams, nlit, treeless_second=tl)
+        add(nm, f, out, note="Huffman tree of depth %d as direct weights%s" % (11 if "huf11" in nm else 12, "; second block treeless" if tl else ""))
 
     # ---------------------------------------------------------------- 4. container features
     a = corpus.gen("json", 4, 1, 5000); b = corpus.gen("text", 4, 2, 70000)
@@ -293,6 +340,9 @@ def main():
     add("bad_seq_modes_reserved", frame(block_header(1, 2, len(body)) + body, b"ab" + b"x" * 3, checksum=False), expect="error")
     body = lit_header_raw_rle(0, 2) + b"ab" + nbseq_bytes(1) + bytes([(3 << 6)]) + backward_stream("0" * 11)
     add("bad_repeat_without_table", frame(block_header(1, 2, len(body)) + body, b"ab" + b"x" * 3, checksum=False), expect="error")
+
+    f13, _ = hand_huffman_depth(13, 4, 1021)
+    add("bad_huf13", f13, expect="error", note="Huffman tree of depth 13: past libzstd's HUF_TABLELOG_MAX")
 
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
