@@ -23,6 +23,9 @@ struct Ctl {
     uint32_t lit_is_raw;
     uint32_t huf_tree_off, huf_tree_len;           // Huffman tree description inside the block
     uint32_t huf_ready, huf_fill, lit_done, walk_prog; // intra-workgroup flags of the block pipeline
+    uint32_t walk_inexact; // the walk ended without having consumed the sequence bitstream exactly: an error, but one that is found BEHIND the
+                           // block's sequences -- the reference executes sequence after sequence and checks the stream's end last, so an
+                           // execution error (destination too small, literals, offset) of any sequence is reported first (libzstd >= 1.5.4)
     uint32_t next_stream, streams_done, streams_mask; // Huffman streams are handed out to whichever wavefront is free; mask: bit k = stream k decoded
     uint32_t tables_ready, plan_prog, copy_prog, plan_lit_used; // walker -> planner -> copier
     uint32_t walk_g0;                               // (read head - 32) of the block's first walk record: records carry 16 bits of it

@@ -443,14 +443,15 @@ __device__ __noinline__ int chunk_verdict(const uint4* plan, uint32_t base, int 
     uint32_t off = pe.z;
     if (off & kOffTag) off = (uint32_t)sel3((off >> 29) & 3, (int32_t)rep0, (int32_t)rep1, (int32_t)rep2) + (off & 0x1FFFFFFFu) - (uint32_t)kOffBias; // (as in copy_wave)
     const uint32_t ll = pe.x, ml = pe.y, ex_t = pe.w, incl_t = ex_t + ll + ml;
-    // per sequence the reference checks: literals left (lit_room: literals not yet used at the chunk's start), destination's
-    // end, block limit, offset -- "destination too small" only if nothing before it in that order is wrong
+    // per sequence the reference checks (ZSTD_execSequenceEnd): the destination's end, literals left (lit_room: literals not yet used at
+    // the chunk's start), then -- ours -- the block limit, then the offset: "destination too small" when the earliest offending sequence
+    // has that wrong, whatever else is wrong with it
     const uint64_t nolit = __ballot(valid && wave_incl_scan(ll, lane) > lit_room);
     const uint64_t over = __ballot(valid && incl_t > room);
     const uint64_t bad = __ballot(valid && (incl_t > blk_room || off == 0 || off > hist + ex_t + ll));
     const int fl = nolit ? __builtin_ctzll(nolit) : 64, fo = over ? __builtin_ctzll(over) : 64, fb = bad ? __builtin_ctzll(bad) : 64;
     // (none of the three: the plan ended here without a sequence of this chunk being at fault, which cannot happen; corrupt)
-    return exec_verdict(fo < fl && fo <= fb ? MZD_E_DSTSIZE : MZD_E_CORRUPT, nseq, lit_streams);
+    return exec_verdict(fo <= fl && fo <= fb ? MZD_E_DSTSIZE : MZD_E_CORRUPT, nseq, lit_streams);
 }
 
 __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint64_t* opos_io, int lane) {
@@ -737,6 +738,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         if (it == (1u << 24)) post_err(&S.c.err, MZD_E_DEVICE);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (flag_load_u((const uint32_t*)&S.c.err)) return MZD_E_CORRUPT;
+        if (flag_load_u(&S.c.walk_inexact)) return MZD_E_CORRUPT; // every sequence executed, the bitstream not consumed exactly (the planner has finished, so the walker has)
         if (flag_load_u(&S.c.plan_too_long) == 2) // only the literals after the last sequence pass the block limit: the destination's end comes first
             return exec_verdict(cap - *opos_io <= kBlockMax ? MZD_E_DSTSIZE : MZD_E_CORRUPT, nseq, lit_streams);
         if (lpos != flag_load_u(&S.c.plan_lit_used)) return MZD_E_CORRUPT;

@@ -83,6 +83,7 @@ __device__ __noinline__ void parse_literals(Ctl& c, const uint8_t* b, uint32_t n
         return;
     }
     if (n < 3) { c.err = MZD_E_CORRUPT; return; }
+    if (type == 3 && !c.huf_valid) { c.err = MZD_E_DICT; return; } // treeless literals without a tree: libzstd's dictionary_corrupted, found before the section's sizes are looked at
     if (sf == 0 || sf == 1) { hs = 3; uint32_t v = ld24(b); regen = (v >> 4) & 0x3FF; comp = v >> 14; streams = sf ? 4 : 1; }
     else if (sf == 2) { if (n < 4) { c.err = MZD_E_CORRUPT; return; } hs = 4; uint32_t v = ld32(b); regen = (v >> 4) & 0x3FFF; comp = v >> 18; streams = 4; }
     else { if (n < 5) { c.err = MZD_E_CORRUPT; return; } hs = 5; uint64_t v = (uint64_t)ld32(b) | ((uint64_t)b[4] << 32); regen = (uint32_t)(v >> 4) & 0x3FFFF; comp = (uint32_t)(v >> 22); streams = 4; }
@@ -96,7 +97,7 @@ __device__ __noinline__ void parse_literals(Ctl& c, const uint8_t* b, uint32_t n
         if (tl > rem) { c.err = MZD_E_CORRUPT; return; }
         c.huf_tree_off = (uint32_t)(p - b); c.huf_tree_len = tl;
         p += tl; rem -= tl;
-    } else if (!c.huf_valid) { c.err = MZD_E_CORRUPT; return; }
+    }
     uint32_t base = (uint32_t)(p - b); // offset of the streams inside the block
     if (streams == 1) {
         c.s_off[0] = base; c.s_len[0] = rem; c.s_out[0] = 0; c.s_n[0] = regen;

@@ -117,6 +117,7 @@ __device__ __noinline__ void role_walk(BlockRun<TASKS> r) {
             rc = walk_sequences_wave(b.src + r.seq_off, r.seq_len, r.nseq, b.walk, &c.walk_prog, lane);
             __builtin_amdgcn_s_setprio(0);
         }
+        if (rc == kWalkInexact) { rc = 0; if (lane == 0) c.walk_inexact = 1; } // (every record is there: the planner and the copier go on; the copier gives the verdict)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) {
             post_err(&c.err, rc);
@@ -219,7 +220,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
             } else if (!frame_first) { // treeless: the table of the previous compressed-literals block
                 FileState* const fs = b.fs; TableArea* const ta = b.ta;
                 if (!r.wait_tables()) hr = MZD_E_DEVICE;
-                else if (!g_ld(&fs->huf_valid)) hr = MZD_E_CORRUPT;
+                else if (!g_ld(&fs->huf_valid)) hr = MZD_E_DICT; // (treeless literals without a tree: libzstd's dictionary_corrupted)
                 else {
                     for (int i = lane; i < (int)kHufWords; i += 64) reinterpret_cast<uint32_t*>(S.huf)[i] = g_ld(&reinterpret_cast<const uint32_t*>(ta->huf)[i]);
                     if (lane == 0) c.huf_log = g_ld(&fs->huf_log);
@@ -345,7 +346,7 @@ __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const Bloc
         __syncthreads();
     }
     if (tid == 0) {
-        c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.exec_done = 0; c.exec_pos = TASKS ? 0 : b.out0;
+        c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.walk_inexact = 0; c.exec_done = 0; c.exec_pos = TASKS ? 0 : b.out0;
         c.next_stream = 0; c.streams_done = 0; c.streams_mask = 0;
         c.tables_ready = 0; c.plan_prog = 0; c.copy_prog = 0; c.plan_lit_used = 0; c.plan_too_long = 0; c.seq_parsed = 0;
         S.res[0] = 0; S.res[1] = 0; S.res_nsym = 0;

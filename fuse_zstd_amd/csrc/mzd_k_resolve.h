@@ -102,7 +102,7 @@ __device__ __noinline__ void resolve_build_follow(uint32_t* map, const uint4* pl
         for (uint32_t it = 0; it < (1u << 24); it++) { // chunk `chunk` is public once the planner has started on chunk + 1 (or has finished)
             const uint32_t pg = flag_load(&S.c.plan_prog);
             if ((pg & ~kPlanFin) > chunk) { have = true; break; }
-            if (pg & kPlanFin) { have = (pg & ~kPlanFin) > chunk && !__atomic_load_n(&S.c.err, __ATOMIC_RELAXED) && !__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED); break; }
+            if (pg & kPlanFin) { have = (pg & ~kPlanFin) > chunk && !__atomic_load_n(&S.c.err, __ATOMIC_RELAXED) && !__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED) && !__atomic_load_n(&S.c.walk_inexact, __ATOMIC_RELAXED); break; }
             if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) break;
             __builtin_amdgcn_s_sleep(8);
         }

@@ -58,6 +58,7 @@ __device__ __forceinline__ uint64_t ring_read64(uint32_t e) {
 
 
 constexpr uint32_t kWalkFin = 0x80000000u;
+constexpr int kWalkInexact = 1; // walk_sequences_wave: every sequence walked, the bitstream not consumed exactly (Ctl::walk_inexact)
 constexpr uint32_t kNoJob = 0xFFFFFFFFu;
 constexpr uint32_t kDoneJob = 0xFFFFFFFEu; // the queue is empty
 #ifndef MZD_PRE_PRIO
@@ -314,7 +315,8 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         __builtin_memcpy(&eO, tO + vO, 8);
         *(__attribute__((address_space(1))) uint64_t*)(gwalk + woff) = walk_record(vL, vM, vO, G - 32);
         uint32_t extra = (uint32_t)(eL >> 56) + (uint32_t)(eM >> 56) + (uint32_t)(eO >> 56);
-        if (G - Gzero != extra) return MZD_E_CORRUPT; // the bitstream must be consumed exactly
+        if (G - Gzero < extra) return MZD_E_CORRUPT;  // the last sequence's fields reach below the stream's start: over-read, as above
+        if (G - Gzero != extra) return kWalkInexact; // the bitstream must be consumed exactly: found last (Ctl::walk_inexact)
     }
     return 0; // the caller publishes nseq | kWalkFin after a release fence
 }

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs) {
                     // (the block's arguments live in LDS: the roles take them by reference, and on the stack they would be a copy per lane)
                     if (tid == 0) { S.ba = BlockArgs{src, n, dst, cap, dst2, src + pos0, bsize, pos0, out0, lit_buf, seqs, walk, last, hashing, block_pre, 0u, false, true, nullptr, nullptr, j, &a}; }
                     __syncthreads();
-                    if (!compressed_block<false>(a, S.ba, xv, xstripes, mirrored, tid, lane, wave)) break;
+                    if (!compressed_block<false>(a, S.ba, xv, xstripes, mirrored, tid, lane, wave)) { WG_SNAPSHOT(err = c.err); break; } // (an error of the block's headers: the class it posted stands)
                 }
                 if (btype == 2) { // the block's repeat-offset transform (the planner leaves it symbolic) -> the offsets after it
                     __syncthreads();
@@ -565,13 +565,13 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                 TFIN(7); // (diagnostic builds: the resolve timeline reuses the literal-side slots 7, 8, 4 and the copier's 9, 1, 2)
                 // (the planning wavefront has passed the repeat-offset chain on: S.res_rep, S.res[3]; the copying and the hashing wavefront
                 //  have built the map behind the planner, but for the chunks with symbolic offsets: S.res_sym)
-                uint32_t nseq = 0, nlit = 0, pout = 0, lused = 0, too_long = 0, lit_type = 0, r0 = 0, r1 = 0, r2 = 0, hop_ok = 0;
+                uint32_t nseq = 0, nlit = 0, pout = 0, lused = 0, too_long = 0, lit_type = 0, r0 = 0, r1 = 0, r2 = 0, hop_ok = 0, inexact = 0;
                 uint64_t lit_off = 0;
                 WG_SNAPSHOT(err = c.err; nseq = c.nseq; nlit = c.nlit; pout = c.plan_out; lused = c.plan_lit_used; too_long = c.plan_too_long; lit_type = c.lit_type;
-                            lit_off = c.lit_off; r0 = S.res_rep[0]; r1 = S.res_rep[1]; r2 = S.res_rep[2]; hop_ok = S.res[3]);
+                            lit_off = c.lit_off; r0 = S.res_rep[0]; r1 = S.res_rep[1]; r2 = S.res_rep[2]; hop_ok = S.res[3]; inexact = c.walk_inexact);
                 uint32_t* const map = a.resolve_map + (size_t)slot * kResMapStride;
                 const uint32_t B = pout + (nlit - lused);
-                bool ok = !err && hop_ok && nseq != 0 && !too_long && lused <= nlit && B <= kBlockMax;
+                bool ok = !err && !inexact && hop_ok && nseq != 0 && !too_long && lused <= nlit && B <= kBlockMax; // (anything wrong: the copying wavefront gives the verdict, in the reference's order)
                 if (ok) {
                     resolve_build_rest(map, seqs, walk, nseq, pout, lused, nlit, r0, r1, r2, a.debug ? seqs : nullptr, lane, wave);
                     wg_fence();

@@ -65,6 +65,7 @@ def lib():
         L.ozs_content_size.argtypes = [C.c_char_p, C.c_size_t]
         L.ozs_xxh64.restype = C.c_uint64
         L.ozs_xxh64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
+        L.ozs_last_verdict_unpinned.restype = C.c_int
         L.ozs_strerror.restype = C.c_char_p
         L.ozs_strerror.argtypes = [C.c_int]
         _lib = L
@@ -103,6 +104,12 @@ def decode(src, cap=None, dictionary=None, want_trace=False, dump=False):
             return rc, out, blocks, blocks_extra
         return rc, out, blocks
     return rc, out
+
+
+def last_verdict_unpinned():
+    """The last decode() rejected its input because a sequence bitstream ran out inside a block: libzstd rejects it too, with the
+    class its bit container's leftovers lead to (zstd_oracle.h)."""
+    return bool(lib().ozs_last_verdict_unpinned())
 
 
 def content_size(src):

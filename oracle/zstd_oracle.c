@@ -299,6 +299,7 @@ static int decode_literals(dctx* d, scratch* sc, const uint8_t* src, size_t n, u
         else { CHECK(hs + 1 <= n, OZS_E_CORRUPT); memset(sc->lit, src[hs], regen); *consumed = hs + 1; }
     } else {
         CHECK(n >= 3, OZS_E_CORRUPT);
+        if (type == 3) CHECK(d->huf_valid, OZS_E_DICT); /* libzstd: dictionary_corrupted (ZSTD_decodeLiteralsBlock, litEntropy == 0), before the sizes */
         if (sf == 0 || sf == 1) { hs = 3; uint32_t v = rd24(src); regen = (v >> 4) & 0x3FF; comp = v >> 14; streams = sf ? 4 : 1; }
         else if (sf == 2) { CHECK(n >= 4, OZS_E_CORRUPT); hs = 4; uint32_t v = rd32(src); regen = (v >> 4) & 0x3FFF; comp = v >> 18; streams = 4; }
         else { CHECK(n >= 5, OZS_E_CORRUPT); hs = 5; uint64_t v = (uint64_t)rd32(src) | ((uint64_t)src[4] << 32); regen = (uint32_t)(v >> 4) & 0x3FFFF; comp = (uint32_t)(v >> 22); streams = 4; }
@@ -312,7 +313,7 @@ static int decode_literals(dctx* d, scratch* sc, const uint8_t* src, size_t n, u
             CHECK(used > 0, OZS_E_CORRUPT);
             d->huf_valid = 1; p += used; rem -= (size_t)used;
         } else {
-            CHECK(d->huf_valid, OZS_E_CORRUPT);
+            CHECK(d->huf_valid, OZS_E_DICT);
         }
         if (streams == 1) {
             int rc = huf_decode_stream(&d->huf, p, rem, sc->lit, regen);
@@ -356,7 +357,14 @@ static int seq_table(fse_tab* t, int mode, const uint8_t* p, size_t n, int max_l
 }
 
 /* K4: sequences section -> resolved (ll, ml, off) triples */
-static int decode_sequences(dctx* d, scratch* sc, const uint8_t* src, size_t n, uint32_t* nseq_out, ozs_block_info* bi) {
+/* libzstd decodes and executes sequence after sequence (ZSTD_decompressSequences_body): an execution error of sequence i is
+ * reported before anything the bitstream does wrong behind it, and that the bitstream was not consumed exactly is found last.
+ * So this function gives no verdict on the bitstream: *valid_out = the sequences decoded before the first field that reaches
+ * below the stream's start (from there on libzstd decodes whatever its bit container holds: not a property of the format),
+ * *stream_bad = the stream was over-read or not consumed exactly.  execute_sequences() turns that into the verdict. */
+static int g_unpinned; /* the last verdict came from "the bitstream was over-read before the block's sequences were executed" */
+int ozs_last_verdict_unpinned(void) { return g_unpinned; }
+static int decode_sequences(dctx* d, scratch* sc, const uint8_t* src, size_t n, uint32_t* nseq_out, uint32_t* valid_out, int* stream_bad, ozs_block_info* bi) {
     CHECK(n >= 1, OZS_E_CORRUPT);
     const uint8_t* p = src; const uint8_t* end = src + n;
     uint32_t nseq = *p++;
@@ -364,7 +372,7 @@ static int decode_sequences(dctx* d, scratch* sc, const uint8_t* src, size_t n, 
         if (nseq == 0xFF) { CHECK(p + 2 <= end, OZS_E_CORRUPT); nseq = rd16(p) + 0x7F00; p += 2; }
         else { CHECK(p + 1 <= end, OZS_E_CORRUPT); nseq = ((nseq - 0x80) << 8) + *p++; }
     }
-    *nseq_out = nseq;
+    *nseq_out = nseq; *valid_out = nseq; *stream_bad = 0;
     if (nseq == 0) { CHECK(p == end, OZS_E_CORRUPT); return 0; }
     CHECK(nseq <= OZS_MAX_SEQ, OZS_E_CORRUPT);
     CHECK(p + 1 <= end, OZS_E_CORRUPT);
@@ -382,7 +390,7 @@ static int decode_sequences(dctx* d, scratch* sc, const uint8_t* src, size_t n, 
 #endif
     bbr b; CHECK(bbr_init(&b, p, (size_t)(end - p)) == 0, OZS_E_CORRUPT);
     uint32_t sll = bbr_read(&b, d->ll.log), sof = bbr_read(&b, d->of.log), sml = bbr_read(&b, d->ml.log);
-    CHECK(b.pos >= 0, OZS_E_CORRUPT);
+    if (b.pos < 0) { *valid_out = 0; *stream_bad = 1; return 0; } /* (shorter than the three initial states) */
     uint32_t rep0 = d->rep[0], rep1 = d->rep[1], rep2 = d->rep[2];
     for (uint32_t i = 0; i < nseq; i++) {
         fse_ent el = d->ll.e[sll], eo = d->of.e[sof], em = d->ml.e[sml];
@@ -397,7 +405,8 @@ static int decode_sequences(dctx* d, scratch* sc, const uint8_t* src, size_t n, 
             if (idx == 0) off = rep0;
             else if (idx == 1) { off = rep1; rep1 = rep0; rep0 = off; }
             else if (idx == 2) { off = rep2; rep2 = rep1; rep1 = rep0; rep0 = off; }
-            else { off = rep0 - 1; CHECK(off != 0, OZS_E_CORRUPT); rep2 = rep1; rep1 = rep0; rep0 = off; }
+            else { off = rep0 - 1; if (off == 0) off = 0xFFFFFFFFu; /* libzstd 1.5: "0 is not valid: force offset to -1 => corruption detected at execSequence" */
+                   rep2 = rep1; rep1 = rep0; rep0 = off; }
         }
         sc->seq[i].ll = ll; sc->seq[i].ml = ml; sc->seq[i].off = off;
         if (i + 1 < nseq) {
@@ -405,23 +414,28 @@ static int decode_sequences(dctx* d, scratch* sc, const uint8_t* src, size_t n, 
             sml = em.base + bbr_read(&b, em.nb);
             sof = eo.base + bbr_read(&b, eo.nb);
         }
-        CHECK(b.pos >= 0, OZS_E_CORRUPT);
+        if (b.pos < 0) { *valid_out = i; *stream_bad = 1; return 0; } /* (sequence i itself took bits from below the start) */
     }
-    CHECK(b.pos == 0, OZS_E_CORRUPT);
+    if (b.pos != 0) *stream_bad = 1;
     d->rep[0] = rep0; d->rep[1] = rep1; d->rep[2] = rep2;
     return 0;
 }
 
 /* K5: execute.  frame_start..op is this frame's output so far; the dictionary content sits
  * logically just before frame_start. */
-static int execute_sequences(const dctx* d, const scratch* sc, uint32_t nlit, uint32_t nseq,
+static int execute_sequences(const dctx* d, const scratch* sc, uint32_t nlit, uint32_t nseq, uint32_t valid, int stream_bad,
                              uint8_t* frame_start, uint8_t** opp, uint8_t* oend) {
     uint8_t* op = *opp; const uint8_t* lit = sc->lit; uint32_t lpos = 0;
     uint8_t* block_start = op;
-    for (uint32_t i = 0; i < nseq; i++) {
+    g_unpinned = 0;
+    /* The bitstream ran out inside the block: libzstd goes on decoding whatever its bit container holds and rejects the block in the
+     * end, with the class its garbage leads to -- not a property of the format.  Rejected here at once (the GPU walker stops there too). */
+    if (valid < nseq) { g_unpinned = 1; return OZS_E_CORRUPT; }
+    for (uint32_t i = 0; i < valid; i++) {
         uint32_t ll = sc->seq[i].ll, ml = sc->seq[i].ml, off = sc->seq[i].off;
-        CHECK(ll <= nlit - lpos, OZS_E_CORRUPT);
+        /* the checks of ZSTD_execSequenceEnd, in its order: room in the destination, literals left, then the offset */
         CHECK((size_t)(oend - op) >= (size_t)ll + ml, OZS_E_DSTSIZE);
+        CHECK(ll <= nlit - lpos, OZS_E_CORRUPT);
         CHECK((size_t)(op - block_start) + ll + ml <= OZS_BLOCK_MAX, OZS_E_CORRUPT);
         memcpy(op, lit + lpos, ll); op += ll; lpos += ll;
         size_t have = (size_t)(op - frame_start);
@@ -434,6 +448,7 @@ static int execute_sequences(const dctx* d, const scratch* sc, uint32_t nlit, ui
         for (uint32_t k = 0; k < ml; k++) { op[k] = op[(ptrdiff_t)k - (ptrdiff_t)off]; }
         op += ml;
     }
+    CHECK(!stream_bad, OZS_E_CORRUPT);                          /* not consumed exactly: checked behind the loop (libzstd >= 1.5.4) */
     uint32_t rest = nlit - lpos;
     CHECK((size_t)(oend - op) >= rest, OZS_E_DSTSIZE);
     CHECK((size_t)(op - block_start) + rest <= OZS_BLOCK_MAX, OZS_E_CORRUPT);
@@ -544,10 +559,11 @@ static int decode_frame(const uint8_t* src, size_t n, size_t* consumed, uint8_t*
             rc = decode_literals(d, sc, ip, bsize, block_max, &lit_used, &nlit, &bi);
             if (rc) break;
             if (lit_used >= bsize) { rc = OZS_E_CORRUPT; break; } /* sequences section needs >= 1 byte */
-            rc = decode_sequences(d, sc, ip + lit_used, bsize - lit_used, &nseq, &bi);
+            uint32_t valid = 0; int stream_bad = 0;
+            rc = decode_sequences(d, sc, ip + lit_used, bsize - lit_used, &nseq, &valid, &stream_bad, &bi);
             if (rc) break;
             uint8_t* before = op;
-            rc = execute_sequences(d, sc, nlit, nseq, dst, &op, oend);
+            rc = execute_sequences(d, sc, nlit, nseq, valid, stream_bad, dst, &op, oend);
             if (rc) break;
             bi.n_lit = nlit; bi.n_seq = nseq; bi.regen = (uint32_t)(op - before);
             if (tr) {

@@ -103,6 +103,61 @@ def test_oracle_accept_reject_agrees_with_libzstd_on_mutations():
         assert not stricter, stricter[:10]
 
 
+# ZSTD_ErrorCode (zstd_errors.h; the values below are stable across 1.4 / 1.5) -> the error classes of oracle/ and include/mzd.h
+_LIBZSTD_CLASS = {10: oracle.E_BADMAGIC, 12: oracle.E_UNSUPPORTED, 14: oracle.E_UNSUPPORTED, 16: oracle.E_UNSUPPORTED, 20: oracle.E_CORRUPT,
+                  22: oracle.E_CHECKSUM, 30: oracle.E_DICT, 32: oracle.E_DICT, 70: oracle.E_DSTSIZE, 72: oracle.E_TRUNCATED}
+
+
+@needs_zstd
+def test_error_classes_are_libzstds():
+    """Which ERROR a rejected input gets is pinned by the reference's codec, not only by this repository: on the negative golden
+    vectors, on every single-byte mutation and every truncation of a small frame and on too-small destinations, the oracle's class
+    is the class of libzstd's own code (ZSTD_getErrorCode through oracle/libzstd_dl.c: checksum_wrong, dictionary_wrong /
+    dictionary_corrupted, dstSize_tooSmall, srcSize_wrong, corruption_detected, prefix_unknown, frameParameter_*) in the streaming
+    shape copy_decode uses (reference src/main.rs:463) or in the one-shot shape -- libzstd's two entry points name some errors
+    differently (a frame cut inside its checksum: srcSize_wrong / checksum_wrong).  Two kinds of input are exempt, both rejected by
+    everybody: (a) a sequence bitstream that runs out inside its block -- libzstd goes on decoding what its bit container holds, so
+    its class there is no property of the format (oracle.last_verdict_unpinned); (b) with a libzstd older than 1.5.4 on the machine,
+    inputs whose only fault is a bitstream not consumed exactly, which old decoders do not look at (they report what happens
+    next: a checksum failure)."""
+    Z = oracle.LibZstd
+    old_lib = tuple(int(x) for x in Z.version().split(".")[:3]) < (1, 5, 4)
+
+    def classes(comp, cap, dictionary=None):
+        one = Z.decompress(comp, cap, dictionary=dictionary)
+        st = Z.decompress(comp, cap, stream8k=True) if dictionary is None else one
+        return {(_LIBZSTD_CLASS.get(-x, x) if isinstance(x, int) else 0) for x in (one, st)}
+
+    for v in golden_util.load_manifest():
+        if v.ok:
+            continue
+        rc, _ = oracle.decode(v.comp, cap=1 << 22, dictionary=v.dict)
+        assert rc in classes(v.comp, 1 << 22, v.dict) or oracle.last_verdict_unpinned(), (v.name, rc)
+    raw = corpus.gen("json", 12, 1, 700)
+    comp = bytearray(Z.compress(raw, 3, True))
+    cases = [(bytes(comp[:cut]), 1 << 16) for cut in range(len(comp))] + [(bytes(comp), c) for c in (0, 1, 100, 699)]
+    for pos in range(len(comp)):
+        for flip in (0x01, 0x80, 0xFF):
+            m = bytearray(comp)
+            m[pos] ^= flip
+            cases.append((bytes(m), 1 << 16))
+    pinned = exempt_a = exempt_b = 0
+    for m, cap in cases:
+        rc, _ = oracle.decode(m, cap=cap)
+        want = classes(m, cap)
+        if rc == 0:
+            continue  # (accept / reject parity: test_oracle_accept_reject_agrees_with_libzstd_on_mutations)
+        if rc in want:
+            pinned += 1
+        elif oracle.last_verdict_unpinned():
+            exempt_a += 1
+        elif old_lib and rc == oracle.E_CORRUPT and want <= {0, oracle.E_CHECKSUM}:
+            exempt_b += 1
+        else:
+            raise AssertionError((len(m), cap, rc, want))
+    assert pinned > 1500 and exempt_a < 40 and exempt_b < 12, (pinned, exempt_a, exempt_b)
+
+
 _CHECK_157 = r"""
 import ctypes as C, glob, os, sys, sysconfig
 sys.path.insert(0, os.environ["MZD_ROOT"])
