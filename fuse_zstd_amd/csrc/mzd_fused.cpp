@@ -575,6 +575,7 @@ int usage() {
 } // namespace
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0); // before the first HIP call: the host path overlaps four kernel streams and two copy streams (include/mzd.h); the caller's own setting wins
     Options o;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];

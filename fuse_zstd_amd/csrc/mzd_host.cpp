@@ -170,8 +170,9 @@ int init_device(Device& d, int hip_id, int index, const InitCfg& cfg) {
     HIPCHK(hipMalloc(&d.walk_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
     HIPCHK(hipMalloc(&d.small_lit, d.small_lit_total));
     if (cfg.resolve_ahead) HIPCHK(hipMalloc(&d.resolve_map, (size_t)d.max_wg * kResMapStride * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&d.debug, (size_t)d.max_wg * sizeof(DebugSlot)));
-    HIPCHK(hipMemset(d.debug, 0, (size_t)d.max_wg * sizeof(DebugSlot)));
+    const size_t debug_bytes = std::max<size_t>((size_t)d.max_wg * sizeof(DebugSlot), 1032 * sizeof(uint64_t)); // (diagnostic builds of the small-file kernel keep 1 032 stamps there: mzd_debug_small_stamps)
+    HIPCHK(hipMalloc(&d.debug, debug_bytes));
+    HIPCHK(hipMemset(d.debug, 0, debug_bytes));
     HIPCHK(hipMalloc(&d.counters, 2 * (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
     HIPCHK(hipMemset(d.counters, 0, 2 * (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&d.d_dicts, sizeof(DevDict) * kMaxDicts));

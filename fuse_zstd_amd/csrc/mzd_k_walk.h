@@ -126,6 +126,7 @@ __device__ __forceinline__ void walk_run_asm(uint32_t& A, uint32_t& Gm, uint32_t
     static_assert(kRingBytes - 4 == 0x1ffc && offsetof(Shared, ring) == 0, "the window address mask / the ring's place are spelled out in MZD_WALK_STEP");
     static_assert(kWalkGroup == 8 && kWalkLag == 32 && kWalkLag >= kWalkGroup + 2, "spelled out below");
     uint32_t av, sa, sb;
+    uint64_t saved_exec;
     const uint64_t l3 = 0x8888888888888888ull; // lane 3 of every quad: its record dword is the read head
 // The lanes that run the loop: all 64 (16 quads doing the same work) when the wavefront has its SIMD to itself -- few active lanes
     // issue VALU work 2-4x slower there (tools/micro/exec_micro.hip) --, quad 0 alone when the launch fills the machine: with four
@@ -134,7 +135,7 @@ __device__ __forceinline__ void walk_run_asm(uint32_t& A, uint32_t& Gm, uint32_t
     const uint64_t lanes = gridDim.x > 512 ? 0xFull : ~0ull;
     asm volatile(
         "v_mov_b32_e32 v84, %[A]\n v_mov_b32_e32 v87, %[Gm]\n"
-        "s_mov_b64 exec, %[lanes]\n"
+        "s_and_saveexec_b64 %[ex], %[lanes]\n" // (the incoming mask is kept and put back: the loop runs on `lanes` of the lanes that were active)
         "v_lshrrev_b32_e32 v71, 3, v87\n"
         "ds_read_b64 v[48:49], v84\n"
         "v_and_b32_e32 v71, 0x1ffc, v71\n"
@@ -158,10 +159,10 @@ __device__ __forceinline__ void walk_run_asm(uint32_t& A, uint32_t& Gm, uint32_t
         "s_cbranch_scc1 1b\n"
         "2:\n"
         "s_waitcnt lgkmcnt(0)\n" // (the reads issued by the last step: nothing may be in flight into v[48:55] past this block)
-        "s_mov_b64 exec, -1\n"
+        "s_mov_b64 exec, %[ex]\n"
         "v_mov_b32_e32 %[A], v84\n v_mov_b32_e32 %[Gm], v87\n"
         : [A] "+v"(A), [Gm] "+v"(Gm), [woff] "+v"(woff), [slack] "+v"(slack), [av] "=&v"(av), [n] "+s"(n),
-          [pv] "+v"(pv), [s0] "=&v"(startA), [s3] "=&v"(startG), [sa] "=&v"(sa), [sb] "=&v"(sb)
+          [pv] "+v"(pv), [s0] "=&v"(startA), [s3] "=&v"(startG), [sa] "=&v"(sa), [sb] "=&v"(sb), [ex] "=&s"(saved_exec)
         : [base] "s"(gwalk), [thresh] "s"(thresh), [prog] "v"(prog_lds), [l3] "s"(l3), [lanes] "s"(lanes)
         : "v48", "v49", "v54", "v55", "v64", "v65", "v66", "v67", "v69", "v70", "v71", "v84", "v87", "vcc", "scc", "memory");
 }
