@@ -173,6 +173,7 @@ int launch_lds(const LdsArgs& a, uint32_t grid, int g, int xg, int with_dict, vo
 int lds_prepare_device();   // once per device, with that device current
 uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes);
 uint32_t lds_kernel_bytes_per_file(uint32_t tab_bytes, uint32_t comp_bytes);
+uint32_t lds_waves_by_registers(int g, int xg, int with_dict);
 size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap);
 uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes);
 

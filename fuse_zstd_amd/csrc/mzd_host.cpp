@@ -344,7 +344,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
             // 1 792 bytes (a 9-bit Huffman table, 224 FSE entries).
             auto waves_per_cu = [&](int g, int xg, uint32_t tab) -> uint32_t {
                 const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(g, xg, p.with_dict, tab, p.lds_comp, p.lds_out), kLdsGranule);
-                return lds > kLdsPerCu ? 0u : std::min<uint32_t>(8u, kLdsPerCu / lds); // (8: two wavefronts per SIMD, registers)
+                return lds > kLdsPerCu ? 0u : std::min<uint32_t>(lds_waves_by_registers(g, xg, p.with_dict), kLdsPerCu / lds);
             };
             auto split_plan = [&](uint32_t& tab) -> bool { // G = 8, XG = 4 in one round?
                 if (p.with_dict || cus == 0) return false;
@@ -434,7 +434,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         // one wavefront per workgroup; as many as the whole device holds, also for a launch on one of the host path's lanes: this
         // kernel uses none of the per-workgroup scratch the lanes divide, and a chunk of small files that gets a quarter of the wave
         // slots takes four rounds of groups where one would do (cfg4 host -> host: 1.5 -> ms)
-        const uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(8u, kLdsPerCu / lds)); // (8: two wavefronts per SIMD, registers)
+        const uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(lds_waves_by_registers(p.lds_g, p.lds_xg, p.with_dict), kLdsPerCu / lds));
         la.lit_stride = p.lit_stride; la.seq_cap = (p.lit_stride - 64) / 3 + 2;
         la.scratch = l.small_lit;
         if (&l == &d.whole) { d.last_lds_lit_stride = la.lit_stride; d.last_lds_seq_cap = la.seq_cap; }

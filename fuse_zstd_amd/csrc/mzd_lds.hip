@@ -365,7 +365,7 @@ struct DictInfo { // the dictionary whose image sits in LDS (wave-uniform)
 // 4 KiB (3.9 KB each) fit where only four windows (4.1 KB each) do, so five wavefronts per CU hold 40 files -- 10 240 on the
 // device -- instead of 32.  What an execution pass needs to know about a file crosses over in a 32-byte record in LDS.
 template <int G, bool DICT, int XG>
-__global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
+__global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(LdsArgs a) {
     constexpr uint32_t LPF = 64 / G; // lanes per file in the entropy phases
     constexpr uint32_t XLPF = 64 / XG, NX = G / XG; // lanes per file = sequences per plan step in the execution; passes
     static_assert(LPF >= 4, "four Huffman streams");
@@ -1387,6 +1387,8 @@ __global__ __launch_bounds__(64) void mzd_lds_kernel(LdsArgs a) {
 
 } // namespace lw
 
+// wavefronts a CU holds by the kernels' register budgets: three per SIMD for the plain G = 4 kernel (168 registers: __launch_bounds__), two for the others
+uint32_t lds_waves_by_registers(int g, int xg, int with_dict) { return (g == 4 && xg == 4 && !with_dict) ? 12u : 8u; }
 uint32_t lds_kernel_bytes_per_file(uint32_t tab_bytes, uint32_t comp_bytes) { return tab_bytes + lw::kAux + comp_bytes; } // a file's entropy image
 uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes) {
     const uint32_t ent = tab_bytes + lw::kAux + comp_bytes;
