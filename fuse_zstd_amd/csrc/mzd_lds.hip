@@ -76,6 +76,7 @@ DI void lds_s64(uint32_t off, uint64_t v) { __builtin_memcpy(lptr<uint8_t>(off),
 DI void lds_s32(uint32_t off, uint32_t v) { __builtin_memcpy(lptr<uint8_t>(off), &v, 4); }
 DI void lds_s16(uint32_t off, uint32_t v) { const uint16_t w = (uint16_t)v; __builtin_memcpy(lptr<uint8_t>(off), &w, 2); }
 DI void lds_xor32(uint32_t off, uint32_t v) { __hip_atomic_fetch_xor(lptr<uint32_t>(off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DI void lds_add32(uint32_t off, uint32_t v) { __hip_atomic_fetch_add(lptr<uint32_t>(off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DI void lds_or32(uint32_t off, uint32_t v) { __hip_atomic_fetch_or(lptr<uint32_t>(off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // The lanes of a wavefront talk through LDS without a barrier: a wavefront's LDS operations execute in issue order, so a
@@ -672,31 +673,32 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
             good = (uint32_t)__shfl((int)good, (int)(f * LPF));
             nw_l = (uint32_t)__shfl((int)nw_l, (int)(f * LPF));
             wsync();
-            // ---- validation, implied last weight, canonical table (A.4): the weight classes 1..12 on the file's lanes (class v on lane
-            // (v - 1) % LPF).  A class lane counts its symbols (eight weights per read, compared bytewise), the classes' sizes are
-            // scanned into start positions (weight 1 = longest codes first), and every lane fills the entries of its own symbols in
-            // ascending order -- no counter is read back from LDS.
+            // ---- validation, implied last weight, canonical table (A.4).  Lane = symbol, LPF consecutive symbols per round:
+            //   pass 1: a histogram of the weights (LDS adds: two 16-bit counters per word); the weight classes 1..12 then sit on the file's
+            //           lanes (class v on lane (v - 1) % LPF): total, table depth, the implied last weight, the classes' start positions
+            //           (weight 1 = longest codes first) -- which take the histogram's place as the classes' write heads;
+            //   pass 2: a symbol's entries start at its class's write head + (lower lanes of the round with the same weight) x its span
+            //           -- a lane mask per class, OR-ed together in LDS as in mzd_l_tables.h's numbering -- and the class's first lane
+            //           moves the head on.  Round 3 had a class lane walk all the weights for its symbols, one LDS round trip and a
+            //           divergent loop per symbol: 20 K cycles a group.
+            // Work memory: the file's share of the dump area (24 + 12 * LPF / 8 bytes of its 8 * LPF).
             if (good) {
                 constexpr uint32_t NCL = (12 + LPF - 1) / LPF;
-                const uint32_t words = (nw_l + 8) / 8; // (covers index nw: the implied last weight is appended below)
-                auto eqflags = [&](uint32_t word, uint32_t v) -> uint32_t { // 0x80 in every byte of `word` that equals v (all bytes < 0x80)
-                    const uint32_t x = word ^ (v * 0x01010101u);
-                    return ~((x | 0x80808080u) - 0x01010101u) & 0x80808080u;
-                };
-                uint32_t cnt[NCL];
+                const uint32_t hist = kShDump + 8 * LPF * f, hmask = hist + 24;
+                for (uint32_t o = 4 * sub; o < 48; o += 4 * LPF) L32(hist + o) = 0;
+                wsync();
                 uint32_t over = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < NCL; j++) cnt[j] = 0;
-                for (uint32_t wi = 0; wi < words; wi++) {
-                    const uint64_t W8 = L64(wts + 8 * wi);
-                    const uint32_t lo = (uint32_t)W8, hi = (uint32_t)(W8 >> 32);
-                    over |= ((lo + 0x73737373u) | (hi + 0x73737373u)) & 0x80808080u; // a weight above 12
-#pragma unroll
-                    for (uint32_t j = 0; j < NCL; j++) {
-                        const uint32_t v = sub + 1 + j * LPF;
-                        cnt[j] += (uint32_t)__builtin_popcount(eqflags(lo, v)) + (uint32_t)__builtin_popcount(eqflags(hi, v));
-                    }
+                for (uint32_t s0 = 0; s0 < nw_l; s0 += LPF) {
+                    const uint32_t s = s0 + sub;
+                    const uint32_t w = s < nw_l ? L8(wts + s) : 0u;
+                    over |= w > 12 ? 1u : 0u;
+                    if (w - 1 < 12) lds_add32(hist + 4 * ((w - 1) >> 1), 1u << (16 * ((w - 1) & 1)));
                 }
+                over = __ballot(over != 0) >> (f * LPF) & ((1ull << LPF) - 1) ? 1u : 0u; // a weight above 12 anywhere in the file
+                wsync();
+                uint32_t cnt[NCL];
+#pragma unroll
+                for (uint32_t j = 0; j < NCL; j++) { const uint32_t v = sub + 1 + j * LPF; cnt[j] = v <= 12 ? (L32(hist + 4 * ((v - 1) >> 1)) >> (16 * ((v - 1) & 1))) & 0xFFFF : 0u; }
                 uint32_t part = 0;
 #pragma unroll
                 for (uint32_t j = 0; j < NCL; j++) { const uint32_t v = sub + 1 + j * LPF; part += v <= 12 ? cnt[j] << (v - 1) : 0u; }
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                 const uint32_t total = bcast<LPF - 1, LPF>(tot);
                 bool g2 = over == 0 && total != 0;
                 const uint32_t maxbits = g2 ? (uint32_t)hibit32(total) + 1 : 1u;
-                g2 = g2 && maxbits <= 11 && (2u << maxbits) <= a.tab_bytes; // (a table that does not fit the slot: the general path takes the file)
+                g2 = g2 && maxbits <= 11 && (2u << maxbits) <= a.tab_bytes; // (a table that does not fit the slot, a tree of depth 12: the general path takes the file)
                 const uint32_t left = (1u << maxbits) - total;
                 g2 = g2 && (left & (left - 1)) == 0;
                 const uint32_t wl = (uint32_t)hibit32(left | 1u) + 1; // the implied last weight, of symbol nw
@@ -717,7 +719,6 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                 const uint32_t r1 = bcast<0, LPF>(cnt[0]); // symbols of weight 1: an even number, at least two
                 g2 = g2 && r1 >= 2 && (r1 & 1) == 0;
                 // start positions: exclusive scan of the class sizes, class after class
-                uint32_t start[NCL];
                 {
                     uint32_t carry = 0;
 #pragma unroll
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                         inc += seg_shr<1, LPF>(inc, sub); inc += seg_shr<2, LPF>(inc, sub);
                         if (LPF > 4) inc += seg_shr<4, LPF>(inc, sub);
                         if (LPF > 8) inc += seg_shr<8, LPF>(inc, sub);
-                        start[j] = carry + inc - sz;
+                        if (v <= 12) L16(hist + 2 * (v - 1)) = (uint16_t)(carry + inc - sz); // the class's write head (the histogram has been read)
                         carry += bcast<LPF - 1, LPF>(inc);
                     }
                     g2 = g2 && carry == (1u << maxbits); // (also catches weights above maxbits)
@@ -736,27 +737,29 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                 SSTAMP(16);
                 wsync();
                 if (g2) {
-#pragma unroll
-                    for (uint32_t j = 0; j < NCL; j++) {
-                        const uint32_t v = sub + 1 + j * LPF;
-                        if (v > maxbits) continue;
-                        uint32_t pos = start[j];
-                        const uint32_t len0 = maxbits + 1 - v, span = 1u << (v - 1); // (an entry: code length | symbol << 8 -- the length is the window's shift count as it is loaded)
-                        for (uint32_t wi = 0; wi < words; wi++) {
-                            const uint64_t W8 = L64(wts + 8 * wi);
-                            uint64_t z = (uint64_t)eqflags((uint32_t)W8, v) | ((uint64_t)eqflags((uint32_t)(W8 >> 32), v) << 32);
-                            while (z) {
-                                const uint32_t sym = 8 * wi + ((uint32_t)__builtin_ctzll(z) >> 3);
-                                z &= z - 1;
-                                const uint32_t e = (sym << 8) | len0, e2 = e | (e << 16);
-                                const uint32_t at = tabo + 2 * pos;
-                                if (v == 1) L16(at) = (uint16_t)e;
-                                else if (v == 2) L32(at) = e2;
-                                else if (v == 3) L64(at) = (uint64_t)e2 | ((uint64_t)e2 << 32);
-                                else { const V16 q = {(uint64_t)e2 | ((uint64_t)e2 << 32), (uint64_t)e2 | ((uint64_t)e2 << 32)}; for (uint32_t o = 0; o < 2 * span; o += 16) lds_sv16(at + o, q); }
-                                pos += span;
-                            }
+                    for (uint32_t s0 = 0; s0 <= nw_l; s0 += LPF) {
+                        const uint32_t s = s0 + sub;
+                        const uint32_t w = s <= nw_l ? L8(wts + s) : 0u;
+                        const bool on = w != 0;
+                        const uint32_t c = on ? w - 1 : 0u; // (span = 1 << c entries)
+                        const uint32_t mo = hmask + 4 * ((c * LPF) >> 5), sh = (c * LPF) & 31;
+                        if (on) lds_or32(mo, (1u << sub) << sh);
+                        wsync();
+                        if (on) {
+                            const uint32_t lm = (L32(mo) >> sh) & ((1u << LPF) - 1);
+                            const uint32_t lower = (uint32_t)__builtin_popcount(lm & ((1u << sub) - 1));
+                            const uint32_t head = L16(hist + 2 * c);
+                            const uint32_t at = tabo + 2 * (head + (lower << c));
+                            const uint32_t e = (s << 8) | (maxbits - c), e2 = e | (e << 16); // (an entry: code length | symbol << 8 -- the length is the window's shift count as it is loaded)
+                            asm volatile("" ::: "memory");
+                            if (c == 0) L16(at) = (uint16_t)e;
+                            else if (c == 1) L32(at) = e2;
+                            else if (c == 2) L64(at) = (uint64_t)e2 | ((uint64_t)e2 << 32);
+                            else { const V16 q = {(uint64_t)e2 | ((uint64_t)e2 << 32), (uint64_t)e2 | ((uint64_t)e2 << 32)}; for (uint32_t o = 0; o < (2u << c); o += 16) lds_sv16(at + o, q); }
+                            if (lower == 0) L16(hist + 2 * c) = (uint16_t)(head + ((uint32_t)__builtin_popcount(lm) << c));
+                            lds_xor32(mo, (1u << sub) << sh); // (the mask is clean again for the next round)
                         }
+                        wsync();
                     }
                     maxbits_l = maxbits;
                 }
