@@ -17,7 +17,8 @@ ONE JSON line (rank 0).  `value` is T1 of SURVEY.md 8d: inputs in HBM when the t
 HBM (several buffer sets are rotated so that the working set exceeds the 256 MiB Infinity Cache).  Extra objects:
   roofline         HBM bound.  achieved = algorithmic bytes per launch (compressed bytes read once + decompressed
                    bytes written once) / average kernel duration measured here with events on the
-                   launch stream.  traffic = HBM bytes per launch from the PMC passes recorded in profiles/.
+                   launch stream.  traffic = HBM bytes per launch, measured by this run where rocprofv3 is on the machine
+                   (two child passes, FETCH_SIZE and WRITE_SIZE; --no-traffic skips them), else the value recorded in profiles/.
   cpu_baseline     rank 0 at N=1: the reference's CPU codec (system libzstd through dlopen) timed on this box's host
                    cores on the same files, repeated to ~10 s of CPU work.
   t2_end_to_end    T2: the path open() takes -- host buffers -> mzd_decode_batch -> host buffers, PCIe included
@@ -231,6 +232,44 @@ def recorded_traffic(workload):
         return None
 
 
+def measure_traffic(workload, files, level):
+    """HBM bytes per launch of this workload, measured NOW: two child runs of this script under `rocprofv3 --kernel-trace --pmc`
+    (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes: they do not fit one pass on gfx950), the
+    counters of the step's kernels summed per launch.  Raw counter values (these kernels read with 4..16-byte accesses, for which
+    the guide calls FETCH_SIZE uncalibrated).  None when rocprofv3 is not on the machine or a pass fails (then the line carries
+    the recorded value of profiles/pmc_traffic.json and says so)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="mzd_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", workload, "--files", str(files), "--level", str(level), "--steps", "4", "--warmup", "1",
+                   "--no-others", "--no-t2", "--no-cpu-baseline", "--no-traffic"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, TMPDIR="/tmp"), cwd=ROOT)
+            if r.returncode != 0:
+                return None
+            per_kernel = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    kn = row.get("Kernel_Name", "")
+                    if row.get("Counter_Name") == ctr and ("mzd_decode_kernel" in kn or "mzd_lds_kernel" in kn):
+                        per_kernel.setdefault(kn.split("(")[0], []).append(float(row["Counter_Value"]))
+            if not per_kernel:
+                return None
+            launches = max(len(v) for v in per_kernel.values())
+            out[ctr] = sum(sum(v) for v in per_kernel.values()) / launches * 1024.0  # KiB -> bytes, per launch of the batch
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fb, wb = int(out["FETCH_SIZE"]), int(out["WRITE_SIZE"])
+    return {"bytes": fb + wb, "fetch_bytes": fb, "write_bytes": wb}
+
+
 def traffic_recorded_at():
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
@@ -435,6 +474,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the other_workloads / single_file objects")
     ap.add_argument("--no-t2", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
@@ -553,6 +593,15 @@ def main():
             line["other_workloads"] = others
             line["single_file"] = single_file(mzd, corpus, dev, stream)
             line["single_file_ms"] = line["single_file"]["kernel_ms"]
+        if not args.no_traffic:  # roofline.traffic measured by this run (two rocprofv3 --pmc child passes over the headline workload)
+            torch.cuda.empty_cache()
+            m = measure_traffic(args.workload, nfiles, args.level)
+            if m:
+                r = line["roofline"]
+                r["traffic"] = m["bytes"]
+                r["traffic_fetch_bytes"], r["traffic_write_bytes"] = m["fetch_bytes"], m["write_bytes"]
+                r["traffic_over_algorithmic"] = round(m["bytes"] / r["algorithmic_bytes_per_launch"], 3)
+                r["traffic_recorded_at"] = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over child runs of this script, raw counter bytes per launch"
     else:
         w.free()
     if rank == 0:

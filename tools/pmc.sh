@@ -4,7 +4,7 @@ set -e
 ctr="$1"; shift
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_tmp; rm -rf "$out"; mkdir -p "$out"
-rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$out" -- python3 bench.py --no-cpu-baseline --no-others --no-t2 --steps 4 --warmup 2 "$@" > "$out/bench.json" 2> "$out/bench.err" || { tail -5 "$out/bench.err"; exit 1; }
+rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$out" -- python3 bench.py --no-cpu-baseline --no-others --no-t2 --no-traffic --steps 4 --warmup 2 "$@" > "$out/bench.json" 2> "$out/bench.err" || { tail -5 "$out/bench.err"; exit 1; }
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)
