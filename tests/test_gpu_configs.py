@@ -223,15 +223,22 @@ def test_small_files_of_every_class_and_size(kind):
     sizes = [0, 1, 2, 7, 15, 16, 17, 31, 32, 33, 63, 64, 100, 255, 256, 300, 511, 700, 1000, 1023, 1024, 2000, 3000, 4095, 4096, 4097,
              5000, 6000, 8191, 8192, 8193, 9000, 12000]
     mzd.set_driver(3)  # the small-file kernel for every eligible file (by itself it only takes thousands at a time)
-    for level in (1, 3, 19):
-        cp = corpus.build_corpus(kind, 77, sizes * 3, level=level)
-        srcs = [cp.comp_file(i).tobytes() for i in range(cp.nfiles)]
-        res = mzd.decode_batch(srcs, [int(s) for s in cp.raw_sizes])
-        for i, (st, out) in enumerate(res):
-            assert st == 0 and out == cp.raw_file(i).tobytes(), (kind, level, int(cp.raw_sizes[i]), st)
-        rc, ref = oracle.decode(srcs[7], cap=int(cp.raw_sizes[7]))
-        assert rc == 0 and ref == cp.raw_file(7).tobytes()
-    mzd.set_driver(0)
+    try:
+        for level in (1, 3, 19):
+            cp = corpus.build_corpus(kind, 77, sizes * 3, level=level)
+            srcs = [cp.comp_file(i).tobytes() for i in range(cp.nfiles)]
+            for g, xg in ((0, 0), (8, 4)):  # the library's choice of shape; eight files per wavefront executed four at a time (raw and RLE blocks take their bytes from the input again in their pass)
+                mzd.lib().mzd_debug_host_path(0, 4, g)
+                mzd.lib().mzd_debug_host_path(0, 5, xg)
+                res = mzd.decode_batch(srcs, [int(s) for s in cp.raw_sizes])
+                for i, (st, out) in enumerate(res):
+                    assert st == 0 and out == cp.raw_file(i).tobytes(), (kind, level, g, xg, int(cp.raw_sizes[i]), st)
+            rc, ref = oracle.decode(srcs[7], cap=int(cp.raw_sizes[7]))
+            assert rc == 0 and ref == cp.raw_file(7).tobytes()
+    finally:
+        mzd.lib().mzd_debug_host_path(0, 4, 0)
+        mzd.lib().mzd_debug_host_path(0, 5, 0)
+        mzd.set_driver(0)
 
 
 def test_small_kernel_hands_on_what_is_not_plain():
