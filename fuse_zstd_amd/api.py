@@ -88,8 +88,9 @@ def lib():
         L.mzd_init.argtypes = [C.POINTER(C.c_int), C.c_int]
         L.mzd_content_size.restype = C.c_uint64
         L.mzd_content_size.argtypes = [C.c_char_p, C.c_size_t]
-        L.mzd_content_bound.restype = C.c_uint64
-        L.mzd_content_bound.argtypes = [C.c_char_p, C.c_size_t]
+        if hasattr(L, "mzd_content_bound"):  # (tools/ load older builds of the library side by side)
+            L.mzd_content_bound.restype = C.c_uint64
+            L.mzd_content_bound.argtypes = [C.c_char_p, C.c_size_t]
         L.mzd_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mzd_decode_batch.argtypes = [C.POINTER(Job), C.c_size_t]
         L.mzd_decode_batch_device.argtypes = [C.c_int, C.POINTER(Job), C.c_size_t, C.c_void_p]
@@ -108,8 +109,9 @@ def lib():
         L.mzd_debug_last_block.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_size_t)]
         L.mzd_last_kernel_ms.argtypes = [C.c_int, C.POINTER(C.c_float)]
-        L.mzd_last_kernel_name.restype = C.c_char_p
-        L.mzd_last_kernel_name.argtypes = [C.c_int]
+        if hasattr(L, "mzd_last_kernel_name"):
+            L.mzd_last_kernel_name.restype = C.c_char_p
+            L.mzd_last_kernel_name.argtypes = [C.c_int]
         L.mzd_strerror.restype = C.c_char_p
         L.mzd_strerror.argtypes = [C.c_int]
         L.mzd_version.restype = C.c_char_p

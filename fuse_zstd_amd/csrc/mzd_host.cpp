@@ -28,6 +28,9 @@
 
 namespace mzd {
 void launch_dict_kernel(const uint8_t* dict, uint32_t n, DevDict* out, int32_t* status, void* stream);
+#ifdef MZD_EXP_DEVSITE
+void devsite_take(uint32_t* out3);
+#endif
 void* decode_kernel_ptr(int tasks);
 }
 
@@ -1201,6 +1204,9 @@ int mzd_debug_counters(int device, uint32_t* out8) {
     HIPCHK(hipSetDevice(d->hip_id));
     if (!d->job0_counter) return MZD_E_PARAM;
     HIPCHK(hipMemcpy(out8, d->job0_counter, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+#ifdef MZD_EXP_DEVSITE
+    mzd::devsite_take(out8 + 5); // (words 5, 6, 7: first, max, count)
+#endif
     return MZD_OK;
 }
 

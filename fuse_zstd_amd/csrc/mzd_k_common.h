@@ -176,12 +176,19 @@ __device__ __forceinline__ void post_err(int32_t* err, int rc) {
 }
 // (a wait that runs out is a failure of the launch -- a co-tenant starved the workgroup, a role died -- not of the input:
 //  it posts MZD_E_DEVICE, and whatever the waiting role reports afterwards loses to it)
+#ifdef MZD_EXP_DEVSITE // (experiment: which bounded wait ran out -- the highest site id seen, in counter word 7)
+__device__ uint32_t g_devsite[4]; // first, max, count (read and cleared by devsite_take, mzd_kernels.hip)
+#define DEVSITE(id) do { atomicCAS(&g_devsite[0], 0u, (uint32_t)(id)); atomicMax(&g_devsite[1], (uint32_t)(id)); atomicAdd(&g_devsite[2], 1u); } while (0)
+#else
+#define DEVSITE(id) ((void)0)
+#endif
 __device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want, int32_t* err) {
     for (uint32_t it = 0; it < (1u << 24); it++) {
         if (flag_load(p) >= want) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
         if (__atomic_load_n(err, __ATOMIC_RELAXED)) return false;
         __builtin_amdgcn_s_sleep(2);
     }
+    DEVSITE(1 + (uint32_t)(((const uint8_t*)p - (const uint8_t*)&S) & 0xFFF) * 16);
     post_err(err, MZD_E_DEVICE);
     return false;
 }

@@ -169,7 +169,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
             if ((pg & ~kWalkFin) >= need || (pg & kWalkFin)) break;
             __builtin_amdgcn_s_sleep(4);
         }
-        if (it == (1u << 24)) post_err(&S.c.err, MZD_E_DEVICE); // (a wait that ran out: see spin_ge)
+        if (it == (1u << 24)) { DEVSITE(2); post_err(&S.c.err, MZD_E_DEVICE); } // (a wait that ran out: see spin_ge)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return (pg & ~kWalkFin) >= need;
     };
@@ -430,7 +430,7 @@ __device__ __noinline__ int exec_verdict(int rc, uint32_t nseq, uint32_t lit_str
         if ((walked && lits) || __atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) break;
         __builtin_amdgcn_s_sleep(4);
     }
-    if (it == (1u << 24)) post_err(&S.c.err, MZD_E_DEVICE);
+    if (it == (1u << 24)) { DEVSITE(3); post_err(&S.c.err, MZD_E_DEVICE); }
     return rc;
 }
 // ... and inside the chunk that cannot be executed (sequences base .. base+63 of the plan, read again here) the earliest
@@ -481,7 +481,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             if ((pg & ~kPlanFin) >= nchunks_needed || (pg & kPlanFin)) break;
             __builtin_amdgcn_s_sleep(4);
         }
-        if (it == (1u << 24)) post_err(&S.c.err, MZD_E_DEVICE);
+        if (it == (1u << 24)) { DEVSITE(4); post_err(&S.c.err, MZD_E_DEVICE); }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return (pg & ~kPlanFin) >= nchunks_needed;
     };
@@ -498,6 +498,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             if (flag_load_u((const uint32_t*)&S.c.err)) return false;
             __builtin_amdgcn_s_sleep(4);
         }
+        DEVSITE(5);
         post_err(&S.c.err, MZD_E_DEVICE);
         return false;
     };
@@ -735,7 +736,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             if (flag_load_u(&S.c.plan_prog) & kPlanFin) break;
             __builtin_amdgcn_s_sleep(4);
         }
-        if (it == (1u << 24)) post_err(&S.c.err, MZD_E_DEVICE);
+        if (it == (1u << 24)) { DEVSITE(6); post_err(&S.c.err, MZD_E_DEVICE); }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (flag_load_u((const uint32_t*)&S.c.err)) return MZD_E_CORRUPT;
         if (flag_load_u(&S.c.walk_inexact)) return MZD_E_CORRUPT; // every sequence executed, the bitstream not consumed exactly (the planner has finished, so the walker has)

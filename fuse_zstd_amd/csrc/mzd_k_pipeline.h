@@ -76,7 +76,7 @@ template <bool TASKS> struct BlockRun {
     // TASKS: the file's tables at version t (what the predecessor left): one lane waits, the wavefront copies
     __device__ __forceinline__ bool wait_tables() const {
         int ok = 1;
-        if (lane == 0) ok = g_wait_ge(&b.fs->tables_ver, b.t) ? 1 : 0;
+        if (lane == 0) ok = g_wait_ge(&b.fs->tables_ver, b.t, 3) ? 1 : 0;
         ok = __builtin_amdgcn_readfirstlane(ok);
         return ok != 0;
     }
@@ -99,7 +99,7 @@ __device__ __noinline__ void role_walk(BlockRun<TASKS> r) {
             const bool inherit = !b.frame_first && (c.mode[0] == 3 || c.mode[1] == 3 || c.mode[2] == 3);
             if (inherit) { // repeat mode: the table the previous block used (another workgroup built it)
                 FileState* const fs = b.fs; TableArea* const ta = b.ta;
-                if (!r.wait_tables()) rc = MZD_E_DEVICE;
+                if (!r.wait_tables()) { DEVSITE(7); rc = MZD_E_DEVICE; }
                 else if (!g_ld(&fs->fse_valid)) rc = MZD_E_CORRUPT;
                 else {
                     if (c.mode[0] == 3) { for (int i = lane; i < 512; i += 64) S.ll[i] = g_ld(&ta->ll[i]); if (lane == 0) c.al[0] = g_ld(&fs->al[0]); }
@@ -219,7 +219,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
                 if (!TASKS && lane == 0 && !hr) c.huf_valid = 1;
             } else if (!frame_first) { // treeless: the table of the previous compressed-literals block
                 FileState* const fs = b.fs; TableArea* const ta = b.ta;
-                if (!r.wait_tables()) hr = MZD_E_DEVICE;
+                if (!r.wait_tables()) { DEVSITE(8); hr = MZD_E_DEVICE; }
                 else if (!g_ld(&fs->huf_valid)) hr = MZD_E_DICT; // (treeless literals without a tree: libzstd's dictionary_corrupted)
                 else {
                     for (int i = lane; i < (int)kHufWords; i += 64) reinterpret_cast<uint32_t*>(S.huf)[i] = g_ld(&reinterpret_cast<const uint32_t*>(ta->huf)[i]);
@@ -325,6 +325,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
                 }
                 if (fin) break;
                 if (!did) { if (__atomic_load_n(&c.err, __ATOMIC_RELAXED)) break; __builtin_amdgcn_s_sleep(8); }
+                if (it == (1u << 24) - 1 && lane == 0) DEVSITE(12);
             }
         }
         TFIN(2);

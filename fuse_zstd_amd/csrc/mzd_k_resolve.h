@@ -24,12 +24,12 @@ constexpr uint32_t kResRounds = 24;         // > log2(128 Ki) + slack (reads rac
 
 // Step 1, lane = sequence, a chunk of 64 sequences per call.  cbase[k] = {output, literals} before chunk k (plan_wave).
 // Returns false -- and writes nothing -- when the chunk holds an offset that is still symbolic and `rep_known` is not set.
-// bad: an offset of 0 was seen (the copier must give the verdict); maxprev: the largest distance a match reaches before the
+// bad: an offset of 0, or a sequence that lies outside the block, was seen (the copier must give the verdict); maxprev: the largest distance a match reaches before the
 // block start.
 __device__ __forceinline__ bool resolve_build_chunk(uint32_t* map, const uint4* plan, const uint4* cbase, uint32_t chunk, uint32_t nseq, bool rep_known,
                                                     uint32_t rep0, uint32_t rep1, uint32_t rep2, uint4* plan_wb, int lane, uint32_t& bad, uint32_t& maxprev) {
     const uint32_t i = chunk * 64 + (uint32_t)lane;
-    const bool valid = i < nseq;
+    bool valid = i < nseq;
     const uint4 pe = valid ? plan[i] : make_uint4(0, 0, 1, 0);
     uint32_t off = pe.z;
     if (__any(valid && (off & kOffTag) != 0)) { // start slot + delta (plan_wave)
@@ -43,7 +43,12 @@ __device__ __forceinline__ bool resolve_build_chunk(uint32_t* map, const uint4* 
     const uint32_t ll = pe.x, ml = pe.y, ex_t = pe.w;
     const uint32_t p_l = cb.x + ex_t, p_m = p_l + ll;
     const uint32_t li = cb.y + (wave_incl_scan(ll, lane) - ll);
-    if (valid && (off == 0 || off >= (1u << 30))) bad = 1;
+    // A plan made of garbage passes 128 KiB in the chunk the planner marks (Ctl::plan_too_long) -- which is public all the same, and
+    // may be seen here before the mark: a sequence that does not lie inside the block writes nothing (the map's slot ends there,
+    // the next workgroup's begins), and the copier gives the verdict.  (No overflow: ll, ml < 2^18, 64 of them in a chunk.)
+    const bool valid_in = valid;
+    valid = valid && p_m + ml <= kBlockMax;
+    if (valid_in && (!valid || off == 0 || off >= (1u << 30))) bad = 1;
     if (valid && ml && off > p_m) { const uint32_t d = off - p_m; maxprev = d > maxprev ? d : maxprev; }
     // short pieces: every lane its own, four entries per store (16 bytes, 4-byte aligned), as many steps as the longest needs
     typedef __attribute__((address_space(1))) uint32_t* gmap;
@@ -105,6 +110,7 @@ __device__ __noinline__ void resolve_build_follow(uint32_t* map, const uint4* pl
             if (pg & kPlanFin) { have = (pg & ~kPlanFin) > chunk && !__atomic_load_n(&S.c.err, __ATOMIC_RELAXED) && !__atomic_load_n(&S.c.plan_too_long, __ATOMIC_RELAXED) && !__atomic_load_n(&S.c.walk_inexact, __ATOMIC_RELAXED); break; }
             if (__atomic_load_n(&S.c.err, __ATOMIC_RELAXED)) break;
             __builtin_amdgcn_s_sleep(8);
+            if (it == (1u << 24) - 1 && lane == 0) DEVSITE(13);
         }
         if (!have) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -193,7 +199,10 @@ __device__ __noinline__ bool resolve_jump_tiled(uint32_t* map, uint32_t B, int t
         wg_fence(); // the next tile reads these entries
         __syncthreads(); // (and every wavefront is done with this tile's LDS image)
     }
-    return good;
+    // `good` is a wavefront's own finding (its entries' chains): the caller branches on the answer around workgroup barriers, so it
+    // must be the same in all four.  (A consistent map always settles; one that does not has been written to from outside.)
+    if (!good && (tid & 63) == 0) DEVSITE(15);
+    return __syncthreads_and(good ? 1 : 0) != 0;
 }
 
 // Step 2, all 256 threads (workgroup barriers inside).  true: no entry refers to the block any more.

@@ -134,11 +134,13 @@ __device__ __forceinline__ void g_settle() { __builtin_amdgcn_fence(__ATOMIC_REL
 // therefore stored behind an agent-scope RELEASE (L2 write-back + wait), like the one that publishes the output bytes.
 __device__ __forceinline__ void g_publish(uint32_t* flag, uint32_t v) { g_release(); g_store(flag, v); }
 // wait until *p >= want (bounded: a launch that lost a task must end, not hang); one lane calls this
-__device__ __noinline__ bool g_wait_ge(const uint32_t* p, uint32_t want) {
+__device__ __noinline__ bool g_wait_ge(const uint32_t* p, uint32_t want, uint32_t site = 0) {
     for (uint32_t it = 0; it < (1u << 23); it++) {
         if (g_load(p) >= want) return true;
         __builtin_amdgcn_s_sleep(8);
     }
+    DEVSITE(20 + site);
+    (void)site;
     return false;
 }
 // lane 0: what the predecessor of task t left behind -> S.c.pred_*.  false: the launch is broken (timeout).
@@ -151,7 +153,7 @@ __device__ __noinline__ bool load_pred_copy(const FileState* fs, uint32_t t) {
         c.pred_err = 0; c.pred_out = 0; c.pred_frame_out0 = 0;
         c.pred_rep[0] = 1; c.pred_rep[1] = 4; c.pred_rep[2] = 8;
     } else {
-        if (!g_wait_ge(&fs->copied, t)) { c.pred_err = MZD_E_DEVICE; c.pred_out = 0; c.pred_frame_out0 = 0; return false; }
+        if (!g_wait_ge(&fs->copied, t)) { DEVSITE(9); c.pred_err = MZD_E_DEVICE; c.pred_out = 0; c.pred_frame_out0 = 0; return false; }
         c.pred_err = g_ld(&fs->err); c.pred_out = g_ld(&fs->out); c.pred_frame_out0 = g_ld(&fs->frame_out0);
         c.pred_rep[0] = g_ld(&fs->rep[0]); c.pred_rep[1] = g_ld(&fs->rep[1]); c.pred_rep[2] = g_ld(&fs->rep[2]);
     }
@@ -163,7 +165,7 @@ __device__ __noinline__ bool load_pred_hash(const FileState* fs, uint32_t t) {
         c.pred_xstripes = 0;
         for (int k = 0; k < 4; k++) c.pred_xxh[k] = 0;
     } else {
-        if (!g_wait_ge(&fs->hashed, t)) { c.pred_err = MZD_E_DEVICE; c.pred_xstripes = 0; return false; }
+        if (!g_wait_ge(&fs->hashed, t)) { DEVSITE(10); c.pred_err = MZD_E_DEVICE; c.pred_xstripes = 0; return false; }
         c.pred_xstripes = g_ld(&fs->xstripes);
         for (int k = 0; k < 4; k++) c.pred_xxh[k] = g_ld(&fs->xxh[k]);
         const int32_t he = g_ld(&fs->herr);
@@ -180,7 +182,7 @@ __device__ __noinline__ bool load_pred(const FileState* fs, uint32_t t) {
 // sequences), publish.  `rin` receives the offsets this task starts with.  false: the launch is broken (timeout).
 __device__ __noinline__ bool rep_hop(FileState* fs, uint32_t t, bool frame_first, bool planned, uint32_t* rin) {
     Ctl& c = S.c;
-    const bool ok = g_wait_ge(&fs->rep_ver, t);
+    const bool ok = g_wait_ge(&fs->rep_ver, t, 1);
     uint32_t r0 = c.rep[0], r1 = c.rep[1], r2 = c.rep[2]; // a frame starts with its own (1, 4, 8 or the dictionary's)
     if (!frame_first) { r0 = g_ld(&fs->rep_e[0]); r1 = g_ld(&fs->rep_e[1]); r2 = g_ld(&fs->rep_e[2]); }
     rin[0] = r0; rin[1] = r1; rin[2] = r2;
@@ -385,6 +387,13 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs) {
 }
 
 // ---- driver 2: block tasks (the hand-over helpers are above, in front of the shared block pipeline)
+#ifdef MZD_EXP_DEVSITE // (experiment: the first segment of a task that took more than 50 ms, with its job and task)
+#define DEVSLOW_DECL uint64_t ds_t0_ = wall_clock64()
+#define DEVSLOW(k) do { const uint64_t n_ = wall_clock64(); if (tid == 0 && n_ - ds_t0_ > 5000000ull) DEVSITE(((200u + (k)) << 16) | ((j & 0xFF) << 8) | (t & 0xFF)); ds_t0_ = n_; } while (0)
+#else
+#define DEVSLOW_DECL ((void)0)
+#define DEVSLOW(k) ((void)0)
+#endif
 __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
     const KernelArgs& a = launch_args();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -416,6 +425,9 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                         got = __hip_atomic_load(&r->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
                         if (!got) break;
                     }
+#ifdef MZD_EXP_DEVSITE
+                    if (it == (1u << 23) - 1) DEVSITE((100u << 16) | (m & 0xFFFF));
+#endif
                     if (got) {
                         c.job = g_ld(&r->job); c.task = g_ld(&r->task); c.pos = g_ld(&r->pos); c.in_frame = g_ld(&r->in_frame); c.with_dict = g_ld(&r->with_dict);
                         c.has_fcs = g_ld(&r->has_fcs); c.has_cksum = g_ld(&r->has_cksum); c.block_max = g_ld(&r->block_max); c.fcs = g_ld(&r->fcs);
@@ -430,6 +442,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
         WG_SNAPSHOT(t_valid = c.t_valid; j = c.job; t = c.task; in_frame = c.in_frame);
         if (!t_valid) break;
         TTASK();
+        DEVSLOW_DECL;
         const uint8_t* const src = a.jobs[j].src;
         const uint64_t n = a.jobs[j].src_len;
         uint8_t* const dst = a.jobs[j].dst;
@@ -519,6 +532,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
             }
         }
 
+        DEVSLOW(1);
         if (a.resolve && !(have_block && btype == 2)) { // resolving launches: a task that plans nothing hands the repeat offsets on at once
             if (tid == 0) rep_hop(fs, t, frame_first, false, S.res_rep);
             rep_hopped = true;
@@ -560,6 +574,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
             const BlockArgs& ba = S.ba; // (in LDS: see driver 1)
             const bool started = compressed_block<true>(a, ba, xv, xstripes, mirrored, tid, lane, wave, resolving);
             bool resolved = false;
+            __syncthreads();
+            DEVSLOW(2);
             if (resolving && started) {
                 __syncthreads(); // walk, plan and literals are complete (every role has returned); nothing of the block has been written yet
                 TFIN(7); // (diagnostic builds: the resolve timeline reuses the literal-side slots 7, 8, 4 and the copier's 9, 1, 2)
@@ -617,7 +633,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                                 const bool dead = early && (!chain_ok || __atomic_load_n(&c.pred_err, __ATOMIC_RELAXED) != 0); // a checksum failed earlier in the file
                                 xv = frame_first ? xxh_init(lane) : c.pred_xxh[lane & 3];
                                 xstripes = frame_first ? 0 : c.pred_xstripes;
-                                if (!dead && !resolve_hash_behind(xv, xstripes, dst + fstart0, out0 - fstart0, B, lane) && lane == 0) post_err(&c.err, MZD_E_DEVICE);
+                                if (!dead && !resolve_hash_behind(xv, xstripes, dst + fstart0, out0 - fstart0, B, lane) && lane == 0) { DEVSITE(11); post_err(&c.err, MZD_E_DEVICE); }
                                 if (early) {
                                     int herr_now = 0;
                                     if (!dead && last && !err_c) { // close the digest
@@ -645,6 +661,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                                         for (uint32_t it = 0; it < (1u << 24); it++) {
                                             if (flag_load(&S.res_prog[1]) >= nsteps && flag_load(&S.res_prog[2]) >= nsteps) break;
                                             __builtin_amdgcn_s_sleep(4);
+                                            if (it == (1u << 24) - 1) DEVSITE(14);
                                         }
                                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                                         RepOp Rf; Rf.s = c.rep_op[0]; Rf.v0 = (int32_t)c.rep_op[1]; Rf.v1 = (int32_t)c.rep_op[2]; Rf.v2 = (int32_t)c.rep_op[3];
@@ -684,7 +701,8 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                 }
             }
             if (started) rep_hopped = true; // (role_plan)
-            if (resolving && started && !resolved) { compressed_block_copy(a, ba, xv, xstripes, mirrored, tid, lane, wave); have_mirrored = true; }
+            DEVSLOW(3);
+            if (resolving && started && !resolved) { compressed_block_copy(a, ba, xv, xstripes, mirrored, tid, lane, wave); have_mirrored = true; __syncthreads(); DEVSLOW(4); }
             else if (!resolving) have_mirrored = true;
             WG_SNAPSHOT(err = c.err);
             STAMP(6);
@@ -697,6 +715,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
 
         // ---------------- completion, in task order: frame trailer (K7), then the state for the successor
         __syncthreads();
+        DEVSLOW(5);
         if (tid == 0 && !pred_loaded) load_pred(fs, t);
         int perr = 0;
         uint64_t pred_out = 0, fstart = 0, out_now = 0, pos_now = 0;
@@ -735,7 +754,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
                 if (lane == 0) g_st(&fs->xstripes, xstripes);
             }
             if (!c.tables_published) { // raw/RLE block, early error: the tables are unchanged, the version still moves on
-                if (tid == 0) c.t_valid = g_wait_ge(&fs->tables_ver, t) ? 1u : 0u;
+                if (tid == 0) c.t_valid = g_wait_ge(&fs->tables_ver, t, 2) ? 1u : 0u;
                 uint32_t ver_ok = 0, hv = 0, fv = 0;
                 WG_SNAPSHOT(ver_ok = c.t_valid; hv = c.huf_valid; fv = c.fse_valid);
                 if (ver_ok) {
@@ -778,6 +797,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
         }
         // the host mirror of this task's block: behind the hand-over -- the successor copies on, this wavefront feeds PCIe
         if (mirror_rest && wave == 2 && out_now > mirror_from) mirror_wave(dst, dst2, mirror_from, out_now, lane);
+        DEVSLOW(6);
         TTASK_END();
         STAMP_FLUSH();
         TFIN_FLUSH();
@@ -857,6 +877,9 @@ void launch_dict_kernel(const uint8_t* dict, uint32_t n, DevDict* out, int32_t* 
 
 void* decode_kernel_ptr(int tasks) { return tasks ? (void*)mzd_decode_kernel_tasks : (void*)mzd_decode_kernel_files; }
 
+#ifdef MZD_EXP_DEVSITE
+void devsite_take(uint32_t* out3) { uint32_t z[4] = {0, 0, 0, 0}; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_devsite), 12); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_devsite), z, 16); }
+#endif
 void launch_decode(const KernelArgs& a, uint32_t grid, void* stream) {
     if (a.use_tasks) hipLaunchKernelGGL(mzd_decode_kernel_tasks, dim3(grid), dim3(kWG), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(mzd_decode_kernel_files, dim3(grid), dim3(kWG), 0, (hipStream_t)stream, a);

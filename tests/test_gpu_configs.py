@@ -200,6 +200,46 @@ def test_hand_overs_between_block_tasks_hold_under_repetition_on_a_machine_filli
 
 
 @needs_zstd
+@pytest.mark.parametrize("mode", [0, 3, 2, 4, 5])
+def test_a_batch_of_corrupted_multi_block_files_holds_under_repetition(mode):
+    """Round 4's one real defect as a test: the 512 mutated, truncated and too-small multi-block files of
+    tests/test_gpu_parity.py::test_corrupted_multi_block_files_report_the_oracles_error, decoded 40 times under each
+    block-task driver.  A walk that ends inexactly leaves a plan made of garbage; the byte map a resolving task builds
+    from it reached past the workgroup's map slot into its neighbour's (mzd_k_resolve.h: resolve_build_chunk) -- whose
+    chains then did not settle, in ONE of its four wavefronts, which took the other side of a branch around workgroup
+    barriers: once in ten to fifty batches a bounded wait ran out (5 .. 7 s, MZD_E_DEVICE for one file).  Every status
+    must be the oracle's in every repetition, and no repetition may take seconds."""
+    import time
+    rng = np.random.RandomState(77)
+    cases = []
+    for kind, size in (("json", 600000), ("text", 400000), ("xray", 300000), ("repeats", 500000)):
+        good = corpus.build_corpus(kind, 21, [size]).comp_file(0).tobytes()
+        for _ in range(120):
+            b = bytearray(good)
+            pos = int(rng.randint(0, len(b)))
+            b[pos] ^= int(rng.randint(1, 256))
+            cases.append((bytes(b), size))
+        for cut in (len(good) - 1, len(good) - 5, len(good) // 2, 40):
+            cases.append((good[:cut], size))
+        for cap in (size - 1, size // 2, 150000, 10):
+            cases.append((good, cap))
+    want = [oracle.decode(c, cap=cap)[0] for c, cap in cases]
+    comps, caps = [c for c, _ in cases], [cap for _, cap in cases]
+    mzd.set_driver(mode)
+    try:
+        mzd.decode_batch(comps, caps)  # (buffers, lanes)
+        for rep in range(40):
+            t0 = time.perf_counter()
+            res = mzd.decode_batch(comps, caps)
+            wall = time.perf_counter() - t0
+            bad = [(i, st, want[i]) for i, (st, _) in enumerate(res) if st != want[i]]
+            assert not bad, (mode, rep, bad[:5])
+            assert wall < 2.0, (mode, rep, wall)  # (~0.05 s; the shortest of the kernels' bounded waits takes 4 s to run out)
+    finally:
+        mzd.set_driver(0)
+
+
+@needs_zstd
 def test_config5_full_size_shared_dictionary():
     """BASELINE configs[4]: 50 000 records of 300..3000 B, the 112 640-byte trained dictionary (tables shared in LDS by the
     64 files of a wavefront; most matches read the dictionary content)."""
