@@ -169,6 +169,12 @@ __device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __atom
 // loaded value counts as divergent, and every wave-uniform boolean alive across it is then merged through exec-mask arithmetic
 // (three scalar instructions each, at every join).  Reading it through readfirstlane makes value and branch uniform.
 __device__ __forceinline__ uint32_t flag_load_u(const uint32_t* p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__atomic_load_n(p, __ATOMIC_RELAXED)); }
+// LDS by offset: an address-space-qualified access is a DS instruction (a generic pointer into LDS makes FLAT ones, which
+// take the vector memory path as well)
+typedef __attribute__((address_space(3))) uint8_t lds_byte;
+__device__ __forceinline__ uint32_t lds_offset_of(const void* p) { return (uint32_t)(uintptr_t)(const lds_byte*)p; }
+__device__ __forceinline__ uint64_t lds_load_u64(uint32_t off) { uint64_t v; __builtin_memcpy(&v, (const lds_byte*)(uintptr_t)off, 8); return v; } // any alignment
+__device__ __forceinline__ void lds_store_u128(uint32_t off, const uint4& v) { __builtin_memcpy((lds_byte*)__builtin_assume_aligned((lds_byte*)(uintptr_t)off, 16), &v, 16); } // 16-byte aligned
 __device__ __forceinline__ void flag_store(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 // first error wins: a wavefront that merely gave up because another one failed must not overwrite the cause
 __device__ __forceinline__ void post_err(int32_t* err, int rc) {

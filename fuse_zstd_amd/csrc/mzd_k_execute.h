@@ -749,6 +749,16 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         if (nlit_all > cap - opos) return MZD_E_DSTSIZE; // a block without sequences has no planner to check this
     }
     const uint32_t rest = nlit_all - lpos;
+    if (lit + lpos == dst + opos && lit_streams > 1) {
+        // a literal-only block decoded in place: nothing to move, but the hashing wavefront follows exec_pos -- it is told of every
+        // stream's share of the output as the streams before it complete (the hash of 128 KiB takes as long as a stream's decode)
+        for (uint32_t k = 1; k < lit_streams; k++) {
+            const uint32_t upto = u32(S.c.s_out[k]);
+            if (!wait_lits(upto)) return MZD_E_CORRUPT;
+            wg_fence();
+            if (lane == 0) __atomic_store_n(&S.c.exec_pos, opos + upto, __ATOMIC_RELAXED);
+        }
+    }
     if (!wait_lits(nlit_all)) return MZD_E_CORRUPT;
     if (lit + lpos != dst + opos) wave_copy(dst + opos, lit + lpos, rest, lane); // (literal-only block decoded in place: nothing to move)
     opos += rest;

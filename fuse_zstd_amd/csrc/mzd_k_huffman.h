@@ -28,6 +28,7 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
     const int32_t nbits = (int32_t)((sl - 1) * 8 + (uint32_t)hibit(last));
     const uint32_t mask = (1u << L) - 1;
     const uint16_t* const tab = S.huf;
+    const uint32_t lseg = lds_offset_of(seg); // (the staging segment is in LDS: DS instructions -- through the generic pointer every window load is a flat_load)
     int32_t pos = 0;        // bits consumed so far (wave-uniform, exact)
     uint32_t done = 0;      // symbols written so far
     while (pos < nbits) {
@@ -41,7 +42,7 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
         for (uint32_t o = (uint32_t)lane * 16; o < bhi - blo + 16; o += 1024) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (blo + o >= 16) __builtin_memcpy(&v, sp + (blo + o - 16), 16); // may over-read <= 15 bytes past the stream (input padding)
-            *reinterpret_cast<uint4*>(seg + o) = v;
+            lds_store_u128(lseg + o, v);
         }
         const int32_t seg_bias = 16 - (int32_t)blo; // stream byte j lives at seg[j + seg_bias] (the index is formed first: a pointer below `seg` would be out of bounds)
         int32_t C = (s1 - s0 + 63) / 64;
@@ -55,11 +56,38 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
         auto walk = [&](int32_t from, uint32_t& cnt, uint8_t* dst) -> int32_t {
             int32_t rem = nbits - from; // bits below the read point
             uint32_t c = 0;
-            uint64_t acc = 0; // the write pass packs 8 symbols per HBM store (byte stores cost a sector write each)
+            if (!BIG) {
+                // Whole windows of five symbols without the per-symbol boundary test, as long as the window STARTS above the lane's
+                // boundary: the last one may pass it -- it is then taken back and left to the checked loop below, which reads the same
+                // window.  (Four instruction slots per symbol instead of eleven; the decoder is bound by VALU issue on noisy data.)
+                int32_t rem_p = rem;
+                uint32_t it = 0;
+                for (; it < 52 && rem > lim; it++) { // (a window consumes >= 5 bits of <= 248; the bound only guards a table with a void entry)
+                    rem_p = rem;
+                    const int32_t bi = (rem - 57) >> 3;
+                    const uint64_t W = lds_load_u64(lseg + (uint32_t)(bi + seg_bias));
+                    uint32_t t = (uint32_t)(rem - bi * 8) - L - 1; // shift of the next code's window, less one: the index comes out doubled (a byte offset)
+                    uint32_t e[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const uint32_t ix2 = (uint32_t)(W >> t) & (mask << 1);
+                        e[k] = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(tab) + ix2);
+                        t -= e[k] >> 8;
+                    }
+                    rem = bi * 8 + (int32_t)(t + L + 1);
+                    if (dst && rem > lim) { // five symbols, all of them the lane's own: a dword and a byte, wherever they fall (the sectors are completed in L2)
+                        const uint32_t four = (e[0] & 0xFF) | (e[1] & 0xFF) << 8 | (e[2] & 0xFF) << 16 | e[3] << 24;
+                        __builtin_memcpy(dst + c, &four, 4);
+                        dst[c + 4] = (uint8_t)e[4];
+                    }
+                    c += 5;
+                }
+                if (it && rem <= lim) { rem = rem_p; c -= 5; } // (the last window reached the boundary: again, symbol by symbol)
+            }
             while (rem > lim) {
                 const int32_t bi = (rem - 57) >> 3; // window = stream bytes [bi, bi + 8): the 57..64 bits below the read point
                 uint64_t W;
-                __builtin_memcpy(&W, seg + (uint32_t)(bi + seg_bias), 8);
+                W = lds_load_u64(lseg + (uint32_t)(bi + seg_bias));
                 int32_t h = rem - bi * 8;           // read point inside the window
 #pragma unroll
                 for (int k = 0; k < (BIG ? 4 : 5); k++) {
@@ -69,17 +97,13 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
                     uint32_t l = e >> 8;
                     if (BIG && l == 12 && (v & 1)) e = reinterpret_cast<const uint8_t*>(&S.huf[2048])[v >> 1]; // the odd one of two codes of length 12
                     l = l ? l : 1u;
-                    if (dst && act) {
-                        acc |= (uint64_t)(e & 0xFF) << ((c & 7) * 8);
-                        if ((c & 7) == 7) { __builtin_memcpy(dst + (c & ~7u), &acc, 8); acc = 0; }
-                    }
+                    if (dst && act) dst[c] = (uint8_t)e; // (one window per walk, but for a tree of depth 12)
                     l = act ? l : 0u;
                     c += act ? 1u : 0u;
                     h -= (int32_t)l;
                     rem -= (int32_t)l;
                 }
             }
-            if (dst) for (uint32_t k = c & ~7u; k < c; k++) { dst[k] = (uint8_t)acc; acc >>= 8; }
             cnt = c;
             return nbits - rem;
         };
