@@ -226,7 +226,9 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
                     if (lane == 0) c.huf_log = g_ld(&fs->huf_log);
                 }
             }
-            if (lane == 0 && hr) post_err(&c.err, hr);
+            // (treeless literals without a tree are found before anything else in the block: the class outranks what the walking
+            //  wavefront may have posted about the sequence section meanwhile)
+            if (lane == 0 && hr) { if (hr == MZD_E_DICT) __atomic_store_n(&c.err, (int32_t)MZD_E_DICT, __ATOMIC_RELAXED); else post_err(&c.err, hr); }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) flag_store(&c.huf_fill, 2);
             TFIN(8);
@@ -358,7 +360,15 @@ __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const Bloc
     uint64_t lit_off = 0, seq_off = 0;
     WG_SNAPSHOT(err = c.err; lit_type = c.lit_type; nlit = c.nlit; streams = c.streams; lit_off = c.lit_off;
                 seq_off = c.seq_off; seq_len = c.seq_len);
-    if (err) return false;
+    if (err) {
+        if (TASKS && !b.frame_first && lit_type == 3 && b.bsize >= 3 && err != MZD_E_DICT) {
+            // A block that continues a frame parses its headers before it knows what the frame has inherited (Ctl::huf_valid is
+            // provisional): treeless literals without a tree are libzstd's first finding in the section, before its sizes
+            if (tid == 0 && g_wait_ge(&b.fs->tables_ver, b.t) && !g_ld(&b.fs->huf_valid)) c.err = MZD_E_DICT;
+            __syncthreads();
+        }
+        return false;
+    }
     if (!b.block_pre) {
         for (uint32_t k = tid; k < seq_len && k < 256; k += kWG) S.stage[256 + k] = b.src[seq_off + k];
         __syncthreads();

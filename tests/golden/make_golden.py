@@ -336,6 +336,15 @@ def main():
     body = lit_header_raw_rle(0, 2) + b"ab" + nbseq_bytes(1) + bytes([(1 << 6) | (1 << 4) | (1 << 2)]) + bytes([2, 5, 0])
     body += backward_stream(bits(31, 5))
     add("bad_offset_beyond_history", frame(block_header(1, 2, len(body)) + body, b"ab" + b"x" * 3, checksum=False), expect="error")
+    # treeless literals in a frame's SECOND block when no block before it carried a tree: libzstd's dictionary_corrupted, found before
+    # the literals section's sizes and before the sequence section are looked at (a block task learns what the frame has inherited
+    # only from its predecessor).  a: the rest of the block is sound; b: its sizes are impossible; c: its sequence section is garbage.
+    b0 = lit_header_raw_rle(0, 6) + b"abcdef" + nbseq_bytes(0)
+    for tag, lh, tail in (("a", (3 | (0 << 2) | (8 << 4) | (5 << 14)).to_bytes(3, "little"), bytes([0x11, 0x22, 0x33, 0x44, 0x81]) + nbseq_bytes(0)),
+                          ("b", (3 | (0 << 2) | (8 << 4) | (900 << 14)).to_bytes(3, "little"), bytes([0x11, 0x22, 0x33, 0x44, 0x81]) + nbseq_bytes(0)),
+                          ("c", (3 | (0 << 2) | (8 << 4) | (5 << 14)).to_bytes(3, "little"), bytes([0x11, 0x22, 0x33, 0x44, 0x81]) + nbseq_bytes(3) + bytes([0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x00]))):
+        b1 = lh + tail
+        add("bad_treeless_no_tree_block2_" + tag, frame(block_header(0, 2, len(b0)) + b0 + block_header(1, 2, len(b1)) + b1, b"abcdef" + b"x" * 58, checksum=False), expect="error")  # (a content size above every block's size)
     body = lit_header_raw_rle(0, 2) + b"ab" + nbseq_bytes(1) + bytes([(1 << 6) | (1 << 4) | (1 << 2) | 1]) + bytes([2, 5, 0]) + backward_stream(bits(0, 5))
     add("bad_seq_modes_reserved", frame(block_header(1, 2, len(body)) + body, b"ab" + b"x" * 3, checksum=False), expect="error")
     body = lit_header_raw_rle(0, 2) + b"ab" + nbseq_bytes(1) + bytes([(3 << 6)]) + backward_stream("0" * 11)
