@@ -71,6 +71,18 @@ struct BlockArgs {
     const KernelArgs* args;               // the launch's arguments (the roles reach them through the block: launch_args)
 };
 
+// Residency: MZD_WGS_PER_CU workgroups share a CU -- 512 / that many registers a lane, and an LDS image of at most 160 KiB / that
+// many, in the 1 280-byte steps LDS is allocated in (tools/micro/lds_granule_micro.hip).  Five: 96 registers, 32 000 bytes.
+#ifndef MZD_WGS_PER_CU
+#define MZD_WGS_PER_CU 4
+#endif
+#if defined(MZD_TFIN) || defined(MZD_STAMPS)
+constexpr uint32_t kStage = MZD_WGS_PER_CU >= 5 ? 1472 : 2048; // (the diagnostic builds' stamps take LDS too)
+#else
+constexpr uint32_t kStage = MZD_WGS_PER_CU >= 5 ? 1536 : 2048;
+#endif
+static_assert(true, ""); // K5: bytes of a staged run (mzd_k_execute.h)
+constexpr uint32_t kSeg2Bytes = MZD_WGS_PER_CU >= 5 ? 1024 : 2048; // Huffman stream segment of wavefront 2 (the others' are 2 KiB: mzd_k_huffman.h)
 constexpr uint32_t kResSymMax = 30;
 struct __attribute__((aligned(16))) Shared {
     uint8_t ring[kRingBytes + 16]; // first: at LDS offset 0 the walker's window address needs no base add
@@ -79,8 +91,8 @@ struct __attribute__((aligned(16))) Shared {
     uint64_t ll[512];
     uint64_t ml[512];
     uint64_t of[256];
-    uint8_t stage[3 * (2048 + 16)]; // K5 staging: the run being assembled and the two before it (kStage each)
-    uint8_t hseg2[2048 + 64];       // Huffman stream segment of wavefront 2 (it still decodes while the copier already uses `stage`)
+    uint8_t stage[3 * (kStage + 16)]; // K5 staging: the run being assembled and the two before it (kStage each); >= 2064 + 2112: the copying wavefront's Huffman segment lies at 2064
+    uint8_t hseg2[kSeg2Bytes + 64]; // Huffman stream segment of wavefront 2 (it still decodes while the copier already uses `stage`)
     uint32_t ll_base[36], ml_base[53]; // code -> base value (copied once from constant memory)
 #ifdef MZD_STAMPS
     uint64_t cdiag[8];
@@ -111,11 +123,17 @@ struct __attribute__((aligned(16))) Shared {
     // reading them from HBM again for each file costs a round trip per dependent load)
     struct { uint32_t id, formatted, al[3], huf_log, rep[3], content_len; const uint8_t* content; } dcache;
     struct { const uint8_t* src; uint64_t n; uint8_t* dst; uint64_t cap; uint32_t dict; } pj; // the job table entry of pre_job (read once, by pre_parse_next)
+#ifdef MZD_EXP_PADLDS // (experiment: three workgroups per CU instead of four -- how throughput follows residency)
+    uint8_t pad_[MZD_EXP_PADLDS];
+#endif
 };
 
 // The workgroup's LDS image.  File scope, so that every device function addresses it with DS
 // instructions and immediate offsets (a `Shared&` parameter would be a flat pointer).
-static_assert(sizeof(Shared) <= 40 * 1024, "four workgroups per CU");
+#ifndef MZD_EXP_PADLDS
+static_assert(sizeof(Shared) <= (128 / MZD_WGS_PER_CU) * 1280, "MZD_WGS_PER_CU workgroups per CU");
+static_assert(sizeof(((Shared*)nullptr)->stage) >= 2064 + 2048 + 64, "the copying wavefront's Huffman segment");
+#endif
 __shared__ Shared S;
 constexpr uint32_t kLdsLL = (uint32_t)offsetof(Shared, ll), kLdsML = (uint32_t)offsetof(Shared, ml), kLdsOF = (uint32_t)offsetof(Shared, of);
 constexpr uint32_t kLdsWalkDummy = (uint32_t)offsetof(Shared, walk_dummy);

@@ -14,7 +14,7 @@
 //      to HBM with coalesced 16-byte stores;
 //   4. long literal runs / matches bypass the staging buffer and are copied by all 64 lanes
 //      (overlapping matches replicate their pattern).
-constexpr uint32_t kStage = 2048;
+// (kStage, the bytes of a staged run: mzd_k_common.h)
 constexpr uint32_t kShort = 64; // longest literal run / match that goes through the staging buffer
 
 typedef __attribute__((address_space(3))) uint8_t* lds_p;

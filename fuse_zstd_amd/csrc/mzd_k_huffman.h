@@ -13,7 +13,8 @@
 //     lookup, not a walk;
 //   * a DPP scan of the symbol counts gives the output offsets, and a last pass writes.
 // A walk reads the stream through a 64-bit window loaded once per five symbols (5 * 11 bits <= 57).
-constexpr int32_t kSegBits = 64 * 248; // 31 bytes per lane: lane windows fall into different LDS banks
+constexpr int32_t kSegBits = 64 * 248; // 31 bytes per lane: lane windows fall into different LDS banks (the segment buffer: 2 KiB + 64)
+constexpr int32_t kSegBitsHalf = 64 * 120; // ... 15 bytes per lane: a segment buffer of 1 KiB + 64 (wavefront 2 with five workgroups per CU)
 
 #ifndef MZD_HUF_MINC
 #define MZD_HUF_MINC 16
@@ -21,7 +22,7 @@ constexpr int32_t kSegBits = 64 * 248; // 31 bytes per lane: lane windows fall i
 // BIG: a tree of depth 12 (L == 12), which libzstd accepts and no encoder emits: the table is indexed by the top 11 of the next 12
 // bits and two codes of length 12 share an entry (mzd_device.h: kHufEntries); four symbols per window instead of five (4 * 12 <= 57).
 template <bool BIG>
-__device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int lane) {
+__device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int32_t seg_bits, int lane) {
     if (sl == 0) return MZD_E_CORRUPT;
     uint32_t last = sp[sl - 1];
     if (last == 0) return MZD_E_CORRUPT;
@@ -32,7 +33,7 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
     int32_t pos = 0;        // bits consumed so far (wave-uniform, exact)
     uint32_t done = 0;      // symbols written so far
     while (pos < nbits) {
-        const int32_t s0 = pos, s1 = pos + kSegBits < nbits ? pos + kSegBits : nbits;
+        const int32_t s0 = pos, s1 = pos + seg_bits < nbits ? pos + seg_bits : nbits;
         // stage stream bytes [blo - 16, bhi): everything the segment can touch (16 bits of slack below it) behind a
         // 16-byte prefix, so that a window may start up to 8 bytes below the lowest byte needed; bytes below the
         // stream start read as zero (bits below bit 0 of a backward stream are zero)
@@ -160,6 +161,6 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
     if (done != nsym) return MZD_E_CORRUPT; // pos == nbits here: the stream was consumed exactly
     return 0;
 }
-__device__ __forceinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int lane) {
-    return L == 12 ? huf_stream_wave_t<true>(sp, sl, out, nsym, L, seg, lane) : huf_stream_wave_t<false>(sp, sl, out, nsym, L, seg, lane);
+__device__ __forceinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int32_t seg_bits, int lane) {
+    return L == 12 ? huf_stream_wave_t<true>(sp, sl, out, nsym, L, seg, seg_bits, lane) : huf_stream_wave_t<false>(sp, sl, out, nsym, L, seg, seg_bits, lane);
 }

@@ -60,7 +60,7 @@ template <bool TASKS> struct BlockRun {
             if (st >= streams || st >= 4) break;
             int r = 0;
             if (!__atomic_load_n(&c.err, __ATOMIC_RELAXED))
-                r = huf_stream_wave(b.blk + c.s_off[st], c.s_len[st], lbase + c.s_out[st], c.s_n[st], hl, hseg(), lane);
+                r = huf_stream_wave(b.blk + c.s_off[st], c.s_len[st], lbase + c.s_out[st], c.s_n[st], hl, hseg(), (wave == 2 && kSeg2Bytes < 2048) ? kSegBitsHalf : kSegBits, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) { post_err(&c.err, r); __atomic_fetch_or(&c.streams_mask, 1u << st, __ATOMIC_RELAXED); __atomic_fetch_add(&c.streams_done, 1u, __ATOMIC_RELAXED); }
         }
@@ -88,7 +88,7 @@ __device__ __noinline__ void role_walk(BlockRun<TASKS> r) {
     Ctl& c = S.c;
     const BlockArgs& b = r.b;
     const int lane = r.lane;
-    __builtin_amdgcn_s_setprio(MZD_PRIO_WALK); // header parse, tables and walk are one serial chain: the block's critical path
+    MZD_SETPRIO(MZD_PRIO_WALK); // header parse, tables and walk are one serial chain: the block's critical path
     if (lane == 0 && !b.block_pre) parse_seq_header(c, S.stage + 256, r.seq_len, 256);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) flag_store(&c.seq_parsed, 1);
@@ -113,9 +113,9 @@ __device__ __noinline__ void role_walk(BlockRun<TASKS> r) {
         if (lane == 0) { post_err(&c.err, rc); flag_store(&c.tables_ready, 1); }
         TFIN(5);
         if (!rc) {
-            __builtin_amdgcn_s_setprio(MZD_PRIO_WALK); // the chain is the critical path: win issue arbitration on this SIMD
+            MZD_SETPRIO(MZD_PRIO_WALK); // the chain is the critical path: win issue arbitration on this SIMD
             rc = walk_sequences_wave(b.src + r.seq_off, r.seq_len, r.nseq, b.walk, &c.walk_prog, lane);
-            __builtin_amdgcn_s_setprio(0);
+            MZD_SETPRIO(0);
         }
         if (rc == kWalkInexact) { rc = 0; if (lane == 0) c.walk_inexact = 1; } // (every record is there: the planner and the copier go on; the copier gives the verdict)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -126,10 +126,11 @@ __device__ __noinline__ void role_walk(BlockRun<TASKS> r) {
         }
         TFIN(0);
     }
-    __builtin_amdgcn_s_setprio(0);
+    MZD_SETPRIO(MZD_PRIO_HELP);
     r.huf_helper();
+    MZD_SETPRIO(0);
     if (!TASKS && b.last && b.pos0 + b.bsize + (b.hashing ? 4u : 0u) == b.n) { // this block closes the file: the next file's headers, meanwhile
-        __builtin_amdgcn_s_setprio(MZD_PRE_PRIO); pre_parse_next(*r.b.args, lane); __builtin_amdgcn_s_setprio(0);
+        MZD_SETPRIO(MZD_PRE_PRIO); pre_parse_next(*r.b.args, lane); MZD_SETPRIO(0);
     }
 }
 
@@ -171,9 +172,9 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
         if (spin_ge(&c.tables_ready, 1, &c.err)) {
             // (a task plans before its predecessor has finished: the repeat offsets at its start are unknown unless it opens the frame)
             PlanCtx px{b.walk, b.src + r.seq_off, &c.walk_prog, r.nlit, (!TASKS || b.frame_first) ? 1u : 0u, {c.rep[0], c.rep[1], c.rep[2]}, b.walk};
-            __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
+            MZD_SETPRIO(MZD_PRIO_PLAN);
             rc = plan_wave(b.seqs, r.nseq, px, lane);
-            __builtin_amdgcn_s_setprio(0);
+            MZD_SETPRIO(0);
             if (rc == kPlanBlockTooLong) rc = 0; // (not an error yet: Ctl::plan_too_long, copy_wave)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -186,7 +187,9 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
     if (TASKS && r.b.args->resolve) { // resolving launches: the repeat offsets go on to the successor as soon as this block's transform is known
         if (lane == 0) S.res[3] = rep_hop(b.fs, b.t, b.frame_first, seq_ok && r.nseq != 0 && !__atomic_load_n(&c.err, __ATOMIC_RELAXED), S.res_rep) ? 1u : 0u;
     }
+    MZD_SETPRIO(MZD_PRIO_HELP);
     r.huf_helper(); // the ring (its staging area) is free: the walker has finished before the planner does
+    MZD_SETPRIO(0);
 }
 
 // ---- waves 1 and 2: K1 Huffman table (wave 1), K2 literal streams, then the copying half of K5 (wave 1) / K7 behind it (wave 2)
@@ -204,7 +207,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
     if (phase & 1) {
     // the literals gate the copier (the tail of the block): the copying wavefront's tree + first stream run at the
     // copier's priority, the remaining streams just below
-    if (wave == 1) __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); else __builtin_amdgcn_s_setprio(MZD_PRIO_PLAN);
+    if (wave == 1) MZD_SETPRIO(MZD_PRIO_COPY); else MZD_SETPRIO(MZD_PRIO_PLAN);
     if (lit_type == 2 || (TASKS && lit_type == 3)) { // K1: the Huffman table, by wavefront 1: built from this block's tree, or (a task) inherited
         if (wave == 1) {
             int hr = 0;
@@ -248,7 +251,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
         post_err(&c.err, rc);
         __atomic_fetch_add(&c.lit_done, 1u, __ATOMIC_RELAXED);
     }
-    __builtin_amdgcn_s_setprio(0);
+    MZD_SETPRIO(0);
     if (wave == 1) TFIN(4);
     }
     if (phase == 1) { // a resolving task: these two wavefronts build the block's byte map behind the planner (mzd_k_resolve.h)
@@ -276,9 +279,9 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
             CopyCtx cx{b.seqs, dst, fstart, c.dict_content, c.dict_content_len, r.lit_in_place() ? r.place() : r.lit, nlit, b.cap, lit_type >= 2 ? streams : 0u,
                        {r0, r1, r2}, (TASKS && a.debug) ? b.seqs : nullptr};
             TFIN(9);
-            __builtin_amdgcn_s_setprio(MZD_PRIO_COPY); // second on the critical path, behind the walker
+            MZD_SETPRIO(MZD_PRIO_COPY); // second on the critical path, behind the walker
             rc = copy_wave(r.nseq, cx, &opos, lane);
-            __builtin_amdgcn_s_setprio(0);
+            MZD_SETPRIO(0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) {

@@ -145,7 +145,7 @@ __device__ __noinline__ void resolve_build_rest(uint32_t* map, const uint4* plan
 // their target with one global load, the rest is pointer jumping inside the tile -- in LDS, where a scattered read costs a
 // few cycles.  The tile lives in the front of the workgroup's LDS image (sequence ring, FSE tables, staging buffers: all
 // dead once the block's walk, plan and literals are complete).  true: no entry refers to the block any more.
-constexpr uint32_t kResTile = 6144; // entries (24 KiB)
+constexpr uint32_t kResTile = MZD_WGS_PER_CU >= 5 ? 5120 : 6144; // entries (20 / 24 KiB: what lies in front of Shared::ll_base)
 __device__ __noinline__ bool resolve_jump_tiled(uint32_t* map, uint32_t B, int tid) {
     static_assert(offsetof(Shared, ring) == 0 && offsetof(Shared, ll_base) >= kResTile * 4, "the tile overlays ring, ll, ml, of, stage, hseg2");
     uint32_t* const tile = reinterpret_cast<uint32_t*>(&S);

@@ -265,7 +265,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
         // takes issue slots from the copiers it shares its SIMD with: it yields while its own file's copier is more than kWalkYield
         // sequences behind (checked each time the assembly run returns: per KiB of bitstream).  Measured (thresholds 320 .. 2048, side by side): 400 .. 512 is best -- cfg2 +3.5 %, cfg2x8 +4 %, cfg3 +1 %; files
         // whose copier keeps up (cfg3's sequence-heavy classes) keep the walker in front.
-        if (i > kWalkYield + 64 * flag_load_u(&S.c.copy_prog)) __builtin_amdgcn_s_setprio(MZD_PRIO_WALK_YIELD); else __builtin_amdgcn_s_setprio(MZD_PRIO_WALK);
+        if (i > kWalkYield + 64 * flag_load_u(&S.c.copy_prog)) MZD_SETPRIO(MZD_PRIO_WALK_YIELD); else MZD_SETPRIO(MZD_PRIO_WALK);
         // keep the ring one group ahead of the read head
         while (st.lowest > 0 && (int32_t)Gm < st.lowest * (int32_t)(kChunk * 8) + kLook) {
             st.lowest--;
@@ -306,7 +306,7 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
 #if defined(MZD_STAMPS) && defined(MZD_EXP_WALKSTAT)
     if (lane == 0) for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = ws_[k_];
 #endif
-    __builtin_amdgcn_s_setprio(MZD_PRIO_WALK);
+    MZD_SETPRIO(MZD_PRIO_WALK);
     G = Gm + 32;
     // last sequence: extra bits only
     {

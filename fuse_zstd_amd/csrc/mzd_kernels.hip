@@ -48,6 +48,17 @@
 #ifndef MZD_PRIO_PLAN
 #define MZD_PRIO_PLAN 1
 #endif
+#ifndef MZD_LB_WAVES
+#define MZD_LB_WAVES MZD_WGS_PER_CU
+#endif
+#ifdef MZD_EXP_NOPRIO // (experiment: no s_setprio instruction at all)
+#define MZD_SETPRIO(x) ((void)0)
+#else
+#define MZD_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+#ifndef MZD_PRIO_HELP
+#define MZD_PRIO_HELP 0 // wavefronts 0 and 3 decoding literal streams once their own role is over (BlockRun::huf_helper)
+#endif
 
 namespace mzd {
 
@@ -209,7 +220,7 @@ __device__ __forceinline__ void clean_next_counters(const KernelArgs& a, int tid
 // ---- driver 1: one workgroup decodes a whole file, block after block.  Used when no file of the launch can have more
 // than one block (every output capacity <= 128 KiB): nothing is forked, nothing is published, the file's state
 // stays in registers and LDS.
-__global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs) {
+__global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_files(KernelArgs) {
     const KernelArgs& a = launch_args();
     // A workgroup's first ticket is its own index: one past the queue's end has nothing to do -- the launch behind the small-file
     // kernel when that kernel handed nothing on.  Leaving at once keeps most of the kernel's private-segment stores out of HBM (1 200
@@ -394,7 +405,7 @@ __global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_files(KernelArgs) {
 #define DEVSLOW_DECL ((void)0)
 #define DEVSLOW(k) ((void)0)
 #endif
-__global__ __launch_bounds__(kWG, 4) void mzd_decode_kernel_tasks(KernelArgs) {
+__global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_tasks(KernelArgs) {
     const KernelArgs& a = launch_args();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t slot = a.wg0 + blockIdx.x; // this workgroup's place in the scratch arrays

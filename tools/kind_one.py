@@ -17,3 +17,4 @@ for rep in range(6):
 got = dout.cpu().numpy()
 ok = all(j.status == 0 for j in jobs) and all(bytes(got[int(cp.raw_offs[i]):int(cp.raw_offs[i]) + size]) == cp.raw_file(i).tobytes() for i in range(0, n, 17))
 print("%s x %d: ok=%s kernel ms %s (%s)" % (kind, n, ok, " ".join("%.3f" % m for m in ms), mzd.last_kernel_name(0)), flush=True)
+print("workgroups of the last launch (counter word 6):", mzd.debug_counters(0)[6], flush=True)
