@@ -6,6 +6,7 @@ if os.environ.get('MZD_AB_SO'): _api._SO = os.path.join(os.path.dirname(_api._SO
 import fuse_zstd_amd as mzd, corpus
 import torch
 mzd.init()
+if os.environ.get("MZD_DRIVER"): mzd.set_driver(int(os.environ["MZD_DRIVER"]))  # (mzd_debug_set_driver: 1 a workgroup per file, 2 block tasks, 4 ... all resolved ahead, 5 ... none)
 kind = sys.argv[1]; n = int(sys.argv[2]); size = int(sys.argv[3]) if len(sys.argv) > 3 else 131072
 cp = corpus.build_corpus(kind, 3, [size] * n)
 dcomp = torch.from_numpy(cp.comp).cuda()
