@@ -10,7 +10,7 @@ independent 4 KiB JSON files written like the reference's writer (level 3, check
 configs[1] (1 000 x 128 KiB single-block frames: `cfg2`) is the first of `other_workloads`.  With N GPUs every rank takes
 files r, r+N, r+2N, ... of an N x 10 000-file corpus (file i -> GPU i mod N, no collective; weak scaling).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg3|cfg4lu|cfg5|big1m|...] [--files F]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg3|cfg4lu|cfg5|big1m|cfgmid|...] [--files F]
                   [--no-others] [--no-t2] [--no-cpu-baseline]
 
 ONE JSON line (rank 0).  `value` is T1 of SURVEY.md 8d: inputs in HBM when the timed region starts, outputs left in
@@ -61,10 +61,12 @@ WORKLOADS = {
     "cfg2x8": ("json", 2, 0, "8 000 x 128 KiB single-block JSON frames (cfg2's generator, eight times the files: the sustained single-block rate)"),
     "cfg4x4": ("json", 4, 0, "40 000 x 4 KiB JSON files (cfg4's generator, four times the files: the sustained small-file rate)"),
     "cfg3x8": ("text", 3, 7, "8 000 x 128 KiB frames of cfg3's seven-class mix (eight times the files: chains of very different length, handed out longest first)"),
+    # between the two kernels' sweet spots: too big for the small-file kernel (> 8 KiB), every file a single block or two
+    "cfgmid": ("json", 4, 0, "10 000 JSON files log-uniform 8 KiB..128 KiB (above the small-file kernel's limit, at most one block: a workgroup per file, ten rounds)"),
     # few big files: every file's blocks on different workgroups (the block-task driver)
     "big1m": ("json", 1, 0, "400 x 1 MiB JSON files of eight blocks each, level 3, checksum (BASELINE configs[0]'s file, 400 of them: block tasks)"),
 }
-DEFAULT_FILES = {"cfg2": 1000, "cfg3": 1000, "cfg4": 10000, "cfg4lu": 10000, "cfg5": 50000, "cfg2x8": 8000, "cfg4x4": 40000, "cfg3x8": 8000, "big1m": 400}
+DEFAULT_FILES = {"cfg2": 1000, "cfg3": 1000, "cfg4": 10000, "cfg4lu": 10000, "cfg5": 50000, "cfg2x8": 8000, "cfg4x4": 40000, "cfg3x8": 8000, "big1m": 400, "cfgmid": 10000}
 
 
 def file_sizes(workload, nfiles, rank, world):
@@ -74,6 +76,10 @@ def file_sizes(workload, nfiles, rank, world):
         return [4096] * nfiles
     if workload == "big1m":
         return [1 << 20] * nfiles
+    if workload == "cfgmid":
+        rng = np.random.RandomState(4321)
+        allsz = np.exp(rng.uniform(np.log(8193), np.log(131072), size=nfiles * world)).astype(np.int64)
+        return [int(x) for x in allsz[rank::world]]
     if workload == "cfg5":
         rng = np.random.RandomState(55)
         allsz = rng.randint(300, 3001, size=nfiles * world)
@@ -572,11 +578,11 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_others:
             others = {}
-            for name in ("cfg2", "cfg4", "cfg3", "cfg4lu", "cfg5", "big1m", "cfg2x8", "cfg4x4", "cfg3x8"):
+            for name in ("cfg2", "cfg4", "cfg3", "cfg4lu", "cfg5", "big1m", "cfgmid", "cfg2x8", "cfg4x4", "cfg3x8"):
                 if name == args.workload:
                     continue
                 ow = Workload(name, DEFAULT_FILES[name], 0, 1, args.level, dev, mzd, corpus)
-                steps = 10 if name not in ("cfg4lu", "cfg2x8", "cfg3x8", "big1m") else 6
+                steps = 10 if name not in ("cfg4lu", "cfg2x8", "cfg3x8", "big1m", "cfgmid") else 6
                 el, kms = time_t1(ow, steps, 2, stream, local_fence)
                 ach = (ow.C + ow.U) / (kms * 1e-3) / 1e9
                 others[name] = {"workload": ow.desc, "files": ow.nfiles, "value": round(ow.U * steps / el / GIB, 3), "unit": "GiB/s",

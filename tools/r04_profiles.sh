@@ -2,12 +2,13 @@
 # Round-4 profile set (on the GPU box, from the repo root): bash tools/r04_profiles.sh
 # Per workload: rocprofv3 kernel stats + FETCH_SIZE / WRITE_SIZE passes (tools/rocprof.sh), then instruction counters (tools/pmc.sh).
 export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8
-for w in cfg4 cfg2 cfg5 cfg3 cfg4lu big1m cfg2x8 cfg4x4 cfg3x8; do
+for w in cfg4 cfg2 cfg5 cfg3 cfg4lu big1m cfgmid cfg2x8 cfg4x4 cfg3x8; do
   extra=""
   [ "$w" = cfg4lu ] && extra="--steps 6 --warmup 2"
   [ "$w" = cfg2x8 ] && extra="--steps 6 --warmup 2"
   [ "$w" = cfg3x8 ] && extra="--steps 6 --warmup 2"
   [ "$w" = big1m ] && extra="--steps 6 --warmup 2"
+  [ "$w" = cfgmid ] && extra="--steps 6 --warmup 2"
   bash tools/rocprof.sh r04_$w --workload $w $extra > gpurun_out/r04_prof_$w.log 2>&1 || echo "rocprof.sh $w failed"
   echo "done $w"
 done
