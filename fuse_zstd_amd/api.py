@@ -17,7 +17,7 @@ CONTENTSIZE_ERROR = 2**64 - 2
 EXPORTS = [
     "mzd_init", "mzd_init_ex", "mzd_shutdown", "mzd_device_count", "mzd_content_size", "mzd_content_bound", "mzd_decode", "mzd_decode_batch",
     "mzd_decode_batch_device", "mzd_batch_prepare", "mzd_batch_launch", "mzd_batch_collect", "mzd_batch_free",
-    "mzd_load_dict", "mzd_unload_dict", "mzd_debug_last_block", "mzd_debug_set_driver", "mzd_debug_counters", "mzd_debug_host_path", "mzd_debug_stamps", "mzd_debug_small_stamps", "mzd_debug_small_scratch", "mzd_debug_tfin_all", "mzd_debug_lazy_plan",
+    "mzd_load_dict", "mzd_unload_dict", "mzd_debug_last_block", "mzd_debug_set_driver", "mzd_debug_counters", "mzd_debug_host_path", "mzd_debug_stamps", "mzd_debug_small_stamps", "mzd_debug_small_wg_stamps", "mzd_debug_small_scratch", "mzd_debug_tfin_all", "mzd_debug_lazy_plan",
     "mzd_host_alloc", "mzd_host_free", "mzd_last_kernel_ms", "mzd_last_kernel_name", "mzd_strerror", "mzd_version",
     "mzd_fs_new", "mzd_fs_free", "mzd_fs_open", "mzd_fs_open_lazy", "mzd_fs_read", "mzd_fs_release", "mzd_fs_decode_count", "mzd_fs_decoded_bytes",
 ]

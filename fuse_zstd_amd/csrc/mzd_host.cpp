@@ -173,7 +173,7 @@ int init_device(Device& d, int hip_id, int index, const InitCfg& cfg) {
     HIPCHK(hipMalloc(&d.walk_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
     HIPCHK(hipMalloc(&d.small_lit, d.small_lit_total));
     if (cfg.resolve_ahead) HIPCHK(hipMalloc(&d.resolve_map, (size_t)d.max_wg * kResMapStride * sizeof(uint32_t)));
-    const size_t debug_bytes = std::max<size_t>((size_t)d.max_wg * sizeof(DebugSlot), 1032 * sizeof(uint64_t)); // (diagnostic builds of the small-file kernel keep 1 032 stamps there: mzd_debug_small_stamps)
+    const size_t debug_bytes = std::max<size_t>((size_t)d.max_wg * sizeof(DebugSlot), (2048 + 16 * 3072) * sizeof(uint64_t)); // (diagnostic builds of the small-file kernel keep 1 032 stamps there: mzd_debug_small_stamps)
     HIPCHK(hipMalloc(&d.debug, debug_bytes));
     HIPCHK(hipMemset(d.debug, 0, debug_bytes));
     HIPCHK(hipMalloc(&d.counters, 2 * (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
@@ -349,23 +349,34 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
                 const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(g, xg, p.with_dict, tab, p.lds_comp, p.lds_out), kLdsGranule);
                 return lds > kLdsPerCu ? 0u : std::min<uint32_t>(lds_waves_by_registers(g, xg, p.with_dict), kLdsPerCu / lds);
             };
-            auto split_plan = [&](uint32_t& tab) -> bool { // G = 8, XG = 4 in one round?
+            auto one_round = [&](int g, int xg, uint32_t& tab) -> bool { // does the launch fit ONE round of groups of g files executed xg at a time?
                 if (p.with_dict || cus == 0) return false;
-                const uint32_t w = (uint32_t)((p.nsmall + 8ull * cus - 1) / (8ull * cus));
-                if (w < 1 || w > 8) return false;
+                const uint32_t w = (uint32_t)((p.nsmall + (uint64_t)g * cus - 1) / ((uint64_t)g * cus)); // wavefronts per CU
+                if (w < 1 || w > lds_waves_by_registers(g, xg, 0)) return false;
                 const uint32_t budget = kLdsPerCu / w / kLdsGranule * kLdsGranule;
-                const uint32_t fixed = lds_kernel_bytes(8, 4, 0, 0, 0, 0) - 8 * lds_kernel_bytes_per_file(0, 0); // the wavefront's tables and the files' records
-                if (budget < fixed + 4 * p.lds_out) return false;
-                const uint32_t per_file = (budget - fixed) / 8;                       // tables + (counts, work, input)
+                const uint32_t fixed = lds_kernel_bytes(g, xg, 0, 0, 0, 0) - (uint32_t)g * lds_kernel_bytes_per_file(0, 0); // the wavefront's tables and the files' records
+                if (budget < fixed + (uint32_t)xg * p.lds_out) return false;
+                const uint32_t per_file = (budget - fixed) / (uint32_t)g;            // tables + (counts, work, input)
                 const uint32_t rest = lds_kernel_bytes_per_file(0, p.lds_comp);      // (counts, work, input)
                 if (per_file < rest + 1792u) return false;
                 tab = std::min<uint32_t>(p.lds_tab, (per_file - rest) & ~15u);
-                return waves_per_cu(8, 4, tab) >= w;
+                return waves_per_cu(g, xg, tab) >= w;
             };
             uint32_t split_tab = 0;
-            if (p.nsmall > (uint64_t)cus * waves_per_cu(4, 4, p.lds_tab) * 4 && split_plan(split_tab)) { p.lds_g = 8; p.lds_xg = 4; p.lds_tab = split_tab; }
+            if (p.nsmall > (uint64_t)cus * waves_per_cu(4, 4, p.lds_tab) * 4) {
+                // (8 / 4 first.  4 / 2 -- ten wavefronts of four files per CU, each file executed by 32 lanes -- was built and measured in
+                //  round 5: its groups are shorter (a group's median 281 us against 8 / 4's 254 on one workgroup alone) but ten wavefronts
+                //  share a CU's LDS pipeline and two SIMDs hold three of them: the slowest wavefront ends at 330 us, 8 / 4's at 297
+                //  (tools/lds_wg.py, profiles/r05_lds_wg_*.txt).  It stays for launches 8 / 4 cannot hold in one round.)
+                if (one_round(8, 4, split_tab)) { p.lds_g = 8; p.lds_xg = 4; p.lds_tab = split_tab; }
+                else if (one_round(4, 2, split_tab)) { p.lds_g = 4; p.lds_xg = 2; p.lds_tab = split_tab; }
+            }
             const int dbg_g = g_small_g.load(std::memory_order_relaxed), dbg_xg = g_small_xg.load(std::memory_order_relaxed); // (mzd_debug_host_path 4 / 5)
-            if (dbg_g == 4 || dbg_g == 8 || dbg_g == 16) { p.lds_g = dbg_g; p.lds_xg = (dbg_xg == 4 && dbg_g == 8 && !p.with_dict) ? 4 : dbg_g; }
+            if (dbg_g == 4 || dbg_g == 8 || dbg_g == 16) {
+                p.lds_g = dbg_g; p.lds_xg = (dbg_xg == 4 && dbg_g == 8 && !p.with_dict) ? 4 : ((dbg_xg == 2 && dbg_g == 4 && !p.with_dict) ? 2 : dbg_g);
+                p.lds_tab = (p.with_dict && all_dict) ? lds_spare_table_bytes(p.lds_comp, p.lds_out) : (maxcap <= 5120 ? 2048u : 4096u);
+                if (p.lds_g != p.lds_xg && one_round(p.lds_g, p.lds_xg, split_tab)) p.lds_tab = split_tab;
+            }
             while (p.lds_g > 4 && lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out) > kLdsPerCu) { p.lds_g /= 2; p.lds_xg = p.lds_g; }
         }
     }
@@ -1271,6 +1282,13 @@ int mzd_debug_small_scratch(int device, uint32_t slot, uint8_t* lit, size_t lit_
 }
 
 // Diagnostic (a build with -DMZD_SMALL_STAMPS): the 8 phase stamps of the small-file kernel's workgroup 0.
+int mzd_debug_small_wg_stamps(int device, uint64_t* out, int n) { // (diagnostic builds: per-workgroup entry / exit clocks of the small-file kernel, 16 values each)
+    auto dp = get_device(device);
+    if (!dp || !out || n < 0 || n > 3072) return MZD_E_PARAM;
+    HIPCHK(hipSetDevice(dp->hip_id));
+    HIPCHK(hipMemcpy(out, (uint64_t*)dp->debug + 2048, (size_t)n * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return MZD_OK;
+}
 int mzd_debug_small_stamps(int device, uint64_t* out8) { // (64 values; 32..47: files that left the fast path, by reason)
     auto dp = get_device(device);
     if (!dp || !out8) return MZD_E_PARAM;

@@ -5,7 +5,7 @@
 // (benchmarks/parallel-files.fio:3-7: thousands of files of a few KiB).  A wavefront takes a GROUP of G files and gives
 // each LPF = 64 / G lanes.  A file's LDS slot is used twice:
 //
-//     entropy phase:   [ tables | ring | compressed input ]        execute phase:   [ output window ]
+//     entropy phase:   [ ring | tables | compressed input ]        execute phase:   [ output window ]
 //
 //   * the compressed file is copied into the slot once, 16 bytes per lane (coalesced); every parser and bit reader
 //     works on LDS bytes;
@@ -98,21 +98,35 @@ constexpr uint32_t kAux = 256;    // per file: the normalized counts of the thre
 // scratch of the Huffman weights: their FSE table [64 x 8] | its counts
 constexpr uint32_t kWTab = 0, kWNorm = 512, kWStage = 576; // (the weights' bitstream behind 16 zero bytes: 576 .. 720) // in the table area, which the Huffman table takes over once the weights are decoded; the weights themselves: the ring
 
-// ---- the file's LPF lanes (LPF = 16, 8 or 4: inside one DPP row of 16 lanes)
-// the value of the lane N below, 0 for the file's first N lanes
+// ---- the file's LPF lanes (LPF = 16, 8 or 4: inside one DPP row of 16 lanes; LPF = 32: two rows)
+// the value of the lane N below, 0 for the first N lanes of the file (LPF = 32: of each of its rows -- seg_scan_add carries over)
 template <int N, int LPF> DI uint32_t seg_shr(uint32_t v, uint32_t sub) {
     const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xF, 0xF, false); // row_shr:N
-    return (LPF == 16 || sub >= (uint32_t)N) ? t : 0u;
+    return (LPF >= 16 || sub >= (uint32_t)N) ? t : 0u;
+}
+// inclusive prefix sum over the file's lanes
+template <int LPF> DI uint32_t seg_scan_add(uint32_t v, uint32_t sub) {
+    v += seg_shr<1, LPF>(v, sub); v += seg_shr<2, LPF>(v, sub);
+    if (LPF > 4) v += seg_shr<4, LPF>(v, sub);
+    if (LPF > 8) v += seg_shr<8, LPF>(v, sub);
+    if (LPF > 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3: the total of the file's lower row
+    return v;
 }
 // the value of the file's lane K, in all its lanes
 template <int K, int LPF> DI uint32_t bcast(uint32_t v) {
-    if (LPF == 16) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 + K, 0xF, 0xF, false); // row_newbcast:K
+    if (LPF == 32) { // (two rows: through scalar registers)
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, K), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 32 + K);
+        uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(lo), "v"(hi), "s"(0xFFFFFFFF00000000ull)); return r; // (one scalar operand per instruction: the values go through vector registers)
+    }
+    if (LPF == 16) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 + (K & 15), 0xF, 0xF, false); // row_newbcast:K
     if (LPF == 8) {
         const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x150 + (K & 7), 0xF, 0x3, false);
         return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x150 + 8 + (K & 7), 0xF, 0xC, false);
     }
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, (K & 3) * 0x55, 0xF, 0xF, false); // quad_perm: [K, K, K, K]
 }
+// a file's share of a ballot
+template <int LPF> DI uint32_t file_bits(uint64_t ballot, uint32_t f) { return (uint32_t)(ballot >> (f * LPF)) & (uint32_t)((1ull << LPF) - 1); }
 // Lane masks and selects that stay selects: left to itself the compiler turns a chain of `c == k ? a : b` into exec-mask
 // branch regions (two or three scalar instructions and a branch each; on a lone wavefront every one of them costs an issue slot)
 typedef uint64_t lmask;
@@ -124,19 +138,36 @@ DI lmask m_lt(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 36);
 DI lmask m_le(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 37); }
 DI uint32_t sel(lmask m, uint32_t t, uint32_t f) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m)); return r; }
 // ---- repeat offsets (A.5) as a scan.  The state before a sequence is three REFERENCES: to one of the three offsets the step
-// started with (0, 1, 2) or to the offset value a sequence of the step brought along (0x10 | its lane in the file).  A sequence is
-// a transform of that triple -- a new offset: (own, s0, s1); "repeat 0": identity; 1: (s1, s0, s2); 2: (s2, s0, s1) -- kept as
-// three bytes, and composing two of them is one byte permute: the later one's bytes select among the earlier one's, except where
-// they are constants.  ("repeat 0 minus one" makes a new VALUE out of a reference: steps that hold one take the serial form.)
+// started with (0, 1, 2) or to the offset value a sequence of the step brought along (flag | its lane in the file; the flag is
+// 0x10, 0x20 with 32 lanes a file).  A sequence is a transform of that triple -- a new offset: (own, s0, s1); "repeat 0": identity;
+// 1: (s1, s0, s2); 2: (s2, s0, s1) -- kept as three bytes, and composing two of them is one byte permute: the later one's bytes
+// select among the earlier one's, except where they are constants.  ("repeat 0 minus one" makes a new VALUE out of a reference:
+// steps that hold one take the serial form.)
 constexpr uint32_t kRepId = 0x03020100u;
-DI uint32_t rep_compose(uint32_t later, uint32_t earlier) {
+template <int LPF> struct RepRef { static constexpr uint32_t flag = LPF > 16 ? 0x20u : 0x10u, sh = LPF > 16 ? 5u : 4u; };
+template <int LPF> DI uint32_t rep_compose(uint32_t later, uint32_t earlier) {
     const uint32_t p = __builtin_amdgcn_perm(0u, earlier, later);
-    const uint32_t mask = ((later & 0x00101010u) >> 4) * 0xFFu;
+    const uint32_t mask = ((later & (RepRef<LPF>::flag * 0x00010101u)) >> RepRef<LPF>::sh) * 0xFFu;
     return (later & mask) | (p & ~mask);
 }
-template <int N, int LPF> DI uint32_t rep_shr(uint32_t v, uint32_t sub) { // the transform of the lane N below, the identity for the file's first N lanes
+template <int N, int LPF> DI uint32_t rep_shr(uint32_t v, uint32_t sub) { // the transform of the lane N below, the identity for the first N lanes of the file (LPF = 32: of each row)
     const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)kRepId, (int)v, 0x110 + N, 0xF, 0xF, false);
-    return (LPF == 16 || sub >= (uint32_t)N) ? t : kRepId;
+    return (LPF >= 16 || sub >= (uint32_t)N) ? t : kRepId;
+}
+// inclusive scan of the transforms over the file's lanes
+template <int LPF> DI uint32_t rep_scan(uint32_t P, uint32_t sub) {
+    P = rep_compose<LPF>(P, rep_shr<1, LPF>(P, sub));
+    P = rep_compose<LPF>(P, rep_shr<2, LPF>(P, sub));
+    if (LPF > 4) P = rep_compose<LPF>(P, rep_shr<4, LPF>(P, sub));
+    if (LPF > 8) P = rep_compose<LPF>(P, rep_shr<8, LPF>(P, sub));
+    if (LPF > 16) P = rep_compose<LPF>(P, (uint32_t)__builtin_amdgcn_update_dpp((int)kRepId, (int)P, 0x142, 0xA, 0xF, false)); // (row_bcast:15: the lower row's composition)
+    return P;
+}
+// the scan's value one lane down: the state before this lane's sequence (the identity for the file's first lane)
+template <int LPF> DI uint32_t rep_before(uint32_t P, uint32_t sub) {
+    if (LPF <= 16) return rep_shr<1, LPF>(P, sub);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)kRepId, (int)P, 0x138, 0xF, 0xF, false); // wave_shr:1
+    return sub >= 1u ? t : kRepId;
 }
 
 // n (<= 31) bytes, held in d[0..7], to LDS offset `at`: exact pieces of 16 / 8 / 4 / 2 / 1; a lane without a piece stores to `dump`
@@ -152,6 +183,33 @@ DI void store_exact31(uint32_t at, uint32_t n, uint32_t d0, uint32_t d1, uint32_
     lds_s16(sel(m2, at, dump), d0);
     d0 = sel(m2, d0 >> 16, d0); at += n & 2;
     L8(sel(m1, at, dump)) = (uint8_t)d0;
+}
+// the same in two parts, so that a wavefront none of whose lanes holds 16 bytes or more skips the upper read and the first two stores:
+// store_piece16 takes the 16-byte piece (n & 16) from lo and moves hi down; store_exact15 stores n & 15 bytes held in d[0..3]
+DI void store_piece16(uint32_t& at, uint32_t n, uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3, uint32_t dump) {
+    const lmask m16 = m_ne(n & 16, 0);
+    lds_s64(sel(m16, at, dump), (uint64_t)d0 | ((uint64_t)d1 << 32)); lds_s64(sel(m16, at + 8, dump), (uint64_t)d2 | ((uint64_t)d3 << 32));
+    d0 = sel(m16, h0, d0); d1 = sel(m16, h1, d1); d2 = sel(m16, h2, d2); d3 = sel(m16, h3, d3); at += n & 16;
+}
+DI void store_exact15(uint32_t at, uint32_t n, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t dump) {
+    const lmask m8 = m_ne(n & 8, 0), m4 = m_ne(n & 4, 0), m2 = m_ne(n & 2, 0), m1 = m_ne(n & 1, 0);
+    lds_s64(sel(m8, at, dump), (uint64_t)d0 | ((uint64_t)d1 << 32));
+    d0 = sel(m8, d2, d0); d1 = sel(m8, d3, d1); at += n & 8;
+    lds_s32(sel(m4, at, dump), d0);
+    d0 = sel(m4, d1, d0); at += n & 4;
+    lds_s16(sel(m2, at, dump), d0);
+    d0 = sel(m2, d0 >> 16, d0); at += n & 2;
+    L8(sel(m1, at, dump)) = (uint8_t)d0;
+}
+// the minimum over the file's lanes, in all of them: DPP swaps inside quads, half rows and rows (no trip through the LDS crossbar
+// but for the second row of 32 lanes)
+template <int LPF> DI uint32_t seg_min(uint32_t x, uint32_t lane) {
+    x = min(x, (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, false)); // quad_perm: [1, 0, 3, 2]
+    x = min(x, (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, false)); // quad_perm: [2, 3, 0, 1]
+    if (LPF >= 8) x = min(x, (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, false)); // row_half_mirror
+    if (LPF >= 16) x = min(x, (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xF, 0xF, false)); // row_mirror
+    if (LPF >= 32) x = min(x, (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ 16u) * 4u), (int)x));
+    return x;
 }
 template <int N, class F> DI void static_for(F&& f) {
     if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
@@ -257,7 +315,7 @@ DI uint64_t xxh_tail(uint64_t hh, uint32_t q, uint32_t end) {
 
 // Diagnostic build only (-DMZD_SMALL_STAMPS): cycle counter of workgroup 0 at every phase boundary of its first group.
 #ifdef MZD_SMALL_STAMPS
-#define SSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) a.stamps[k] = __builtin_readcyclecounter(); } while (0)
+#define SSTAMP(k) do { if (a.stamps && lane == 0 && first_group) { if (blockIdx.x == 0) a.stamps[k] = __builtin_readcyclecounter(); if ((k) < 12 && blockIdx.x < 3072) a.stamps[2048 + 16 * blockIdx.x + 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define SSTAMP(k)
 #endif
@@ -279,6 +337,7 @@ __device__ __noinline__ void rare_match(uint32_t outo, uint32_t mp, uint32_t off
         for (uint32_t q = sub; q < m; q += LPF) { const uint32_t v = L8(outo + mp - off + q); asm volatile("" ::: "memory"); L8(outo + mp + q) = (uint8_t)v; asm volatile("" ::: "memory"); }
     } else { // period < LPF: every lane repeats one byte of the pattern
         uint32_t rr = sub; // sub mod off
+        if (LPF > 16 && rr >= 16 * off) rr -= 16 * off;
         if (rr >= 8 * off) rr -= 8 * off;
         if (rr >= 4 * off) rr -= 4 * off;
         if (rr >= 2 * off) rr -= 2 * off;
@@ -366,11 +425,11 @@ struct DictInfo { // the dictionary whose image sits in LDS (wave-uniform)
 // 4 KiB (3.9 KB each) fit where only four windows (4.1 KB each) do, so five wavefronts per CU hold 40 files -- 10 240 on the
 // device -- instead of 32.  What an execution pass needs to know about a file crosses over in a 32-byte record in LDS.
 template <int G, bool DICT, int XG>
-__global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(LdsArgs a) {
+__global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(LdsArgs a) {
     constexpr uint32_t LPF = 64 / G; // lanes per file in the entropy phases
     constexpr uint32_t XLPF = 64 / XG, NX = G / XG; // lanes per file = sequences per plan step in the execution; passes
     static_assert(LPF >= 4, "four Huffman streams");
-    static_assert(XLPF >= 4 && XLPF <= 16 && G % XG == 0, "four XXH64 accumulators; a file's lanes inside one DPP row");
+    static_assert(XLPF >= 4 && XLPF <= 32 && G % XG == 0, "four XXH64 accumulators; a file's lanes inside one DPP row, or two (the scans carry over)");
     const uint32_t lane = threadIdx.x;
     const uint32_t f = lane / LPF, sub = lane % LPF;
     const bool leader = sub == 0;
@@ -379,8 +438,11 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
     const uint32_t ent = a.tab_bytes + kAux + a.comp_bytes;                // the entropy phase's image of a file ...
     const uint32_t stride = G != XG ? ent : (ent > a.out_bytes ? ent : a.out_bytes); // ... and (XG == G) its output window share the slot
     const uint32_t slots0 = kShAll + (DICT ? kDictImg : 0u);
-    const uint32_t tabo = slots0 + f * stride;                             // the file's slot
-    const uint32_t ringo = tabo + a.tab_bytes, cmp = ringo + kAux;
+    // the file's slot: [ counts, later walk records | tables | compressed input ].  The tables sit right in front of the input: the
+    // sequence tables are built when the literals are decoded, so they may grow over the input's dead front -- everything up to
+    // the sequences section -- and a launch whose slots leave less than three full tables' room still keeps its files
+    const uint32_t ringo = slots0 + f * stride;
+    const uint32_t tabo = ringo + kAux, cmp = tabo + a.tab_bytes;
     // the file's share of the scratch in HBM: literals, then the sequences (8 bytes each)
     uint8_t* const lit_g = a.scratch + (size_t)(blockIdx.x * G + f) * ((size_t)a.lit_stride + 8u * (size_t)a.seq_cap);
     uint8_t* const seq_g = lit_g + a.lit_stride;
@@ -421,6 +483,12 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
 #pragma unroll
         for (int k = 0; k < kPF; k++) { const uint32_t o = 16 * (sub + LPF * (uint32_t)k); pf[k] = o < J.n ? gv16(J.src + o) : V16{0, 0}; }
     };
+#ifdef MZD_SMALL_STAMPS
+    // every workgroup: [real-time clock (100 MHz) at entry, at exit, HW_ID | XCC_ID << 32, groups taken] from stamp 2048 on
+    const uint64_t wg_t0_ = __builtin_amdgcn_s_memrealtime();
+    uint32_t wg_groups_ = 0, wg_rounds_ = 0, wg_steps_ = 0;
+    uint64_t wg_te_ = 0;
+#endif
     uint32_t g = ticket();
     JobRegs J = job_entry(list_entry(g));
     V16 pf[kPF];
@@ -895,7 +963,7 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                         if (t == 0) { tabL = tab; alL = al; } else if (t == 1) { tabO = tab; alO = al; } else { tabM = tab; alM = al; }
                         modes3 |= m << (2 * t); rle_syms |= rs << (8 * t); nsyms |= ns << (8 * t);
                     }
-                    if (tbad || used_entries * 8 > a.tab_bytes) break;
+                    if (tbad || used_entries * 8 > ((a.tab_bytes + seq_off) & ~15u)) break; // (the table area and the input in front of the sequences section: dead by now)
                     if (p >= seq_len) break; // the bitstream needs at least one byte
                     bs_off = seq_off + p; bs_len = seq_len - p;
                     good = 1;
@@ -1063,6 +1131,9 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
         wsync();
         SSTAMP(7);
       }
+#ifdef MZD_SMALL_STAMPS
+      if (first_group) wg_te_ = __builtin_amdgcn_s_memrealtime(); // (the entropy phases end)
+#endif
       for (uint32_t pass = 0; pass < NX; pass++) {
         // =============================== an execution pass: XG of the group's files, XLPF lanes each (the names of the entropy phases, for this pass's files)
         constexpr uint32_t LPF = XLPF;
@@ -1121,14 +1192,10 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
             auto stage_a = [&](uint64_t rec, StepA& A) {
                 uint32_t ll = (uint32_t)rec & 0x3FFF, ml = ((uint32_t)rec >> 14) & 0x3FFF;
                 const uint32_t ofv = (uint32_t)(rec >> 32);
-                uint32_t il = ll, it = ll + ml;
-                il += seg_shr<1, LPF>(il, sub); it += seg_shr<1, LPF>(it, sub);
-                il += seg_shr<2, LPF>(il, sub); it += seg_shr<2, LPF>(it, sub);
-                if (LPF > 4) { il += seg_shr<4, LPF>(il, sub); it += seg_shr<4, LPF>(it, sub); }
-                if (LPF > 8) { il += seg_shr<8, LPF>(il, sub); it += seg_shr<8, LPF>(it, sub); }
+                const uint32_t il = seg_scan_add<LPF>(ll, sub), it = seg_scan_add<LPF>(ll + ml, sub);
                 A.lp = lpos + il - ll; A.op = opos + it - ll - ml; // this sequence's literals / its output
                 const uint64_t pm = __ballot((A.lp + ll > nlit) | (A.op + ll + ml > cap)); // literals left, room in the destination (A.5)
-                if ((pm >> (f * LPF)) & ((1ull << LPF) - 1)) { xbad = true; ll = 0; ml = 0; if (!why) why = 7; }
+                if (file_bits<LPF>(pm, f)) { xbad = true; ll = 0; ml = 0; if (!why) why = 7; }
                 if (xbad) { ll = 0; ml = 0; } // (nothing more of this file is executed)
                 A.ll = ll; A.ml = ml;
                 A.w0 = (ll | ml) == 0 ? 0u : (ofv > 3 ? 4u | ((ofv - 3) << 3) : ofv - 1 + (ll == 0 ? 1u : 0u)); // repeat code (0..3; 4 = a new offset) | (offset value - 3) << 3
@@ -1136,7 +1203,7 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                 lpos += A.chunk_l; opos += A.chunk_t;
             };
 #ifdef MZD_SMALL_STAMPS
-            uint64_t xa_ = 0, xr_ = 0, xl_ = 0, xm_ = 0, xn_ = 0, x0_ = __builtin_readcyclecounter(), x1_ = 0;
+            uint64_t xa_ = 0, xr_ = 0, xl_ = 0, xm_ = 0, xn_ = 0, xf_ = 0, xc_ = 0, xq_ = 0, xrare_ = 0, x0_ = __builtin_readcyclecounter(), x1_ = 0;
 #define XSTAMP(acc) do { x1_ = __builtin_readcyclecounter(); acc += x1_ - x0_; x0_ = x1_; } while (0)
 #else
 #define XSTAMP(acc)
@@ -1147,6 +1214,9 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
             for (uint32_t c0 = 0; c0 < nrun; c0 += LPF) {
                 const uint64_t recC = load_rec(c0 + 2 * LPF);
                 StepA nxt;
+#ifdef MZD_SMALL_STAMPS
+                wg_steps_++;
+#endif
                 XSTAMP(xm_);
                 stage_a(recB, nxt);
                 recB = recC;
@@ -1158,22 +1228,21 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                 const uint32_t c = w0 & 7, pushv = w0 >> 3;
                 uint32_t off;
                 if (__ballot(c == 3) == 0) { // the scan over references
-                    const uint32_t T = sel(m_eq(c, 4), 0x03010010u | sub, sel(m_eq(c, 0), kRepId, sel(m_eq(c, 1), 0x03020001u, 0x03010002u)));
+                    const uint32_t T = sel(m_eq(c, 4), (0x03010000u | RepRef<LPF>::flag) | sub, sel(m_eq(c, 0), kRepId, sel(m_eq(c, 1), 0x03020001u, 0x03010002u)));
                     uint32_t P = T;
-                    P = rep_compose(P, rep_shr<1, LPF>(P, sub));
-                    P = rep_compose(P, rep_shr<2, LPF>(P, sub));
-                    if (LPF > 4) P = rep_compose(P, rep_shr<4, LPF>(P, sub));
-                    if (LPF > 8) P = rep_compose(P, rep_shr<8, LPF>(P, sub));
-                    const uint32_t Ex = rep_shr<1, LPF>(P, sub); // the state before this sequence
+                    P = rep_scan<LPF>(P, sub);
+                    const uint32_t Ex = rep_before<LPF>(P, sub); // the state before this sequence
                     const uint32_t PL = bcast<LPF - 1, LPF>(P);  // ... and behind the step's last
-                    auto resolve = [&](uint32_t ref) -> uint32_t {
-                        const uint32_t vc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~(LPF - 1)) | (ref & (LPF - 1))) * 4), (int)pushv);
+                    // (the four trips through the crossbar are requested together: one wait)
+                    auto fetch = [&](uint32_t ref) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~(LPF - 1)) | (ref & (LPF - 1))) * 4), (int)pushv); };
+                    auto pick = [&](uint32_t ref, uint32_t vc) -> uint32_t {
                         const uint32_t vi = sel(m_eq(ref, 0), rep0, sel(m_eq(ref, 1), rep1, rep2));
-                        return sel(m_ne(ref & 0x10, 0), vc, vi);
+                        return sel(m_ne(ref & RepRef<LPF>::flag, 0), vc, vi);
                     };
-                    const uint32_t mine = resolve((Ex >> (8 * (c & 3))) & 0xFF);
-                    off = sel(m_eq(c, 4), pushv, mine);
-                    const uint32_t n0 = resolve(PL & 0xFF), n1 = resolve((PL >> 8) & 0xFF), n2 = resolve((PL >> 16) & 0xFF);
+                    const uint32_t rm = (Ex >> (8 * (c & 3))) & 0xFF, r0 = PL & 0xFF, r1 = (PL >> 8) & 0xFF, r2 = (PL >> 16) & 0xFF;
+                    const uint32_t vm = fetch(rm), v0 = fetch(r0), v1 = fetch(r1), v2 = fetch(r2);
+                    off = sel(m_eq(c, 4), pushv, pick(rm, vm));
+                    const uint32_t n0 = pick(r0, v0), n1 = pick(r1, v1), n2 = pick(r2, v2);
                     rep0 = n0; rep1 = n1; rep2 = n2;
                 } else { // in order
                     off = 0;
@@ -1192,7 +1261,7 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                 const uint32_t mp = op + ll; // where the match goes
                 {   // offset within the history, and not zero ("rep0 - 1")
                     const uint64_t om = __ballot(ml != 0 && off - 1 >= mp + dict_len);
-                    if ((om >> (f * LPF)) & ((1ull << LPF) - 1)) { xbad = true; ll = 0; ml = 0; if (!why) why = 8; }
+                    if (file_bits<LPF>(om, f)) { xbad = true; ll = 0; ml = 0; if (!why) why = 8; }
                 }
                 // the literals (<= 31 bytes per lane in exact pieces; longer runs by the file's lanes, a byte each per round) and the
                 // matches that lie wholly in the dictionary (requested first).  The window's tail is the literals' source: what a sequence
@@ -1211,11 +1280,14 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                         D0 = gv16(dp); D1 = gv16(dp + 16);
                     }
                     const uint32_t sa = lit_base + lp;
-                    const V16 AB_ = lds_u128(sa), CD_ = lds_u128(sa + 16);
-                    const uint64_t A = AB_.a, B = AB_.b, C = CD_.a, D = CD_.b;
+                    const uint32_t ls = ll < 32 ? ll : 0u; // (what this lane stores itself)
+                    const bool lit_hi = __ballot(ls >= 16) != 0; // (wave-uniform: half the steps have no run of 16..31 literals)
+                    const V16 AB_ = lds_u128(sa);
+                    V16 CD_ = {0, 0};
+                    if (lit_hi) CD_ = lds_u128(sa + 16);
                     asm volatile("" ::: "memory");
                     // (this loop runs per file: the lanes of files that are through are not here)
-                    uint32_t big = (uint32_t)(__ballot(ll >= 32) >> (f * LPF)) & ((1u << LPF) - 1);
+                    uint32_t big = file_bits<LPF>(__ballot(ll >= 32), f);
                     while (big) {
                         const uint32_t bl4 = ((lane & ~(LPF - 1)) + (uint32_t)__builtin_ctz(big)) * 4;
                         big &= big - 1;
@@ -1227,7 +1299,11 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                             asm volatile("" ::: "memory");
                         }
                     }
-                    store_exact31(outo + op, ll < 32 ? ll : 0u, (uint32_t)A, (uint32_t)(A >> 32), (uint32_t)B, (uint32_t)(B >> 32), (uint32_t)C, (uint32_t)(C >> 32), (uint32_t)D, (uint32_t)(D >> 32), dump);
+                    {
+                        uint32_t at = outo + op, d0 = (uint32_t)AB_.a, d1 = (uint32_t)(AB_.a >> 32), d2 = (uint32_t)AB_.b, d3 = (uint32_t)(AB_.b >> 32);
+                        if (lit_hi) store_piece16(at, ls, d0, d1, d2, d3, (uint32_t)CD_.a, (uint32_t)(CD_.a >> 32), (uint32_t)CD_.b, (uint32_t)(CD_.b >> 32), dump);
+                        store_exact15(at, ls, d0, d1, d2, d3, dump);
+                    }
                     if (DICT) {
                         store_exact31(outo + mp, dfull ? ml : 0u, (uint32_t)D0.a, (uint32_t)(D0.a >> 32), (uint32_t)D0.b, (uint32_t)(D0.b >> 32), (uint32_t)D1.a, (uint32_t)(D1.a >> 32), (uint32_t)D1.b, (uint32_t)(D1.b >> 32), dump);
                         if (dfull) ml = 0; // done
@@ -1239,47 +1315,88 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                 // everything below its source's end is final, i.e. once that end is at or below the match of the file's first sequence still
                 // waiting; a first sequence of any other kind -- longer, overlapping, starting in the dictionary -- is executed by the
                 // file's lanes together (its source is complete by then).  The first waiting sequence never waits, so every round ends one.
+                // A waiting sequence's place in its file's order travels with what a copy by the file's lanes TOGETHER needs: mp << 18 |
+                // m << 13 | off (a simple match: off <= mp < 2^13 -- the capacity is at most 8 KiB and a match has a byte --, m < 32; any other kind: the m field 0).  The minimum over the waiting lanes
+                // (DPP, no trip through LDS) is the file's first waiting sequence.  Rounds come in two forms (the choice is wave-uniform):
+                //   wide: every lane whose source is complete copies its own match (two reads, six exact-piece stores; the upper 16 bytes
+                //         only when some lane has them) -- the first round of a step finishes a third of the lanes, later ones three;
+                //   together: once no file has more than kTogether sequences waiting, each round copies the first waiting match of every
+                //         file, 32 / LPF bytes per lane (byte reads, byte stores): a third of a wide round's instructions and LDS work.
                 {
+                    constexpr uint32_t kTogether = 3;
                     const uint32_t m = ml;
                     const bool simple = (m < 32) & (off >= m) & (off <= mp);
                     bool pending = m != 0;
                     const uint32_t send = mp - off + m; // end of the source
-                    const uint32_t rowbase = lane & ~(LPF - 1);
+                    const uint32_t key0 = (mp << 18) | (simple ? (m << 13) | off : 0u);
+                    bool wide = true, first_round = true; // (wave-uniform; a step's first round is a wide one)
                     for (;;) {
                         const uint64_t pm = __ballot(pending);
                         if (!pm) break;
 #ifdef MZD_SMALL_STAMPS
-                        xn_++;
+                        xn_++; wg_rounds_++;
 #endif
-                        const uint32_t seg = (uint32_t)(pm >> (f * LPF)) & ((1u << LPF) - 1);
-                        const uint32_t first = seg ? (uint32_t)__builtin_ctz(seg) : 0u;
-                        const uint32_t fl4 = (rowbase + first) * 4;
-                        const uint32_t F = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)mp);
-                        const bool ready = pending & simple & (send <= F);
-                        {
+                        if (wide && !first_round) wide = __ballot((uint32_t)__builtin_popcount(file_bits<LPF>(pm, f)) > kTogether) != 0; // (the counts only fall)
+                        first_round = false;
+                        const uint32_t K = seg_min<LPF>(pending ? key0 : 0xFFFFFFFFu, lane);
+                        const bool is_first = pending & (key0 == K);
+#ifdef MZD_SMALL_STAMPS
+                        XSTAMP(xf_);
+#endif
+                        if (wide) {
+                            const uint32_t F = K >> 18;
+                            const bool ready = pending & simple & (send <= F);
+                            const uint32_t n = ready ? m : 0u;
                             const uint32_t ra = ready ? outo + mp - off : dump;
-                            const V16 AB_ = lds_u128(ra), CD_ = lds_u128(ra + 16);
-                            const uint64_t A = AB_.a, B = AB_.b, C = CD_.a, D = CD_.b;
+                            const bool hi = __ballot(n >= 16) != 0;
+                            const V16 AB_ = lds_u128(ra);
+                            V16 CD_ = {0, 0};
+                            if (hi) CD_ = lds_u128(ra + 16);
                             asm volatile("" ::: "memory");
-                            store_exact31(outo + mp, ready ? m : 0u, (uint32_t)A, (uint32_t)(A >> 32), (uint32_t)B, (uint32_t)(B >> 32), (uint32_t)C, (uint32_t)(C >> 32), (uint32_t)D, (uint32_t)(D >> 32), dump);
+                            uint32_t at = outo + mp, d0 = (uint32_t)AB_.a, d1 = (uint32_t)(AB_.a >> 32), d2 = (uint32_t)AB_.b, d3 = (uint32_t)(AB_.b >> 32);
+                            if (hi) store_piece16(at, n, d0, d1, d2, d3, (uint32_t)CD_.a, (uint32_t)(CD_.a >> 32), (uint32_t)CD_.b, (uint32_t)(CD_.b >> 32), dump);
+                            store_exact15(at, n, d0, d1, d2, d3, dump);
                             asm volatile("" ::: "memory");
+                            pending = pending & !ready;
+                        } else { // the first waiting match of every file, by the file's lanes: bytes sub, sub + LPF, ... (its source ends at or below its own start: complete)
+                            const uint32_t km = K == 0xFFFFFFFFu ? 0u : (K >> 13) & 31u; // (0: nothing waits in this file, or its first is not of the simple kind)
+                            const uint32_t kd = outo + (K >> 18), ks = kd - (K & 0x1FFFu);
+                            constexpr int NB = LPF >= 32 ? 1 : 32 / (int)LPF; // bytes per lane: sub, sub + LPF, ... (< 32)
+                            uint32_t vb[NB];
+#pragma unroll
+                            for (int j = 0; j < NB; j++) vb[j] = L8(sub + (uint32_t)j * LPF < km ? ks + sub + (uint32_t)j * LPF : dump);
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int j = 0; j < NB; j++) L8(sub + (uint32_t)j * LPF < km ? kd + sub + (uint32_t)j * LPF : dump) = (uint8_t)vb[j];
+                            asm volatile("" ::: "memory");
+                            pending = pending & !(is_first & simple);
                         }
-                        pending = pending & !ready;
-                        const bool fc = pending & !simple & (sub == first); // the first one waiting, and not of the simple kind
+#ifdef MZD_SMALL_STAMPS
+                        XSTAMP(xc_);
+#endif
+                        const bool fc = pending & !simple & is_first; // the first one waiting, and not of the simple kind: longer, overlapping itself, starting in the dictionary
                         const uint64_t cm = __ballot(fc);
                         if (cm) {
-                            const uint32_t fmp = F, foff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)off), fm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)m);
-                            if ((cm >> (f * LPF)) & ((1ull << LPF) - 1)) rare_match<LPF, DICT>(outo, fmp, foff, fm, sub, dict_end, dict_len);
+                            const uint32_t seg = file_bits<LPF>(cm, f);
+                            const uint32_t fl4 = ((lane & ~(LPF - 1)) + (seg ? (uint32_t)__builtin_ctz(seg) : 0u)) * 4;
+                            const uint32_t fmp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)mp), foff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)off), fm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)m);
+                            if (seg) rare_match<LPF, DICT>(outo, fmp, foff, fm, sub, dict_end, dict_len);
                             pending = pending & !fc;
+#ifdef MZD_SMALL_STAMPS
+                            xrare_++;
+#endif
                         }
                         asm volatile("" ::: "memory");
+#ifdef MZD_SMALL_STAMPS
+                        XSTAMP(xq_);
+#endif
                     }
                 }
                 wsync();
                 cur = nxt;
             }
 #ifdef MZD_SMALL_STAMPS
-            if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[18] = xa_; a.stamps[19] = xr_; a.stamps[20] = xl_; a.stamps[21] = xm_; a.stamps[22] = xn_; }
+            if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[18] = xa_; a.stamps[19] = xr_; a.stamps[20] = xl_; a.stamps[21] = xm_; a.stamps[22] = xn_; a.stamps[23] = xf_; a.stamps[24] = xc_; a.stamps[25] = xq_; a.stamps[26] = xrare_; }
 #endif
             // the literals behind the last sequence
             bool good = !xbad;
@@ -1337,7 +1454,7 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
                 }
             }
             const uint64_t badm = __ballot(ck_bad != 0);
-            if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) { ok = false; if (!why) why = 10; }
+            if (file_bits<LPF>(badm, f)) { ok = false; if (!why) why = 10; }
         }
         SSTAMP(8);
 
@@ -1379,6 +1496,9 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
         }
       } // pass
         SSTAMP(9);
+#ifdef MZD_SMALL_STAMPS
+        wg_groups_++;
+#endif
         first_group = false;
         if (!early) { g_next = ticket(); Jn = job_entry(list_entry(g_next)); prefetch(Jn, pfn); } // (wave-uniform)
         g = g_next; J = Jn;
@@ -1386,12 +1506,19 @@ __global__ __launch_bounds__(64, (G == 4 && XG == 4 && !DICT) ? 3 : 1) void mzd_
         for (int k = 0; k < kPF; k++) pf[k] = pfn[k];
         wsync(); // the slots are rewritten by the next group
     }
+#ifdef MZD_SMALL_STAMPS
+    if (a.stamps && lane == 0 && blockIdx.x < 3072) {
+        uint64_t* w = a.stamps + 2048 + 16 * blockIdx.x;
+        w[0] = wg_t0_; w[1] = __builtin_amdgcn_s_memrealtime();
+        w[2] = (uint64_t)(uint32_t)__builtin_amdgcn_s_getreg(63492) | ((uint64_t)(uint32_t)__builtin_amdgcn_s_getreg(63508) << 32); w[3] = (uint64_t)wg_groups_ | ((uint64_t)wg_rounds_ << 16) | ((uint64_t)wg_steps_ << 32) | ((uint64_t)(uint32_t)(wg_te_ - wg_t0_) << 48);
+    }
+#endif
 }
 
 } // namespace lw
 
 // wavefronts a CU holds by the kernels' register budgets: three per SIMD for the plain G = 4 kernel (168 registers: __launch_bounds__), two for the others
-uint32_t lds_waves_by_registers(int g, int xg, int with_dict) { return (g == 4 && xg == 4 && !with_dict) ? 12u : 8u; }
+uint32_t lds_waves_by_registers(int g, int xg, int with_dict) { (void)xg; return (g == 4 && !with_dict) ? 12u : 8u; }
 uint32_t lds_kernel_bytes_per_file(uint32_t tab_bytes, uint32_t comp_bytes) { return tab_bytes + lw::kAux + comp_bytes; } // a file's entropy image
 uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes) {
     const uint32_t ent = tab_bytes + lw::kAux + comp_bytes;
@@ -1406,7 +1533,7 @@ uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes) {
 size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap) { return (size_t)lit_stride + 8u * (size_t)seq_cap; }
 
 // every instantiation the host can ask for: (files per wavefront, with a dictionary image, files executed at a time)
-#define MZD_LDS_VARIANTS(X) X(4, false, 4) X(8, false, 8) X(16, false, 16) X(8, false, 4) X(4, true, 4) X(8, true, 8) X(16, true, 16)
+#define MZD_LDS_VARIANTS(X) X(4, false, 4) X(8, false, 8) X(16, false, 16) X(8, false, 4) X(4, false, 2) X(4, true, 4) X(8, true, 8) X(16, true, 16)
 // The kernels ask for up to 160 KiB of dynamic LDS (the default limit is 64 KiB): the attribute belongs to the CURRENT device's
 // function object, so it is raised once per device, from init_device (mzd_host.cpp), for every instantiation.
 int lds_prepare_device() {

@@ -168,6 +168,9 @@ int mzd_debug_host_path(int device, int what, int value);
 int mzd_debug_stamps(int device, uint64_t* out22);
 /* (a build with -DMZD_SMALL_STAMPS, `make sstamps`) the small-file kernel's phase stamps: 1 032 values, tools/lds_stamps.py */
 int mzd_debug_small_stamps(int device, uint64_t* out);
+/* (the same build) per workgroup of the small-file kernel's last launch, 16 values each: 100 MHz clock at entry, at exit,
+ * HW_ID | XCC_ID << 32, groups | rounds | steps, then the clock at the phase boundaries of its first group; n <= 3 072: tools/lds_wg.py */
+int mzd_debug_small_wg_stamps(int device, uint64_t* out, int n);
 /* the small-file kernel's intermediates of resident file slot `slot` after a call on device pointers: literals, and sequences as
  * literal length | match length << 14 | offset value << 32 (before repeat-offset resolution) */
 int mzd_debug_small_scratch(int device, uint32_t slot, uint8_t* lit, size_t lit_n, uint64_t* seq, size_t seq_n);

@@ -267,7 +267,7 @@ def test_small_files_of_every_class_and_size(kind):
         for level in (1, 3, 19):
             cp = corpus.build_corpus(kind, 77, sizes * 3, level=level)
             srcs = [cp.comp_file(i).tobytes() for i in range(cp.nfiles)]
-            for g, xg in ((0, 0), (8, 4)):  # the library's choice of shape; eight files per wavefront executed four at a time (raw and RLE blocks take their bytes from the input again in their pass)
+            for g, xg in ((0, 0), (8, 4), (4, 2)):  # the library's choice of shape; eight files per wavefront executed four at a time, four executed two at a time (32 lanes a file) (raw and RLE blocks take their bytes from the input again in their pass)
                 mzd.lib().mzd_debug_host_path(0, 4, g)
                 mzd.lib().mzd_debug_host_path(0, 5, xg)
                 res = mzd.decode_batch(srcs, [int(s) for s in cp.raw_sizes])

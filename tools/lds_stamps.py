@@ -47,6 +47,7 @@ for rep in range(3):
         print("    inside: walk %d, extract %d cycles" % (t[10], t[11]))
         if t[13] and t[14] and t[15]: print("    Huffman weights: counts %d, their FSE table %d, the weights %d, validation + decode table %d cycles" % (t[13] - t[2], t[14] - t[13], t[15] - t[14], t[3] - t[15]))
         print("    execute: stage A %d, repeat offsets %d, literals %d, match rounds %d cycles (%d rounds)" % (t[18], t[19], t[20], t[21], t[22]))
+        print("    inside the rounds: first waiting sequence %d, copies %d, rare matches + loop %d cycles (%d rare calls)" % (t[23], t[24], t[25], t[26]))
         t = t[:8] + [t[17]] + t[8:10] + t[10:]  # (the execute stamp was added later: index 17)
         for k in range(10):
             print("    %-46s %8d cycles" % (names[k], t[k + 1] - t[k]))
