@@ -168,6 +168,8 @@ struct LdsArgs {
     uint32_t lit_stride;        // >= the largest dst_cap of the launch + 64
     uint32_t seq_cap;           // >= the largest dst_cap of the launch / 3 + 2 (every match is >= 3 bytes)
     uint64_t* stamps;           // diagnostic build (-DMZD_SMALL_STAMPS), else unused
+    uint32_t* counter_next;     // null: a general driver's launch follows this one (it takes what is handed on and cleans the next
+    uint32_t* handed_on;        // launch's counters).  Else: no launch follows; the last wavefront stores counter[4] here and cleans.
 };
 int launch_lds(const LdsArgs& a, uint32_t grid, int g, int xg, int with_dict, void* stream); // g files per wavefront, executed xg at a time
 int lds_prepare_device();   // once per device, with that device current

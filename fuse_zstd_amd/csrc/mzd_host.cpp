@@ -50,7 +50,7 @@ constexpr uint32_t kMaxDicts = 64;
 constexpr size_t kMaxChunks = 16;               // ... and at most this many chunks per call
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
-std::atomic<int> g_small_g{0}, g_small_xg{0}, g_trace_t2{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
+std::atomic<int> g_small_g{0}, g_small_xg{0}, g_trace_t2{0}, g_keep_behind{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
 std::atomic<unsigned> g_small_grid{0};               // mzd_debug_host_path 6: its grid (0: as many wavefronts as the device holds)
 constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 1280u; // (a workgroup's LDS is allocated in steps of 320 dwords: tools/micro/lds_granule_micro.hip -- five workgroups of 32 000 bytes share a CU, five of 32 640 do not, and the occupancy API says they do)
 std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic with the
@@ -410,7 +410,10 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
 }
 
 // enqueue one launch on lane `l`: [small-file kernel] + general driver, timed by the lane's events
-int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, const uint32_t* d_lists, hipEvent_t ev0, hipEvent_t ev1) {
+// handed_on (device word, or null): a launch of small files alone ends with the small-file kernel -- the general driver's launch
+// behind it, 19 us of a 10 000-file launch that hands nothing on, is left out; the kernel's last wavefront stores the number of
+// files it handed on there and the caller decodes those when it collects (redo_handed_on)
+int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, const uint32_t* d_lists, hipEvent_t ev0, hipEvent_t ev1, uint32_t* handed_on = nullptr) {
     const uint32_t njobs = p.njobs;
     KernelArgs ka;
     l.counter = l.cnt[l.flip]; l.flip ^= 1u; // (clean: the lane's previous launch zeroed it; this one zeroes l.cnt[l.flip])
@@ -427,6 +430,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     }
     ka.fstate = l.fstate; ka.tables = l.tables; ka.ring = l.ring; ka.ring_cap = (uint32_t)l.task_cap + 1; ka.epoch = l.epoch;
     ka.use_tasks = use_tasks ? 1u : 0u;
+    const bool solo = handed_on && p.nsmall && p.nbig == 0;
     // few tasks for the lane's workgroups: the in-order copy stage is the critical path -- resolve blocks ahead (mzd_k_resolve.h)
     const int force = g_force_driver.load(std::memory_order_relaxed);
     ka.resolve_map = d.resolve_map;
@@ -443,6 +447,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         la.dicts = d.d_dicts; la.ndicts = d.ndicts;
         la.tab_bytes = p.lds_tab; la.comp_bytes = p.lds_comp; la.out_bytes = p.lds_out;
         la.stamps = reinterpret_cast<uint64_t*>(d.debug); // (diagnostic builds: the first debug slot's first bytes; unused otherwise)
+        la.counter_next = solo ? l.cnt[l.flip] : nullptr; la.handed_on = solo ? handed_on : nullptr;
         const uint32_t ngroups = (p.nsmall + (uint32_t)p.lds_g - 1) / (uint32_t)p.lds_g;
         const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out), kLdsGranule);
         // one wavefront per workgroup; as many as the whole device holds, also for a launch on one of the host path's lanes: this
@@ -460,10 +465,12 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
             char small[48];
             snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg);
             const char* big = use_tasks ? "mzd_decode_kernel_tasks" : "mzd_decode_kernel_files";
-            if (p.nbig > p.nsmall) snprintf(d.last_kernels, sizeof d.last_kernels, "%s+%s", big, small);
+            if (solo) snprintf(d.last_kernels, sizeof d.last_kernels, "%s", small);
+            else if (p.nbig > p.nsmall) snprintf(d.last_kernels, sizeof d.last_kernels, "%s+%s", big, small);
             else snprintf(d.last_kernels, sizeof d.last_kernels, "%s+%s", small, big); // (the general driver's launch behind it takes what was handed on: usually nothing)
         }
         HIPCHK(hipGetLastError());
+        if (solo) { HIPCHK(hipEventRecord(ev1, s)); return MZD_OK; }
         ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig;
         grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
     } else {
@@ -472,11 +479,26 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         if (p.lpt) { ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig; } // (largest first; nothing is appended: counter word 4 stays 0)
     }
     grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, l.nwg));
-    // (the launch behind the small-file kernel is not optional even when nothing is handed on: its last workgroup zeroes the
-    //  counter block of the lane's next launch)
+    // (the launch behind the small-file kernel takes what that kernel handed on, and its last workgroup zeroes the counter block of
+    //  the lane's next launch)
     launch_decode(ka, grid, s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev1, s));
+    return MZD_OK;
+}
+
+// What a launch without a general driver behind it handed on (`count` job indices at d_lists + njobs): one launch of driver 1.
+int redo_handed_on(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, uint32_t njobs, const uint32_t* d_lists, uint32_t count) {
+    KernelArgs ka;
+    l.counter = l.cnt[l.flip]; l.flip ^= 1u;
+    ka.jobs = d_jobs; ka.njobs = njobs; ka.counter = l.counter; ka.counter_next = l.cnt[l.flip];
+    ka.lit_scratch = d.lit_scratch; ka.seq_scratch = d.seq_scratch; ka.walk_scratch = d.walk_scratch;
+    ka.dicts = d.d_dicts; ka.ndicts = d.ndicts; ka.debug = d.debug; ka.job_slot0 = l.counter + 1;
+    ka.job_list = d_lists + njobs; ka.nlist_fixed = count; ka.wg0 = l.wg0; // (the list is complete: nothing is appended, word 4 stays 0)
+    ka.fstate = l.fstate; ka.tables = l.tables; ka.ring = l.ring; ka.ring_cap = (uint32_t)l.task_cap + 1; ka.epoch = l.epoch;
+    ka.use_tasks = 0u; ka.resolve_map = d.resolve_map; ka.resolve = 0u;
+    launch_decode(ka, std::max<uint32_t>(1u, std::min<uint32_t>(count, l.nwg)), s);
+    HIPCHK(hipGetLastError());
     return MZD_OK;
 }
 
@@ -495,7 +517,7 @@ int ensure_staging_jobs(Staging& st, size_t n) {
     st.d_jobs = nullptr; st.h_jobs = nullptr; st.d_lists = nullptr; st.h_lists = nullptr; st.jobs_cap = 0;
     HIPCHK(hipMalloc(&st.d_jobs, cap * sizeof(DevJob)));
     HIPCHK(hipHostMalloc(&st.h_jobs, cap * sizeof(DevJob), hipHostMallocDefault));
-    HIPCHK(hipMalloc(&st.d_lists, cap * 2 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&st.d_lists, (cap * 2 + 4) * sizeof(uint32_t))); // (+ the word a launch of small files alone stores its hand-on count in)
     HIPCHK(hipHostMalloc(&st.h_lists, cap * 2 * sizeof(uint32_t), hipHostMallocDefault));
     st.jobs_cap = cap;
     return MZD_OK;
@@ -516,12 +538,28 @@ int run_device_jobs(Device& d, mzd_job* jobs, size_t njobs, hipStream_t s) {
     if (!s) s = d.whole.stream;
     HIPCHK(hipMemcpyAsync(st->d_jobs, st->h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice, s));
     if (p.nsmall || p.lpt) HIPCHK(hipMemcpyAsync(st->d_lists, st->h_lists, njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    rc = enqueue(d, d.whole, s, st->d_jobs, p, st->d_lists, d.whole.ev0, d.whole.ev1);
+    const bool solo = p.nsmall && p.nbig == 0 && !g_keep_behind.load(std::memory_order_relaxed);
+    uint32_t* const d_handed = st->d_lists + 2 * st->jobs_cap;
+    rc = enqueue(d, d.whole, s, st->d_jobs, p, st->d_lists, d.whole.ev0, d.whole.ev1, solo ? d_handed : nullptr);
     d.job0_counter = d.whole.counter;
     if (rc) { hipStreamSynchronize(s); return rc; }
+    uint32_t handed = 0;
+    if (solo) HIPCHK(hipMemcpyAsync(&handed, d_handed, sizeof handed, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(st->h_jobs, st->d_jobs, njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipEventElapsedTime(&d.last_ms, d.whole.ev0, d.whole.ev1));
+    if (solo && handed) { // (files that were not plain: the general driver, now)
+        if (handed > njobs) return MZD_E_DEVICE;
+        HIPCHK(hipEventRecord(d.whole.ev0, s));
+        rc = redo_handed_on(d, d.whole, s, st->d_jobs, (uint32_t)njobs, st->d_lists, handed);
+        if (rc) { hipStreamSynchronize(s); return rc; }
+        HIPCHK(hipEventRecord(d.whole.ev1, s));
+        HIPCHK(hipMemcpyAsync(st->h_jobs, st->d_jobs, njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        float more = 0.f;
+        HIPCHK(hipEventElapsedTime(&more, d.whole.ev0, d.whole.ev1));
+        d.last_ms += more;
+    }
     for (size_t i = 0; i < njobs; i++) { jobs[i].out_len = (size_t)st->h_jobs[i].out_len; jobs[i].status = st->h_jobs[i].status; jobs[i].device = d.index; }
     return MZD_OK;
 }
@@ -904,10 +942,11 @@ struct mzd_batch {
     int device;
     DevJob* d_jobs;
     DevJob* h_jobs;
-    uint32_t* d_lists;
+    uint32_t* d_lists; // 2 * njobs entries + the word a launch of small files alone stores its hand-on count in
     size_t njobs;
     Plan plan;
     std::shared_ptr<Device> dev;
+    bool solo = false; // the last launch ended with the small-file kernel: what it handed on is decoded by collect
 };
 
 extern "C" {
@@ -970,6 +1009,7 @@ int mzd_debug_host_path(int device, int what, int value) {
     if (what == 5) { g_small_xg.store(value); return MZD_OK; }
     if (what == 6) { g_small_grid.store(value < 0 ? 0u : (unsigned)value); return MZD_OK; }
     if (what == 7) { g_trace_t2.store(value); return MZD_OK; }
+    if (what == 8) { g_keep_behind.store(value); return MZD_OK; } // (the general driver's launch behind a launch of small files alone stays: A/B)
     return MZD_E_PARAM;
 }
 void* mzd_host_alloc(size_t n) {
@@ -1089,9 +1129,9 @@ int mzd_batch_prepare(int device, const mzd_job* jobs, size_t njobs, mzd_batch**
     if (!d) return MZD_E_DEVICE;
     if (!jobs || !out || njobs == 0 || njobs > 0x7FFFFFF0u) return MZD_E_PARAM;
     HIPCHK(hipSetDevice(d->hip_id));
-    auto* b = new mzd_batch{device, nullptr, nullptr, nullptr, njobs, Plan{}, d};
+    auto* b = new mzd_batch{device, nullptr, nullptr, nullptr, njobs, Plan{}, d, false};
     std::vector<uint32_t> lists(njobs * 2);
-    if (hipMalloc(&b->d_jobs, njobs * sizeof(DevJob)) != hipSuccess || hipMalloc(&b->d_lists, njobs * 2 * sizeof(uint32_t)) != hipSuccess ||
+    if (hipMalloc(&b->d_jobs, njobs * sizeof(DevJob)) != hipSuccess || hipMalloc(&b->d_lists, (njobs * 2 + 4) * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc(&b->h_jobs, njobs * sizeof(DevJob), hipHostMallocDefault) != hipSuccess) {
         hipFree(b->d_jobs); hipFree(b->d_lists); delete b; return MZD_E_DEVICE;
     }
@@ -1111,7 +1151,8 @@ int mzd_batch_launch(mzd_batch* b, void* stream) {
     HIPCHK(hipSetDevice(d.hip_id));
     WholeGuard g(d); // (launches of one batch follow each other on `stream`; host-path launches wait for their end event)
     d.whole_used.store(true, std::memory_order_relaxed);
-    const int rc = enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists, d.whole.ev0, d.whole.ev1);
+    b->solo = b->plan.nsmall && b->plan.nbig == 0 && !g_keep_behind.load(std::memory_order_relaxed);
+    const int rc = enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists, d.whole.ev0, d.whole.ev1, b->solo ? b->d_lists + 2 * b->njobs : nullptr);
     d.job0_counter = d.whole.counter;
     return rc;
 }
@@ -1121,9 +1162,19 @@ int mzd_batch_collect(mzd_batch* b, mzd_job* jobs, void* stream) {
     Device& d = *b->dev;
     HIPCHK(hipSetDevice(d.hip_id));
     hipStream_t s = stream ? (hipStream_t)stream : d.whole.stream;
+    uint32_t handed = 0;
+    if (b->solo) HIPCHK(hipMemcpyAsync(&handed, b->d_lists + 2 * b->njobs, sizeof handed, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(b->h_jobs, b->d_jobs, b->njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipEventElapsedTime(&d.last_ms, d.whole.ev0, d.whole.ev1));
+    if (b->solo && handed) { // (the launch ended with the small-file kernel: the files it handed on take the general driver now)
+        if (handed > b->njobs) return MZD_E_DEVICE;
+        WholeGuard g(d);
+        const int rc = redo_handed_on(d, d.whole, s, b->d_jobs, (uint32_t)b->njobs, b->d_lists, handed);
+        if (rc) { hipStreamSynchronize(s); return rc; }
+        HIPCHK(hipMemcpyAsync(b->h_jobs, b->d_jobs, b->njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
     if (jobs)
         for (size_t i = 0; i < b->njobs; i++) { jobs[i].out_len = (size_t)b->h_jobs[i].out_len; jobs[i].status = b->h_jobs[i].status; jobs[i].device = d.index; }
     return MZD_OK;

@@ -211,6 +211,20 @@ template <int LPF> DI uint32_t seg_min(uint32_t x, uint32_t lane) {
     if (LPF >= 32) x = min(x, (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ 16u) * 4u), (int)x));
     return x;
 }
+// n bytes from LDS offset src to dst <= src by the file's LPF lanes, four bytes a lane and round (ascending rounds, every round reads
+// before it writes: a round's stores end below the next round's reads); the run's last 1..3 bytes in exact pieces
+template <int LPF> DI void copy_run_lanes(uint32_t dst, uint32_t src, uint32_t n, uint32_t sub, uint32_t dump) {
+    for (uint32_t q = 4 * sub; q < n + 4 * sub; q += 4 * LPF) { // (the same number of rounds for all the file's lanes)
+        const uint32_t left = q < n ? n - q : 0u;
+        const uint32_t v = lds_u32(left ? src + q : dump);
+        asm volatile("" ::: "memory");
+        const lmask m4 = m_ge(left, 4), m2 = m_lt(left, 4) & m_ne(left & 2, 0), m1 = m_lt(left, 4) & m_ne(left & 1, 0);
+        lds_s32(sel(m4, dst + q, dump), v);
+        lds_s16(sel(m2, dst + q, dump), v);
+        L8(sel(m1, dst + q + (left & 2), dump)) = (uint8_t)(v >> (8 * (left & 2)));
+        asm volatile("" ::: "memory");
+    }
+}
 template <int N, class F> DI void static_for(F&& f) {
     if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
@@ -456,8 +470,17 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
     for (int t = 0; t < 3; t++) { di.al[t] = 0; di.rep[t] = 0; }
 
     const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds == 0; // (offsets are used as LDS addresses)
-    if (!lds_at_zero) { // cannot be (this kernel has no other LDS object); if it ever is, the general driver behind this launch decodes everything
+    // A launch without a general driver behind it (LdsArgs::counter_next): the last wavefront to leave publishes how many files were
+    // handed on -- the host decodes them when it collects the launch -- and zeroes the counter block of the lane's next launch.
+    auto leave = [&]() {
+        if (a.counter_next && lane == 0 && atomicAdd(&a.counter[6], 1u) == gridDim.x - 1) { // (a wavefront's additions to word 4 have returned by now)
+            *a.handed_on = atomicAdd(&a.counter[4], 0u);
+            for (uint32_t k = 0; k < kCounterWords; k++) a.counter_next[k] = 0;
+        }
+    };
+    if (!lds_at_zero) { // cannot be (this kernel has no other LDS object); if it ever is, the general driver decodes everything
         for (uint32_t i = blockIdx.x * 64 + threadIdx.x; i < a.n; i += gridDim.x * 64) a.redo_list[atomicAdd(&a.counter[4], 1u)] = a.list[i];
+        leave();
         return;
     }
     const uint32_t ngroups = (a.n + G - 1) / G;
@@ -1292,12 +1315,7 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                         const uint32_t bl4 = ((lane & ~(LPF - 1)) + (uint32_t)__builtin_ctz(big)) * 4;
                         big &= big - 1;
                         const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bl4, (int)ll), o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bl4, (int)op), s2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bl4, (int)sa);
-                        for (uint32_t q = sub; q < n2 + sub; q += LPF) { // (destination at or below the source: ascending rounds, each read before it is written)
-                            const uint32_t v = L8(s2 + q);
-                            asm volatile("" ::: "memory");
-                            if (q < n2) L8(outo + o2 + q) = (uint8_t)v;
-                            asm volatile("" ::: "memory");
-                        }
+                        copy_run_lanes<LPF>(outo + o2, s2, n2, sub, dump); // (destination at or below the source)
                     }
                     {
                         uint32_t at = outo + op, d0 = (uint32_t)AB_.a, d1 = (uint32_t)(AB_.a >> 32), d2 = (uint32_t)AB_.b, d3 = (uint32_t)(AB_.b >> 32);
@@ -1405,12 +1423,7 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                 const uint32_t rest = nlit - lend;
                 good = rest <= cap - oend;
                 if (good) {
-                    for (uint32_t q = sub; q < rest + sub; q += LPF) { // (destination at or below the source: ascending rounds, each read before it is written)
-                        const uint32_t v = L8(lit_base + lend + q);
-                        asm volatile("" ::: "memory");
-                        if (q < rest) L8(outo + oend + q) = (uint8_t)v;
-                        asm volatile("" ::: "memory");
-                    }
+                    copy_run_lanes<LPF>(outo + oend, lit_base + lend, rest, sub, dump); // (destination at or below the source)
                     out_len = oend + rest;
                     good = !(has_fcs && out_len != fcs);
                 }
@@ -1506,6 +1519,7 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
         for (int k = 0; k < kPF; k++) pf[k] = pfn[k];
         wsync(); // the slots are rewritten by the next group
     }
+    leave();
 #ifdef MZD_SMALL_STAMPS
     if (a.stamps && lane == 0 && blockIdx.x < 3072) {
         uint64_t* w = a.stamps + 2048 + 16 * blockIdx.x;

@@ -130,7 +130,10 @@ int mzd_decode_batch_device(int device, mzd_job* jobs, size_t njobs, void* strea
 
 /* Asynchronous form for measurement loops: the job table stays on the device.
  * prepare uploads the table once; launch enqueues one pass on `stream` and returns at
- * once; collect waits for the stream and copies status/out_len back into `jobs`. */
+ * once; collect waits for the stream and copies status/out_len back into `jobs`.
+ * A launch that holds nothing but small files (capacity <= 8 KiB) ends with the small-file kernel; the few files that kernel hands
+ * on -- several frames or blocks, anything malformed -- are decoded by the general driver when the launch is collected (collect,
+ * or the end of mzd_decode_batch_device): their outputs and statuses are complete when collect returns, not before. */
 typedef struct mzd_batch mzd_batch;
 int mzd_batch_prepare(int device, const mzd_job* jobs, size_t njobs, mzd_batch** out);
 int mzd_batch_launch(mzd_batch* b, void* stream);
@@ -161,7 +164,9 @@ int mzd_debug_set_driver(int driver);
  * [5] groups it took. */
 int mzd_debug_counters(int device, uint32_t* out8);
 /* Host-path diagnostics.  what 2: at most `value` chunks per call when the kernels mirror the outputs into pinned caller
- * memory (default 4).  what 3: `value` host threads for the staging copies of pageable buffers (default 8). */
+ * memory (default 4).  what 3: `value` host threads for the staging copies of pageable buffers (default 8).  what 4 / 5: the small-file
+ * kernel's files per wavefront / files executed at a time (0: the library's choice).  what 6: its grid.  what 7: a timing trace of
+ * mzd_decode_batch on stderr.  what 8: a launch of small files alone keeps the general driver's launch behind it (A/B). */
 int mzd_debug_host_path(int device, int what, int value);
 /* Diagnostic builds only (make diag / tfin): per-phase cycle sums of the workgroup that ran job 0; role finish times of
  * every workgroup slot.  In the product build they return zeros. */
