@@ -242,12 +242,15 @@ def measure_traffic(workload, files, level):
     """HBM bytes per launch of this workload, measured NOW: two child runs of this script under `rocprofv3 --kernel-trace --pmc`
     (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes: they do not fit one pass on gfx950), the
     counters of the step's kernels summed per launch.  Raw counter values (these kernels read with 4..16-byte accesses, for which
-    the guide calls FETCH_SIZE uncalibrated).  None when rocprofv3 is not on the machine or a pass fails (then the line carries
-    the recorded value of profiles/pmc_traffic.json and says so)."""
+    the guide calls FETCH_SIZE uncalibrated).  None when rocprofv3 is not on the machine; {"failed": why} when a pass fails (then the
+    line carries the recorded value of profiles/pmc_traffic.json and says so).  The child is a plain one-GPU run of this script: the
+    launcher's variables (RANK, WORLD_SIZE, MASTER_*, TORCHELASTIC_*) are taken out of its environment."""
     import csv, glob, shutil, subprocess, tempfile
     if not shutil.which("rocprofv3"):
         return None
     out = {}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("TORCHELASTIC_")}
+    env["TMPDIR"] = "/tmp"
     tmp = tempfile.mkdtemp(prefix="mzd_pmc_", dir="/tmp")
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -255,9 +258,9 @@ def measure_traffic(workload, files, level):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--workload", workload, "--files", str(files), "--level", str(level), "--steps", "4", "--warmup", "1",
                    "--no-others", "--no-t2", "--no-cpu-baseline", "--no-traffic"]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, TMPDIR="/tmp"), cwd=ROOT)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
             if r.returncode != 0:
-                return None
+                return {"failed": "%s pass: exit %d: %s" % (ctr, r.returncode, (r.stderr or "")[-300:])}
             per_kernel = {}
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -265,11 +268,11 @@ def measure_traffic(workload, files, level):
                     if row.get("Counter_Name") == ctr and ("mzd_decode_kernel" in kn or "mzd_lds_kernel" in kn):
                         per_kernel.setdefault(kn.split("(")[0], []).append(float(row["Counter_Value"]))
             if not per_kernel:
-                return None
+                return {"failed": "%s pass: no counter rows for the decode kernels" % ctr}
             launches = max(len(v) for v in per_kernel.values())
             out[ctr] = sum(sum(v) for v in per_kernel.values()) / launches * 1024.0  # KiB -> bytes, per launch of the batch
-    except Exception:
-        return None
+    except Exception as e:
+        return {"failed": repr(e)[:300]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     fb, wb = int(out["FETCH_SIZE"]), int(out["WRITE_SIZE"])
@@ -602,7 +605,10 @@ def main():
         if not args.no_traffic:  # roofline.traffic measured by this run (two rocprofv3 --pmc child passes over the headline workload)
             torch.cuda.empty_cache()
             m = measure_traffic(args.workload, nfiles, args.level)
-            if m:
+            line["roofline"]["traffic_measured"] = bool(m) and "failed" not in m
+            if m and "failed" in m:
+                line["roofline"]["traffic_measure_failed"] = m["failed"]  # (the recorded value of profiles/pmc_traffic.json stands in)
+            elif m:
                 r = line["roofline"]
                 r["traffic"] = m["bytes"]
                 r["traffic_fetch_bytes"], r["traffic_write_bytes"] = m["fetch_bytes"], m["write_bytes"]

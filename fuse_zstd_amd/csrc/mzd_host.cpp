@@ -109,8 +109,15 @@ struct Device {
     bool dict_used[kMaxDicts] = {};
     void* dict_bufs[kMaxDicts] = {};
     float last_ms = 0.f;
-    char last_kernels[96] = "";           // what the most recent whole-device launch ran, dominant kernel first (mzd_last_kernel_name)
+    char last_kernels[96] = "";           // what the most recent whole-device launch ran, dominant kernel first (mzd_last_kernel_name); under names_mu
+    std::mutex names_mu;
+    void set_kernels(const char* a, const char* b = nullptr) {
+        std::lock_guard<std::mutex> lk(names_mu);
+        if (b) snprintf(last_kernels, sizeof last_kernels, "%s+%s", a, b); else snprintf(last_kernels, sizeof last_kernels, "%s", a);
+    }
     uint32_t* job0_counter = nullptr;      // counter block of the launch that decoded job 0 of the most recent call (mzd_debug_last_block)
+    uint32_t job0_snap[kCounterWords] = {}; // ... as it stood when a launch of small files alone was collected (the launch of what it handed on
+    bool job0_snap_valid = false;          //     cleans that block): what mzd_debug_counters reports then
     std::atomic<bool> whole_used{false};   // a whole-device launch may still be running on a caller's stream: lanes wait for its end event
     // resources: lanes and stagings are handed out under `mu`
     std::mutex mu;
@@ -465,9 +472,9 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
             char small[48];
             snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg);
             const char* big = use_tasks ? "mzd_decode_kernel_tasks" : "mzd_decode_kernel_files";
-            if (solo) snprintf(d.last_kernels, sizeof d.last_kernels, "%s", small);
-            else if (p.nbig > p.nsmall) snprintf(d.last_kernels, sizeof d.last_kernels, "%s+%s", big, small);
-            else snprintf(d.last_kernels, sizeof d.last_kernels, "%s+%s", small, big); // (the general driver's launch behind it takes what was handed on: usually nothing)
+            if (solo) d.set_kernels(small);
+            else if (p.nbig > p.nsmall) d.set_kernels(big, small);
+            else d.set_kernels(small, big); // (the general driver's launch behind it takes what was handed on: usually nothing)
         }
         HIPCHK(hipGetLastError());
         if (solo) { HIPCHK(hipEventRecord(ev1, s)); return MZD_OK; }
@@ -475,7 +482,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
     } else {
         grid = use_tasks ? std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(njobs, l.nwg)) : njobs;
-        if (&l == &d.whole) snprintf(d.last_kernels, sizeof d.last_kernels, "%s", use_tasks ? "mzd_decode_kernel_tasks" : "mzd_decode_kernel_files");
+        if (&l == &d.whole) d.set_kernels(use_tasks ? "mzd_decode_kernel_tasks" : "mzd_decode_kernel_files");
         if (p.lpt) { ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig; } // (largest first; nothing is appended: counter word 4 stays 0)
     }
     grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, l.nwg));
@@ -544,9 +551,14 @@ int run_device_jobs(Device& d, mzd_job* jobs, size_t njobs, hipStream_t s) {
     d.job0_counter = d.whole.counter;
     if (rc) { hipStreamSynchronize(s); return rc; }
     uint32_t handed = 0;
-    if (solo) HIPCHK(hipMemcpyAsync(&handed, d_handed, sizeof handed, hipMemcpyDeviceToHost, s));
+    d.job0_snap_valid = false;
+    if (solo) {
+        HIPCHK(hipMemcpyAsync(&handed, d_handed, sizeof handed, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(d.job0_snap, d.job0_counter, sizeof d.job0_snap, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(hipMemcpyAsync(st->h_jobs, st->d_jobs, njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    d.job0_snap_valid = solo;
     HIPCHK(hipEventElapsedTime(&d.last_ms, d.whole.ev0, d.whole.ev1));
     if (solo && handed) { // (files that were not plain: the general driver, now)
         if (handed > njobs) return MZD_E_DEVICE;
@@ -868,7 +880,7 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
             e = hipStreamWaitEvent(l.stream, k.in, 0);
             if (e == hipSuccess && d.whole_used.load(std::memory_order_relaxed)) e = hipStreamWaitEvent(l.stream, d.whole.ev1, 0); // a device-path launch may still run on a caller's stream
             if (e == hipSuccess) erc = enqueue(d, l, l.stream, st->d_jobs + c0, p, st->d_lists + 2 * c0, k.k0, k.k1);
-            if (c == 0) d.job0_counter = l.counter;
+            if (c == 0) { d.job0_counter = l.counter; d.job0_snap_valid = false; }
         }
         // results and outputs
         if (e == hipSuccess && erc == MZD_OK) e = hipStreamWaitEvent(d.copy_out, k.k1, 0);
@@ -1153,7 +1165,7 @@ int mzd_batch_launch(mzd_batch* b, void* stream) {
     d.whole_used.store(true, std::memory_order_relaxed);
     b->solo = b->plan.nsmall && b->plan.nbig == 0 && !g_keep_behind.load(std::memory_order_relaxed);
     const int rc = enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists, d.whole.ev0, d.whole.ev1, b->solo ? b->d_lists + 2 * b->njobs : nullptr);
-    d.job0_counter = d.whole.counter;
+    d.job0_counter = d.whole.counter; d.job0_snap_valid = false;
     return rc;
 }
 
@@ -1163,9 +1175,14 @@ int mzd_batch_collect(mzd_batch* b, mzd_job* jobs, void* stream) {
     HIPCHK(hipSetDevice(d.hip_id));
     hipStream_t s = stream ? (hipStream_t)stream : d.whole.stream;
     uint32_t handed = 0;
-    if (b->solo) HIPCHK(hipMemcpyAsync(&handed, b->d_lists + 2 * b->njobs, sizeof handed, hipMemcpyDeviceToHost, s));
+    d.job0_snap_valid = false;
+    if (b->solo) {
+        HIPCHK(hipMemcpyAsync(&handed, b->d_lists + 2 * b->njobs, sizeof handed, hipMemcpyDeviceToHost, s));
+        if (d.job0_counter) HIPCHK(hipMemcpyAsync(d.job0_snap, d.job0_counter, sizeof d.job0_snap, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(hipMemcpyAsync(b->h_jobs, b->d_jobs, b->njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (b->solo) { d.job0_snap[4] = handed; d.job0_snap_valid = true; } // (word 4 is the batch's own record: another batch's launch may have cleaned the block since)
     HIPCHK(hipEventElapsedTime(&d.last_ms, d.whole.ev0, d.whole.ev1));
     if (b->solo && handed) { // (the launch ended with the small-file kernel: the files it handed on take the general driver now)
         if (handed > b->njobs) return MZD_E_DEVICE;
@@ -1265,7 +1282,8 @@ int mzd_debug_counters(int device, uint32_t* out8) {
     WholeGuard g(*d);
     HIPCHK(hipSetDevice(d->hip_id));
     if (!d->job0_counter) return MZD_E_PARAM;
-    HIPCHK(hipMemcpy(out8, d->job0_counter, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (d->job0_snap_valid) memcpy(out8, d->job0_snap, sizeof d->job0_snap);
+    else HIPCHK(hipMemcpy(out8, d->job0_counter, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
 #ifdef MZD_EXP_DEVSITE
     mzd::devsite_take(out8 + 5); // (words 5, 6, 7: first, max, count)
 #endif
@@ -1371,9 +1389,13 @@ int mzd_last_kernel_ms(int device, float* ms) {
     return MZD_OK;
 }
 
-const char* mzd_last_kernel_name(int device) {
+const char* mzd_last_kernel_name(int device) { // (a copy of the calling thread's own: a launch on another thread, or mzd_shutdown, cannot change it under the reader)
+    static thread_local char name[96];
     auto d = get_device(device);
-    return d ? d->last_kernels : "";
+    if (!d) return "";
+    std::lock_guard<std::mutex> lk(d->names_mu);
+    memcpy(name, d->last_kernels, sizeof name);
+    return name;
 }
 
 const char* mzd_strerror(int code) {

@@ -319,6 +319,20 @@ DI uint32_t read_ncount_lane(uint32_t src_off, uint32_t n, int max_log, int max_
 DI uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 DI uint64_t xround(uint64_t acc, uint64_t in) { acc += in * XP2; acc = rotl64(acc, 31); return acc * XP1; }
 DI uint64_t xmerge(uint64_t hh, uint64_t v) { v = xround(0, v); hh ^= v; return hh * XP1 + XP4; }
+// The stripe loop with the product in * P2 off the chain (mzd_k_xxh64.h's form, for a file's lanes): lane 4 s + a of the file holds
+// the product for stripe s of a group, accumulator a; the chain runs in the file's first four lanes and picks the products of
+// stripes 1.. out of the lanes above (DPP row shifts folded into the 64-bit add): one 64-bit multiply per stripe on the chain, not two.
+DI uint64_t rotl64_31(uint64_t x) { const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32); return (uint64_t)__builtin_amdgcn_alignbit(lo, hi, 1) | ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 1) << 32); }
+template <int J> DI uint64_t add_row_up(uint64_t acc, uint64_t t) { // acc + (t of the lane 4 J further up in the row; lanes past the row's end add 0)
+    if (J == 0) return acc + t;
+    uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+    const uint32_t tlo = (uint32_t)t, thi = (uint32_t)(t >> 32);
+    if (J == 1) asm("v_add_co_u32_dpp %0, vcc, %2, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_addc_co_u32_dpp %1, vcc, %3, %1, vcc row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(lo), "+v"(hi) : "v"(tlo), "v"(thi) : "vcc");
+    if (J == 2) asm("v_add_co_u32_dpp %0, vcc, %2, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_addc_co_u32_dpp %1, vcc, %3, %1, vcc row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(lo), "+v"(hi) : "v"(tlo), "v"(thi) : "vcc");
+    if (J == 3) asm("v_add_co_u32_dpp %0, vcc, %2, %0 row_shl:12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_addc_co_u32_dpp %1, vcc, %3, %1, vcc row_shl:12 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(lo), "+v"(hi) : "v"(tlo), "v"(thi) : "vcc");
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+template <int J> DI uint64_t xchain31(uint64_t acc, uint64_t t) { acc = add_row_up<J>(acc, t); acc = rotl64_31(acc); return acc * XP1; }
 DI uint64_t xxh_tail(uint64_t hh, uint32_t q, uint32_t end) {
     while (q + 8 <= end) { hh ^= xround(0, lds_u64(q)); hh = rotl64(hh, 27) * XP1 + XP4; q += 8; }
     if (q + 4 <= end) { hh ^= (uint64_t)lds_u32(q) * XP1; hh = rotl64(hh, 23) * XP2 + XP3; q += 4; }
@@ -776,7 +790,9 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
             if (good) {
                 constexpr uint32_t NCL = (12 + LPF - 1) / LPF;
                 const uint32_t hist = kShDump + 8 * LPF * f, hmask = hist + 24;
-                for (uint32_t o = 4 * sub; o < 48; o += 4 * LPF) L32(hist + o) = 0;
+                constexpr uint32_t kHistBytes = (24 + (12 * LPF + 7) / 8 + 3) & ~3u; // twelve 16-bit counters, twelve lane masks of LPF bits
+                static_assert(kHistBytes <= 8 * LPF, "the histogram and the lane masks stay inside the file's share of the dump area");
+                for (uint32_t o = 4 * sub; o < kHistBytes; o += 4 * LPF) L32(hist + o) = 0;
                 wsync();
                 uint32_t over = 0;
                 for (uint32_t s0 = 0; s0 < nw_l; s0 += LPF) {
@@ -1438,10 +1454,32 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
             uint32_t ck_bad = 0;
             const bool hashing = ok && has_ck && n != 0;
             const uint32_t nstripes = hashing ? out_len / 32 : 0u;
-            if (sub < 4) {
-                const uint32_t acc_i = sub;
-                uint64_t v = acc_i == 0 ? XP1 + XP2 : (acc_i == 1 ? XP2 : (acc_i == 2 ? 0ull : 0ull - XP1));
-                uint32_t q = res_off + 8 * acc_i;
+            uint64_t v = (sub & 3) == 0 ? XP1 + XP2 : ((sub & 3) == 1 ? XP2 : ((sub & 3) == 2 ? 0ull : 0ull - XP1));
+            if constexpr (LPF >= 8) { // SPG stripes per group, a lane per (stripe, accumulator); the chain in the file's first four lanes
+                constexpr uint32_t SPG = LPF >= 16 ? 4 : 2;
+                if (sub < 4 * SPG) { // (32 lanes a file: its first row)
+                    uint32_t q = res_off + 8 * sub;
+                    const uint32_t ng = nstripes / SPG, rest = nstripes % SPG;
+                    auto absorb = [&](uint64_t in) {
+                        const uint64_t t = in * XP2;
+                        v = xchain31<0>(v, t); v = xchain31<1>(v, t);
+                        if (SPG == 4) { v = xchain31<2>(v, t); v = xchain31<3>(v, t); }
+                    };
+                    uint32_t g = 0;
+                    for (; g + 2 <= ng; g += 2) { // (two groups' reads in flight)
+                        const uint64_t i0 = lds_u64(q), i1 = lds_u64(q + 32 * SPG);
+                        q += 64 * SPG;
+                        absorb(i0); absorb(i1);
+                    }
+                    if (g < ng) { absorb(lds_u64(q)); q += 32 * SPG; }
+                    if (rest) { // the last one to three stripes (lanes of stripes past the end hold anything: not used)
+                        const uint64_t t = lds_u64(q) * XP2;
+                        v = xchain31<0>(v, t);
+                        if (SPG == 4) { if (rest > 1) v = xchain31<1>(v, t); if (rest > 2) v = xchain31<2>(v, t); }
+                    }
+                }
+            } else if (sub < 4) {
+                uint32_t q = res_off + 8 * sub;
                 uint32_t s = 0;
                 for (; s + 4 <= nstripes; s += 4) {
                     const uint64_t i0 = lds_u64(q), i1 = lds_u64(q + 32), i2 = lds_u64(q + 64), i3 = lds_u64(q + 96);
@@ -1449,6 +1487,9 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                     q += 128;
                 }
                 for (; s < nstripes; s++) { v = xround(v, lds_u64(q)); q += 32; }
+            }
+            if (sub < 4) {
+                const uint32_t acc_i = sub;
                 const int base = (int)(lane & ~3u);
                 const uint64_t v1 = __shfl(v, base), v2 = __shfl(v, base + 1), v3 = __shfl(v, base + 2), v4 = __shfl(v, base + 3);
                 if (hashing && acc_i == 0) {

@@ -596,6 +596,7 @@ int ozs_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* o
     scratch sc; sc.lit = (uint8_t*)malloc(OZS_BLOCK_MAX + 32); sc.seq = (ozs_seq*)malloc(sizeof(ozs_seq) * (OZS_MAX_SEQ + 1));
     int rc = OZS_E_CORRUPT;
     size_t pos = 0, out = 0;
+    g_unpinned = 0; /* (per call: a decode that fails before any sequence is executed must not inherit the previous call's flag) */
     if (trace) trace->n = 0;
     if (!ds || !sc.lit || !sc.seq) goto done;
     rc = load_dict(ds, dict, dict_len);
