@@ -1070,20 +1070,23 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
 #else
 #define GSTAMP(acc)
 #endif
-            for (uint32_t c0 = 0; __any(c0 < nrun && !bad); c0 += LPF) {
+            // (WS sequences per call of the walk, at least 16 whatever LPF is -- the ring holds 16 records --: a call's fixed cost, the
+            //  hand-over of the state into the quad and back and the checks around it, was as long as four of its steps)
+            constexpr uint32_t WS = LPF < 16 ? 16u : LPF;
+            for (uint32_t c0 = 0; __any(c0 < nrun && !bad); c0 += WS) {
                 const bool act = c0 < nrun && !bad;
                 // ---- the walk
                 uint32_t wbad = 0;
                 bool done_asm = false;
                 if (lds_at_zero) { // the hot form, on the first quad of every file whose step is a full one (every sequence followed by a state update)
-                    if (act && sub < 4 && c0 + LPF < nrun) {
+                    if (act && sub < 4 && c0 + WS < nrun) {
                         auto quad = [](uint32_t v, auto ctrl_c) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl_c)::value, 0xF, 0xF, false); };
                         const std::integral_constant<int, 0x00> q0{}; const std::integral_constant<int, 0x55> q1{}; const std::integral_constant<int, 0xAA> q2{};
                         const uint32_t bL = quad(aL, q0), bM = quad(aM, q0), bO = quad(aO, q0), bG = quad(Gh, q0); // the leader's state
                         uint32_t A = sel(m_eq(sub, 0), bL, sel(m_eq(sub, 1), bM, sel(m_eq(sub, 2), bO, kShWalkDummy)));
                         uint32_t xG = bG - 32;
                         int32_t slack = 64;
-                        walk_asm<(int)LPF>(A, xG, slack, ringo + 4 * sub);
+                        walk_asm<(int)WS>(A, xG, slack, ringo + 4 * sub);
                         const uint32_t nM = quad(A, q1), nO = quad(A, q2);
                         if (leader && slack >= 0) { aL = A; aM = nM; aO = nO; Gh = xG + 32; done_asm = true; } // (else: a sequence wider than 32..63 bits met the window's edge)
                     }
@@ -1105,23 +1108,24 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                         aL = (uint32_t)EL + 8 * bfe(Y, hO + hM, hL);
                         Gh -= tot;
                     };
-                    if (c0 + LPF < nrun) { // every sequence of the step is followed by a state update
+                    if (c0 + WS < nrun) { // every sequence of the step is followed by a state update
                         if (!done_asm) {
-#pragma unroll
-                            for (uint32_t k = 0; k < LPF; k++) { record(k); step(); }
+                            for (uint32_t k = 0; k < WS; k++) { record(k); step(); }
                         }
                     } else { // the file's last step
                         const uint32_t cnt = nrun - c0;
                         for (uint32_t k = 0; k < cnt; k++) { record(k); if (k + 1 < cnt) step(); }
                     }
-                    wbad |= (uint32_t)(Gh - G0) >> 31; // over-read (bounded: <= LPF * 89 bits below the stream, inside the slot)
+                    wbad |= (uint32_t)(Gh - G0) >> 31; // over-read (bounded: <= WS * 89 bits below the stream, inside the slot)
                 }
                 wsync();
                 GSTAMP(tw_);
-                // ---- lane = sequence c0 + sub
+                // ---- lane = sequence c0 + e0 + sub
                 uint32_t pbad = wbad;
-                if (act && c0 + sub < nrun) {
-                    const V16 r16 = lds_v16(ringo + 16 * sub);
+#pragma unroll 1
+                for (uint32_t e0 = 0; e0 < WS; e0 += LPF)
+                if (act && c0 + e0 + sub < nrun) {
+                    const V16 r16 = lds_v16(ringo + 16 * (e0 + sub));
                     const struct { uint32_t x, y, z, w; } r = {(uint32_t)r16.a, (uint32_t)(r16.a >> 32), (uint32_t)r16.b, (uint32_t)(r16.b >> 32)};
                     const uint32_t hL = L32(r.x + 4), hM = L32(r.y + 4), hO = L32(r.z + 4);
                     const uint32_t xL = hL >> 24, xM = hM >> 24, xO = hO >> 24;
@@ -1136,9 +1140,9 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                     const uint32_t ofv = (1u << cO) + vO;
                     const uint32_t ml = (L32(kShML + 4 * cM) & 0xFFFFFF) + vM;
                     const uint32_t ll = (L32(kShLL + 4 * cL) & 0xFFFFFF) + vL;
-                    if (c0 + sub + 1 == nrun && tL != G0) pbad = 1; // the bitstream must be consumed exactly
+                    if (c0 + e0 + sub + 1 == nrun && tL != G0) pbad = 1; // the bitstream must be consumed exactly
                     if (((ll | ml) >> 14) | (cO > 18)) pbad = 1;     // (cannot be right for a window of <= 8 KiB and a dictionary of <= 128 KiB; keeps the packed fields in range)
-                    gs64(seq_g + 8 * (c0 + sub), (uint64_t)(ll | (ml << 14)) | ((uint64_t)ofv << 32));
+                    gs64(seq_g + 8 * (c0 + e0 + sub), (uint64_t)(ll | (ml << 14)) | ((uint64_t)ofv << 32));
                 }
                 {
                     const uint64_t pm = __ballot(pbad != 0);
@@ -1224,7 +1228,16 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
             // The write head of the execution never passes the literal read head -- what is still to be written is at least the
             // literals still to be read -- so literals and output share the window.
             const uint32_t lit_base = outo + cap - nlit;
-            for (uint32_t q = 16 * sub; q < nlit; q += 16 * LPF) { const V16 v = gv16(lit_p + q); lds_s64(lit_base + q, v.a); lds_s64(lit_base + q + 8, v.b); } // (<= 15 bytes past cap: the window's slack)
+            // (four trips in flight: one after the other, each waited for, was five round trips to L2 in front of every pass)
+            for (uint32_t q = 16 * sub; q < nlit; q += 4 * 16 * LPF) { // (<= 15 bytes past cap: the window's slack)
+                constexpr uint32_t S = 16 * LPF;
+                const bool h1 = q + S < nlit, h2 = q + 2 * S < nlit, h3 = q + 3 * S < nlit;
+                const V16 v0 = gv16(lit_p + q), v1 = h1 ? gv16(lit_p + q + S) : V16{0, 0}, v2 = h2 ? gv16(lit_p + q + 2 * S) : V16{0, 0}, v3 = h3 ? gv16(lit_p + q + 3 * S) : V16{0, 0};
+                lds_s64(lit_base + q, v0.a); lds_s64(lit_base + q + 8, v0.b);
+                if (h1) { lds_s64(lit_base + q + S, v1.a); lds_s64(lit_base + q + S + 8, v1.b); }
+                if (h2) { lds_s64(lit_base + q + 2 * S, v2.a); lds_s64(lit_base + q + 2 * S + 8, v2.b); }
+                if (h3) { lds_s64(lit_base + q + 3 * S, v3.a); lds_s64(lit_base + q + 3 * S + 8, v3.b); }
+            }
             wsync();
             auto load_rec = [&](uint32_t c0) -> uint64_t { return c0 + sub < nrun ? gu64(seq_g + 8 * (c0 + sub)) : 0ull; };
             struct StepA { uint32_t ll, ml, w0, lp, op, chunk_l, chunk_t; };
