@@ -203,11 +203,12 @@ DI void store_exact15(uint32_t at, uint32_t n, uint32_t d0, uint32_t d1, uint32_
 }
 // the minimum over the file's lanes, in all of them: DPP swaps inside quads, half rows and rows (no trip through the LDS crossbar
 // but for the second row of 32 lanes)
-template <int LPF> DI uint32_t seg_min(uint32_t x, uint32_t lane) {
-    x = min(x, (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, false)); // quad_perm: [1, 0, 3, 2]
-    x = min(x, (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, false)); // quad_perm: [2, 3, 0, 1]
-    if (LPF >= 8) x = min(x, (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, false)); // row_half_mirror
-    if (LPF >= 16) x = min(x, (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xF, 0xF, false)); // row_mirror
+template <int LPF> DI uint32_t seg_min(uint32_t x, uint32_t lane) { // (the DPP operand folded into the minimum: the compiler makes a move and a minimum of each stage)
+    if (LPF >= 16) asm("s_nop 1\n v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_nop 1\n v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                       " v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n s_nop 1\n v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(x));
+    else if (LPF == 8) asm("s_nop 1\n v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_nop 1\n v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                           " v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(x));
+    else asm("s_nop 1\n v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_nop 1\n v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(x));
     if (LPF >= 32) x = min(x, (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ 16u) * 4u), (int)x));
     return x;
 }
@@ -1376,6 +1377,7 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                     bool pending = m != 0;
                     const uint32_t send = mp - off + m; // end of the source
                     const uint32_t key0 = (mp << 18) | (simple ? (m << 13) | off : 0u);
+                    const bool rare_any = __ballot(pending & !simple) != 0; // (wave-uniform: most steps hold simple matches only)
                     bool wide = true, first_round = true; // (wave-uniform; a step's first round is a wide one)
                     for (;;) {
                         const uint64_t pm = __ballot(pending);
@@ -1422,7 +1424,7 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                         XSTAMP(xc_);
 #endif
                         const bool fc = pending & !simple & is_first; // the first one waiting, and not of the simple kind: longer, overlapping itself, starting in the dictionary
-                        const uint64_t cm = __ballot(fc);
+                        const uint64_t cm = rare_any ? __ballot(fc) : 0ull;
                         if (cm) {
                             const uint32_t seg = file_bits<LPF>(cm, f);
                             const uint32_t fl4 = ((lane & ~(LPF - 1)) + (seg ? (uint32_t)__builtin_ctz(seg) : 0u)) * 4;
