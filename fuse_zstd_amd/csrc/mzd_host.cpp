@@ -370,13 +370,24 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
                 return waves_per_cu(g, xg, tab) >= w;
             };
             uint32_t split_tab = 0;
-            if (p.nsmall > (uint64_t)cus * waves_per_cu(4, 4, p.lds_tab) * 4) {
-                // (8 / 4 first.  4 / 2 -- ten wavefronts of four files per CU, each file executed by 32 lanes -- was built and measured in
-                //  round 5: its groups are shorter (a group's median 281 us against 8 / 4's 254 on one workgroup alone) but ten wavefronts
-                //  share a CU's LDS pipeline and two SIMDs hold three of them: the slowest wavefront ends at 330 us, 8 / 4's at 297
-                //  (tools/lds_wg.py, profiles/r05_lds_wg_*.txt).  It stays for launches 8 / 4 cannot hold in one round.)
-                if (one_round(8, 4, split_tab)) { p.lds_g = 8; p.lds_xg = 4; p.lds_tab = split_tab; }
-                else if (one_round(4, 2, split_tab)) { p.lds_g = 4; p.lds_xg = 2; p.lds_tab = split_tab; }
+            if (!p.with_dict && cus) {
+                // What the shapes cost, measured (tools/small_shapes.py, profiles/r05_small_shapes.txt; JSON files, kernel ms at 10 000 files):
+                //   4 KiB: 4/4 0.390 (two rounds), 8/4 0.290, 4/2 0.315, 8/8 0.454 | 2 KiB: 4/4 0.202, 8/8 0.185 | 512 B: 4/4 0.141, 8/8 0.110
+                //   8 KiB: 4/4 0.755 (three rounds of 16 files a CU), 4/2 0.697 (two of 28)
+                // A CU's wavefronts share its LDS pipeline and, beyond two a SIMD, its issue slots: a launch that fits one round either
+                // way is faster on FEWER wavefronts of more files (8/8: the serial phases cost the same for eight files as for four).
+                const uint32_t w44 = waves_per_cu(4, 4, p.lds_tab);
+                const uint64_t cap44 = (uint64_t)cus * w44 * 4;
+                const uint32_t need44 = (uint32_t)((p.nsmall + 4ull * cus - 1) / (4ull * cus)); // wavefronts per CU that hold the launch at 4 / 4
+                if (p.nsmall > cap44) { // more than one round at 4 / 4
+                    // (8 / 4 first.  4 / 2 -- ten wavefronts of four files per CU, each file executed by 32 lanes -- was built and measured in
+                    //  round 5: its groups are shorter (a group's median 281 us against 8 / 4's 254 on one workgroup alone) but ten wavefronts
+                    //  share a CU's LDS pipeline and two SIMDs hold three of them: the slowest wavefront ends at 330 us, 8 / 4's at 297
+                    //  (tools/lds_wg.py, profiles/r05_lds_wg_*.txt).  It stays for launches 8 / 4 cannot hold in one round.)
+                    if (one_round(8, 4, split_tab)) { p.lds_g = 8; p.lds_xg = 4; p.lds_tab = split_tab; }
+                    else if (one_round(4, 2, split_tab)) { p.lds_g = 4; p.lds_xg = 2; p.lds_tab = split_tab; }
+                    else if (maxcap <= 768 && waves_per_cu(8, 8, p.lds_tab) * 8 > w44 * 4) { p.lds_g = 8; p.lds_xg = 8; } // many rounds of tiny files: more of them resident, half the wavefronts (512 B x 40 000: 0.265 against 0.304 ms; from 1 KiB on 4 / 4 is ahead)
+                } else if (need44 > 8 && one_round(8, 8, split_tab) && split_tab == p.lds_tab) { p.lds_g = 8; p.lds_xg = 8; } // one round either way: five wavefronts of eight rather than ten of four
             }
             const int dbg_g = g_small_g.load(std::memory_order_relaxed), dbg_xg = g_small_xg.load(std::memory_order_relaxed); // (mzd_debug_host_path 4 / 5)
             if (dbg_g == 4 || dbg_g == 8 || dbg_g == 16) {
