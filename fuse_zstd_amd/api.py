@@ -16,7 +16,7 @@ CONTENTSIZE_ERROR = 2**64 - 2
 # every symbol include/mzd.h declares
 EXPORTS = [
     "mzd_init", "mzd_init_ex", "mzd_shutdown", "mzd_device_count", "mzd_content_size", "mzd_content_bound", "mzd_decode", "mzd_decode_batch",
-    "mzd_decode_batch_device", "mzd_batch_prepare", "mzd_batch_launch", "mzd_batch_collect", "mzd_batch_free",
+    "mzd_decode_batch_device", "mzd_batch_prepare", "mzd_batch_launch", "mzd_batch_launch_ex", "mzd_batch_collect", "mzd_batch_free",
     "mzd_load_dict", "mzd_unload_dict", "mzd_debug_last_block", "mzd_debug_set_driver", "mzd_debug_counters", "mzd_debug_host_path", "mzd_debug_stamps", "mzd_debug_small_stamps", "mzd_debug_small_wg_stamps", "mzd_debug_small_scratch", "mzd_debug_tfin_all", "mzd_debug_lazy_plan",
     "mzd_host_alloc", "mzd_host_free", "mzd_last_kernel_ms", "mzd_last_kernel_name", "mzd_strerror", "mzd_version",
     "mzd_fs_new", "mzd_fs_free", "mzd_fs_open", "mzd_fs_open_lazy", "mzd_fs_read", "mzd_fs_release", "mzd_fs_decode_count", "mzd_fs_decoded_bytes",
@@ -96,6 +96,8 @@ def lib():
         L.mzd_decode_batch_device.argtypes = [C.c_int, C.POINTER(Job), C.c_size_t, C.c_void_p]
         L.mzd_batch_prepare.argtypes = [C.c_int, C.POINTER(Job), C.c_size_t, C.POINTER(C.c_void_p)]
         L.mzd_batch_launch.argtypes = [C.c_void_p, C.c_void_p]
+        if hasattr(L, "mzd_batch_launch_ex"):  # (A/B runs load older builds of the library)
+            L.mzd_batch_launch_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
         L.mzd_batch_collect.argtypes = [C.c_void_p, C.POINTER(Job), C.c_void_p]
         L.mzd_batch_free.argtypes = [C.c_void_p]
         L.mzd_batch_free.restype = None
@@ -257,8 +259,12 @@ class Batch:
         if rc != OK:
             raise MzdError(rc, "mzd_batch_prepare")
 
-    def launch(self, stream=None):
-        rc = lib().mzd_batch_launch(self.h, stream)
+    def launch(self, stream=None, untimed=False):
+        """untimed: MZD_LAUNCH_UNTIMED -- no start event in front of the launch (measurement loops time the whole loop themselves)."""
+        if untimed and hasattr(lib(), "mzd_batch_launch_ex"):
+            rc = lib().mzd_batch_launch_ex(self.h, stream, 1)
+        else:
+            rc = lib().mzd_batch_launch(self.h, stream)
         if rc != OK:
             raise MzdError(rc, "mzd_batch_launch")
 

@@ -456,7 +456,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     // or a few very big files, which are chains however many blocks they have); 2: only tasks whose predecessor is still
     // running when they start (launches with more tasks than that)
     ka.resolve = !use_tasks || force == 5 || !d.resolve_map ? 0u : ((force == 4 || p.blocks <= 8ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : 2u);
-    HIPCHK(hipEventRecord(ev0, s));
+    if (ev0) HIPCHK(hipEventRecord(ev0, s)); // (null: an untimed launch -- mzd_batch_launch_ex)
     uint32_t grid;
     if (p.nsmall) {
         LdsArgs la;
@@ -970,6 +970,7 @@ struct mzd_batch {
     Plan plan;
     std::shared_ptr<Device> dev;
     bool solo = false; // the last launch ended with the small-file kernel: what it handed on is decoded by collect
+    bool timed = true; // the last launch recorded its start event (mzd_last_kernel_ms)
 };
 
 extern "C" {
@@ -1152,7 +1153,7 @@ int mzd_batch_prepare(int device, const mzd_job* jobs, size_t njobs, mzd_batch**
     if (!d) return MZD_E_DEVICE;
     if (!jobs || !out || njobs == 0 || njobs > 0x7FFFFFF0u) return MZD_E_PARAM;
     HIPCHK(hipSetDevice(d->hip_id));
-    auto* b = new mzd_batch{device, nullptr, nullptr, nullptr, njobs, Plan{}, d, false};
+    auto* b = new mzd_batch{device, nullptr, nullptr, nullptr, njobs, Plan{}, d, false, true};
     std::vector<uint32_t> lists(njobs * 2);
     if (hipMalloc(&b->d_jobs, njobs * sizeof(DevJob)) != hipSuccess || hipMalloc(&b->d_lists, (njobs * 2 + 4) * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc(&b->h_jobs, njobs * sizeof(DevJob), hipHostMallocDefault) != hipSuccess) {
@@ -1168,14 +1169,19 @@ int mzd_batch_prepare(int device, const mzd_job* jobs, size_t njobs, mzd_batch**
     return MZD_OK;
 }
 
-int mzd_batch_launch(mzd_batch* b, void* stream) {
+int mzd_batch_launch(mzd_batch* b, void* stream) { return mzd_batch_launch_ex(b, stream, 0u); }
+
+int mzd_batch_launch_ex(mzd_batch* b, void* stream, unsigned flags) {
     if (!b) return MZD_E_PARAM;
     Device& d = *b->dev;
     HIPCHK(hipSetDevice(d.hip_id));
     WholeGuard g(d); // (launches of one batch follow each other on `stream`; host-path launches wait for their end event)
     d.whole_used.store(true, std::memory_order_relaxed);
     b->solo = b->plan.nsmall && b->plan.nbig == 0 && !g_keep_behind.load(std::memory_order_relaxed);
-    const int rc = enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists, d.whole.ev0, d.whole.ev1, b->solo ? b->d_lists + 2 * b->njobs : nullptr);
+    // (untimed: the start event is left out -- one packet less between two launches of a measurement loop; the end event stays, it is
+    //  what host-path launches wait for when a device-path launch may still be running on a caller's stream)
+    const int rc = enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists, (flags & MZD_LAUNCH_UNTIMED) ? nullptr : d.whole.ev0, d.whole.ev1, b->solo ? b->d_lists + 2 * b->njobs : nullptr);
+    b->timed = (flags & MZD_LAUNCH_UNTIMED) == 0;
     d.job0_counter = d.whole.counter; d.job0_snap_valid = false;
     return rc;
 }
@@ -1194,7 +1200,7 @@ int mzd_batch_collect(mzd_batch* b, mzd_job* jobs, void* stream) {
     HIPCHK(hipMemcpyAsync(b->h_jobs, b->d_jobs, b->njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (b->solo) { d.job0_snap[4] = handed; d.job0_snap_valid = true; } // (word 4 is the batch's own record: another batch's launch may have cleaned the block since)
-    HIPCHK(hipEventElapsedTime(&d.last_ms, d.whole.ev0, d.whole.ev1));
+    if (b->timed) HIPCHK(hipEventElapsedTime(&d.last_ms, d.whole.ev0, d.whole.ev1)); // (an untimed last launch: the figure of the last timed one stands)
     if (b->solo && handed) { // (the launch ended with the small-file kernel: the files it handed on take the general driver now)
         if (handed > b->njobs) return MZD_E_DEVICE;
         WholeGuard g(d);

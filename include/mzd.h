@@ -137,6 +137,10 @@ int mzd_decode_batch_device(int device, mzd_job* jobs, size_t njobs, void* strea
 typedef struct mzd_batch mzd_batch;
 int mzd_batch_prepare(int device, const mzd_job* jobs, size_t njobs, mzd_batch** out);
 int mzd_batch_launch(mzd_batch* b, void* stream);
+/* The same with flags.  MZD_LAUNCH_UNTIMED: the launch does not record its start event (mzd_last_kernel_ms keeps the figure of the last
+ * timed launch) -- for loops that time many back-to-back launches themselves: an event is a packet between two kernels. */
+#define MZD_LAUNCH_UNTIMED 1u
+int mzd_batch_launch_ex(mzd_batch* b, void* stream, unsigned flags);
 int mzd_batch_collect(mzd_batch* b, mzd_job* jobs, void* stream);
 void mzd_batch_free(mzd_batch* b);
 
