@@ -50,7 +50,7 @@ constexpr uint32_t kMaxDicts = 64;
 constexpr size_t kMaxChunks = 16;               // ... and at most this many chunks per call
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
-std::atomic<int> g_small_g{0}, g_small_xg{0}, g_trace_t2{0}, g_keep_behind{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
+std::atomic<int> g_small_g{0}, g_small_xg{0}, g_small_nw{0}, g_trace_t2{0}, g_keep_behind{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
 std::atomic<unsigned> g_small_grid{0};               // mzd_debug_host_path 6: its grid (0: as many wavefronts as the device holds)
 constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 1280u; // (a workgroup's LDS is allocated in steps of 320 dwords: tools/micro/lds_granule_micro.hip -- five workgroups of 32 000 bytes share a CU, five of 32 640 do not, and the occupancy API says they do)
 std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic with the
@@ -274,6 +274,7 @@ struct Plan {
     bool with_dict = false, multi = false;
     uint32_t lit_stride = 0;   // literal scratch per small file: largest capacity + 64
     int lds_g = 4, lds_xg = 4; // files per wavefront of the small-file kernel (mzd_lds.hip), and how many of them it executes at a time
+    int lds_nw = 1;            // its wavefronts per workgroup (2: a helper wavefront parses the sequence headers beside the Huffman phases)
     uint32_t lds_tab = 0, lds_comp = 0, lds_out = 0; // its slot geometry (LdsArgs)
     uint32_t big_tasks = 0;    // workgroups worth launching for the files that are not small
     uint64_t blocks = 0;       // block tasks of those files, estimated from their capacities
@@ -352,22 +353,22 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
             // and only four are executed at a time: eight entropy images fit where four windows do (mzd_lds.hip, XG).  The table area
             // is cut to what lets W wavefronts of eight files share a CU (files whose tables need more are handed on); not below
             // 1 792 bytes (a 9-bit Huffman table, 224 FSE entries).
-            auto waves_per_cu = [&](int g, int xg, uint32_t tab) -> uint32_t {
-                const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(g, xg, p.with_dict, tab, p.lds_comp, p.lds_out), kLdsGranule);
-                return lds > kLdsPerCu ? 0u : std::min<uint32_t>(lds_waves_by_registers(g, xg, p.with_dict), kLdsPerCu / lds);
+            auto waves_per_cu = [&](int g, int xg, uint32_t tab, int nw = 1) -> uint32_t { // (workgroups per CU)
+                const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(g, xg, p.with_dict, tab, p.lds_comp, p.lds_out, nw), kLdsGranule);
+                return lds > kLdsPerCu ? 0u : std::min<uint32_t>(lds_waves_by_registers(g, xg, p.with_dict, nw) / (uint32_t)nw, kLdsPerCu / lds);
             };
-            auto one_round = [&](int g, int xg, uint32_t& tab) -> bool { // does the launch fit ONE round of groups of g files executed xg at a time?
+            auto one_round = [&](int g, int xg, uint32_t& tab, int nw = 1) -> bool { // does the launch fit ONE round of groups of g files executed xg at a time?
                 if (p.with_dict || cus == 0) return false;
-                const uint32_t w = (uint32_t)((p.nsmall + (uint64_t)g * cus - 1) / ((uint64_t)g * cus)); // wavefronts per CU
-                if (w < 1 || w > lds_waves_by_registers(g, xg, 0)) return false;
+                const uint32_t w = (uint32_t)((p.nsmall + (uint64_t)g * cus - 1) / ((uint64_t)g * cus)); // workgroups per CU
+                if (w < 1 || w > lds_waves_by_registers(g, xg, 0, nw) / (uint32_t)nw) return false;
                 const uint32_t budget = kLdsPerCu / w / kLdsGranule * kLdsGranule;
-                const uint32_t fixed = lds_kernel_bytes(g, xg, 0, 0, 0, 0) - (uint32_t)g * lds_kernel_bytes_per_file(0, 0); // the wavefront's tables and the files' records
+                const uint32_t fixed = lds_kernel_bytes(g, xg, 0, 0, 0, 0, nw) - (uint32_t)g * lds_kernel_bytes_per_file(0, 0); // the wavefront's tables and the files' records
                 if (budget < fixed + (uint32_t)xg * p.lds_out) return false;
                 const uint32_t per_file = (budget - fixed) / (uint32_t)g;            // tables + (counts, work, input)
                 const uint32_t rest = lds_kernel_bytes_per_file(0, p.lds_comp);      // (counts, work, input)
                 if (per_file < rest + 1792u) return false;
                 tab = std::min<uint32_t>(p.lds_tab, (per_file - rest) & ~15u);
-                return waves_per_cu(g, xg, tab) >= w;
+                return waves_per_cu(g, xg, tab, nw) >= w;
             };
             uint32_t split_tab = 0;
             if (!p.with_dict && cus) {
@@ -384,7 +385,13 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
                     //  round 5: its groups are shorter (a group's median 281 us against 8 / 4's 254 on one workgroup alone) but ten wavefronts
                     //  share a CU's LDS pipeline and two SIMDs hold three of them: the slowest wavefront ends at 330 us, 8 / 4's at 297
                     //  (tools/lds_wg.py, profiles/r05_lds_wg_*.txt).  It stays for launches 8 / 4 cannot hold in one round.)
-                    if (one_round(8, 4, split_tab)) { p.lds_g = 8; p.lds_xg = 4; p.lds_tab = split_tab; }
+                    // (8 / 4 with a HELPER wavefront -- the sequence headers, 48 K of a group's 600 K cycles, parsed on a second wavefront beside the
+                    //  Huffman phases -- was built and measured in round 5 and is no faster: 0.290-0.293 ms against 0.2895.  Ten wavefronts a
+                    //  CU put two or three on every SIMD, a workgroup's two go to SIMDs 0/2 or 1/3, so decoding wavefronts share SIMDs with each
+                    //  other where five one-wavefront workgroups have three SIMDs to themselves -- and both phases are bound by instruction issue;
+                    //  168 registers instead of 256 cost 2 % by themselves.  It stays behind mzd_debug_host_path 9 = 2.)
+                    if (g_small_nw.load(std::memory_order_relaxed) == 2 && one_round(8, 4, split_tab, 2)) { p.lds_g = 8; p.lds_xg = 4; p.lds_nw = 2; p.lds_tab = split_tab; }
+                    else if (one_round(8, 4, split_tab)) { p.lds_g = 8; p.lds_xg = 4; p.lds_tab = split_tab; }
                     else if (one_round(4, 2, split_tab)) { p.lds_g = 4; p.lds_xg = 2; p.lds_tab = split_tab; }
                     else if (maxcap <= 768 && waves_per_cu(8, 8, p.lds_tab) * 8 > w44 * 4) { p.lds_g = 8; p.lds_xg = 8; } // many rounds of tiny files: more of them resident, half the wavefronts (512 B x 40 000: 0.265 against 0.304 ms; from 1 KiB on 4 / 4 is ahead)
                 } else if (need44 > 8 && one_round(8, 8, split_tab) && split_tab == p.lds_tab) { p.lds_g = 8; p.lds_xg = 8; } // one round either way: five wavefronts of eight rather than ten of four
@@ -393,9 +400,10 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
             if (dbg_g == 4 || dbg_g == 8 || dbg_g == 16) {
                 p.lds_g = dbg_g; p.lds_xg = (dbg_xg == 4 && dbg_g == 8 && !p.with_dict) ? 4 : ((dbg_xg == 2 && dbg_g == 4 && !p.with_dict) ? 2 : dbg_g);
                 p.lds_tab = (p.with_dict && all_dict) ? lds_spare_table_bytes(p.lds_comp, p.lds_out) : (maxcap <= 5120 ? 2048u : 4096u);
-                if (p.lds_g != p.lds_xg && one_round(p.lds_g, p.lds_xg, split_tab)) p.lds_tab = split_tab;
+                p.lds_nw = (g_small_nw.load(std::memory_order_relaxed) == 2 && p.lds_g == 8 && p.lds_xg == 4) ? 2 : 1;
+                if (p.lds_g != p.lds_xg && one_round(p.lds_g, p.lds_xg, split_tab, p.lds_nw)) p.lds_tab = split_tab;
             }
-            while (p.lds_g > 4 && lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out) > kLdsPerCu) { p.lds_g /= 2; p.lds_xg = p.lds_g; }
+            while (p.lds_g > 4 && lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out, p.lds_nw) > kLdsPerCu) { p.lds_g /= 2; p.lds_xg = p.lds_g; p.lds_nw = 1; }
         }
     }
     // Multi-block files in a launch that fills the machine many times over: block tasks keep a workgroup slot waiting while a file's
@@ -467,21 +475,22 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         la.stamps = reinterpret_cast<uint64_t*>(d.debug); // (diagnostic builds: the first debug slot's first bytes; unused otherwise)
         la.counter_next = solo ? l.cnt[l.flip] : nullptr; la.handed_on = solo ? handed_on : nullptr;
         const uint32_t ngroups = (p.nsmall + (uint32_t)p.lds_g - 1) / (uint32_t)p.lds_g;
-        const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out), kLdsGranule);
+        const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out, p.lds_nw), kLdsGranule);
         // one wavefront per workgroup; as many as the whole device holds, also for a launch on one of the host path's lanes: this
         // kernel uses none of the per-workgroup scratch the lanes divide, and a chunk of small files that gets a quarter of the wave
         // slots takes four rounds of groups where one would do (cfg4 host -> host: 1.5 -> ms)
-        const uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(lds_waves_by_registers(p.lds_g, p.lds_xg, p.with_dict), kLdsPerCu / lds));
-        la.lit_stride = p.lit_stride; la.seq_cap = (p.lit_stride - 64) / 3 + 2;
+        const uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(lds_waves_by_registers(p.lds_g, p.lds_xg, p.with_dict, p.lds_nw) / (uint32_t)p.lds_nw, kLdsPerCu / lds));
+        la.lit_stride = p.lit_stride; la.seq_cap = ((p.lit_stride - 64) / 3 + 3) & ~1u; // (even: the array of full records behind the 4-byte ones is 8-byte aligned)
         la.scratch = l.small_lit;
         if (&l == &d.whole) { d.last_lds_lit_stride = la.lit_stride; d.last_lds_seq_cap = la.seq_cap; }
         const size_t per_wave = (size_t)p.lds_g * lds_scratch_per_file(la.lit_stride, la.seq_cap);
         const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / per_wave);
         const uint32_t dbg_grid = g_small_grid.load(std::memory_order_relaxed); // (mzd_debug_host_path 6: experiments with fewer resident wavefronts)
-        { int lrc = launch_lds(la, std::min(ngroups, std::min(dbg_grid ? dbg_grid : resident, by_scratch)), p.lds_g, p.lds_xg, p.with_dict ? 1 : 0, s); if (lrc) return lrc; }
+        { int lrc = launch_lds(la, std::min(ngroups, std::min(dbg_grid ? dbg_grid : resident, by_scratch)), p.lds_g, p.lds_xg, p.with_dict ? 1 : 0, p.lds_nw, s); if (lrc) return lrc; }
         if (&l == &d.whole) {
             char small[48];
-            snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg);
+            if (p.lds_nw > 1) snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg, p.lds_nw);
+            else snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg);
             const char* big = use_tasks ? "mzd_decode_kernel_tasks" : "mzd_decode_kernel_files";
             if (solo) d.set_kernels(small);
             else if (p.nbig > p.nsmall) d.set_kernels(big, small);
@@ -1033,7 +1042,8 @@ int mzd_debug_host_path(int device, int what, int value) {
     if (what == 5) { g_small_xg.store(value); return MZD_OK; }
     if (what == 6) { g_small_grid.store(value < 0 ? 0u : (unsigned)value); return MZD_OK; }
     if (what == 7) { g_trace_t2.store(value); return MZD_OK; }
-    if (what == 8) { g_keep_behind.store(value); return MZD_OK; } // (the general driver's launch behind a launch of small files alone stays: A/B)
+    if (what == 8) { g_keep_behind.store(value); return MZD_OK; }
+    if (what == 9) { g_small_nw.store(value); return MZD_OK; } // (the small-file kernel's wavefronts per workgroup: 0 the library's choice, 1 never a helper wavefront, 2 with the 8 / 4 shape always) // (the general driver's launch behind a launch of small files alone stays: A/B)
     return MZD_E_PARAM;
 }
 void* mzd_host_alloc(size_t n) {
@@ -1360,10 +1370,18 @@ int mzd_debug_small_scratch(int device, uint32_t slot, uint8_t* lit, size_t lit_
     WholeGuard g(*dp);
     HIPCHK(hipSetDevice(dp->hip_id));
     if (!dp->last_lds_lit_stride) return MZD_E_PARAM;
-    const size_t per = (size_t)dp->last_lds_lit_stride + 8u * (size_t)dp->last_lds_seq_cap;
+    const size_t per = (size_t)dp->last_lds_lit_stride + 12u * (size_t)dp->last_lds_seq_cap;
     if ((slot + 1) * per > dp->small_lit_total || lit_n > dp->last_lds_lit_stride || seq_n > dp->last_lds_seq_cap) return MZD_E_PARAM;
     if (lit && lit_n) HIPCHK(hipMemcpy(lit, dp->small_lit + slot * per, lit_n, hipMemcpyDeviceToHost));
-    if (seq && seq_n) HIPCHK(hipMemcpy(seq, dp->small_lit + slot * per + dp->last_lds_lit_stride, 8 * seq_n, hipMemcpyDeviceToHost));
+    if (seq && seq_n) { // the kernel's 4-byte records, widened (the full records of the sequences that do not fit: the second array)
+        std::vector<uint32_t> r4(seq_n);
+        std::vector<uint64_t> r8(seq_n);
+        const uint8_t* const base = dp->small_lit + slot * per + dp->last_lds_lit_stride;
+        HIPCHK(hipMemcpy(r4.data(), base, 4 * seq_n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(r8.data(), base + 4u * (size_t)dp->last_lds_seq_cap, 8 * seq_n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < seq_n; i++)
+            seq[i] = (r4[i] & 127u) == 127u ? r8[i] : ((uint64_t)((r4[i] & 127u) | ((((r4[i] >> 7) & 63u) + 3u) << 14)) | ((uint64_t)(r4[i] >> 13) << 32));
+    }
     return MZD_OK;
 }
 

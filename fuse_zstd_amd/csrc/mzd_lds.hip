@@ -344,7 +344,7 @@ DI uint64_t xxh_tail(uint64_t hh, uint32_t q, uint32_t end) {
 
 // Diagnostic build only (-DMZD_SMALL_STAMPS): cycle counter of workgroup 0 at every phase boundary of its first group.
 #ifdef MZD_SMALL_STAMPS
-#define SSTAMP(k) do { if (a.stamps && lane == 0 && first_group) { if (blockIdx.x == 0) a.stamps[k] = __builtin_readcyclecounter(); if ((k) < 12 && blockIdx.x < 3072) a.stamps[2048 + 16 * blockIdx.x + 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define SSTAMP(k) do { if (a.stamps && w0 && lane == 0 && first_group) { if (blockIdx.x == 0) a.stamps[k] = __builtin_readcyclecounter(); if ((k) < 12 && blockIdx.x < 3072) a.stamps[2048 + 16 * blockIdx.x + 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define SSTAMP(k)
 #endif
@@ -453,16 +453,28 @@ struct DictInfo { // the dictionary whose image sits in LDS (wave-uniform)
 // 64 / XG lanes each.  XG < G is for launches that would otherwise need two rounds of groups: the entropy images of G = 8 files of
 // 4 KiB (3.9 KB each) fit where only four windows (4.1 KB each) do, so five wavefronts per CU hold 40 files -- 10 240 on the
 // device -- instead of 32.  What an execution pass needs to know about a file crosses over in a 32-byte record in LDS.
-template <int G, bool DICT, int XG>
-__global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(LdsArgs a) {
+// NW = 2: a HELPER wavefront beside the one that decodes.  The sequences section's header -- nbSeq, modes, three normalized-count
+// descriptions: a serial parse on one lane per file, 48 K of a group's 600 K cycles -- depends on nothing the Huffman phases
+// produce, so the helper parses it (on another SIMD) while the first wavefront decodes weights, table and literal streams, and
+// hands the result over in LDS; then it sleeps at the group's last barrier.  Three workgroup barriers a group; the helper
+// learns the group (and the launch's end) from a control word.  Ten wavefronts a CU instead of five: 168 registers.
+template <int G, bool DICT, int XG, int NW = 1>
+__global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) void mzd_lds_kernel(LdsArgs a) {
     constexpr uint32_t LPF = 64 / G; // lanes per file in the entropy phases
     constexpr uint32_t XLPF = 64 / XG, NX = G / XG; // lanes per file = sequences per plan step in the execution; passes
     static_assert(LPF >= 4, "four Huffman streams");
     static_assert(XLPF >= 4 && XLPF <= 32 && G % XG == 0, "four XXH64 accumulators; a file's lanes inside one DPP row, or two (the scans carry over)");
-    const uint32_t lane = threadIdx.x;
+    static_assert(NW == 1 || (NW == 2 && !DICT), "the helper wavefront: files without a dictionary");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = NW > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+    const bool w0 = NW == 1 || wv == 0; // the decoding wavefront (wave-uniform)
     const uint32_t f = lane / LPF, sub = lane % LPF;
     const bool leader = sub == 0;
-    constexpr uint32_t kShRec = kShBytes, kShAll = kShBytes + 32 * G; // the files' records behind the wavefront's tables
+    // the files' records behind the wavefront's tables; (NW = 2) 64 bytes a file between the two wavefronts: {flags, n, cap, dict} from
+    // the decoding one, the parsed sequence header back from the helper
+    constexpr uint32_t kShRec = kShBytes, kShSeqRec = kShBytes + 32 * G, kShAll = kShSeqRec + (NW > 1 ? 64 * G : 0);
+    constexpr uint32_t kShCtl = kShWalkDummy + 8; // (NW = 2) the group the decoding wavefront is on; >= the number of groups: the launch is over
+    auto wgsync = [&]() { if constexpr (NW > 1) __syncthreads(); };
     const uint32_t dict_off = kShAll;
     const uint32_t ent = a.tab_bytes + kAux + a.comp_bytes;                // the entropy phase's image of a file ...
     const uint32_t stride = G != XG ? ent : (ent > a.out_bytes ? ent : a.out_bytes); // ... and (XG == G) its output window share the slot
@@ -472,13 +484,19 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
     // the sequences section -- and a launch whose slots leave less than three full tables' room still keeps its files
     const uint32_t ringo = slots0 + f * stride;
     const uint32_t tabo = ringo + kAux, cmp = tabo + a.tab_bytes;
-    // the file's share of the scratch in HBM: literals, then the sequences (8 bytes each)
-    uint8_t* const lit_g = a.scratch + (size_t)(blockIdx.x * G + f) * ((size_t)a.lit_stride + 8u * (size_t)a.seq_cap);
+    // the file's share of the scratch in HBM: literals, then the sequences -- 4 bytes each: literal length (7 bits) | match length - 3
+    // (6) | offset value (19); a sequence that does not fit (a literal run of 127 bytes or more, a match of 66 or more) says so in
+    // its literal-length field and has its full 8-byte record in a second array at the same index, touched by those sequences only
+    // (round 4 wrote 8 bytes a sequence: 27 of the 108 MB a launch of 10 000 files moved)
+    uint8_t* const lit_g = a.scratch + (size_t)(blockIdx.x * G + f) * ((size_t)a.lit_stride + 12u * (size_t)a.seq_cap);
     uint8_t* const seq_g = lit_g + a.lit_stride;
+    uint8_t* const seq8_g = seq_g + 4u * (size_t)a.seq_cap; // (seq_cap is even: 8-byte aligned)
 
-    if (lane < 36) L32(kShLL + 4 * lane) = LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24);
-    if (lane < 53) L32(kShML + 4 * lane) = ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24);
-    if (lane == 0) L64(kShWalkDummy) = (uint64_t)kShWalkDummy;
+    if (w0) {
+        if (lane < 36) L32(kShLL + 4 * lane) = LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24);
+        if (lane < 53) L32(kShML + 4 * lane) = ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24);
+        if (lane == 0) L64(kShWalkDummy) = (uint64_t)kShWalkDummy;
+    }
     wsync();
     DictInfo di;
     di.handle = 0; di.formatted = 0; di.dict_id = 0; di.content_len = 0; di.huf_log = 0; di.content = nullptr;
@@ -488,13 +506,13 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
     // A launch without a general driver behind it (LdsArgs::counter_next): the last wavefront to leave publishes how many files were
     // handed on -- the host decodes them when it collects the launch -- and zeroes the counter block of the lane's next launch.
     auto leave = [&]() {
-        if (a.counter_next && lane == 0 && atomicAdd(&a.counter[6], 1u) == gridDim.x - 1) { // (a wavefront's additions to word 4 have returned by now)
+        if (a.counter_next && w0 && lane == 0 && atomicAdd(&a.counter[6], 1u) == gridDim.x - 1) { // (a wavefront's additions to word 4 have returned by now)
             *a.handed_on = atomicAdd(&a.counter[4], 0u);
             for (uint32_t k = 0; k < kCounterWords; k++) a.counter_next[k] = 0;
         }
     };
     if (!lds_at_zero) { // cannot be (this kernel has no other LDS object); if it ever is, the general driver decodes everything
-        for (uint32_t i = blockIdx.x * 64 + threadIdx.x; i < a.n; i += gridDim.x * 64) a.redo_list[atomicAdd(&a.counter[4], 1u)] = a.list[i];
+        if (w0) for (uint32_t i = blockIdx.x * 64 + lane; i < a.n; i += gridDim.x * 64) a.redo_list[atomicAdd(&a.counter[4], 1u)] = a.list[i];
         leave();
         return;
     }
@@ -527,12 +545,16 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
     uint32_t wg_groups_ = 0, wg_rounds_ = 0, wg_steps_ = 0;
     uint64_t wg_te_ = 0;
 #endif
-    uint32_t g = ticket();
-    JobRegs J = job_entry(list_entry(g));
+    uint32_t g = 0xFFFFFFFFu;
+    JobRegs J = job_entry(0xFFFFFFFFu);
     V16 pf[kPF];
-    prefetch(J, pf);
+    if (w0) { g = ticket(); J = job_entry(list_entry(g)); prefetch(J, pf); }
     for (;;) {
         SSTAMP(0);
+        if constexpr (NW > 1) { // the helper learns the group from the decoding wavefront (first barrier of the group)
+            if (!w0) { __syncthreads(); g = (uint32_t)__builtin_amdgcn_readfirstlane((int)L32(kShCtl)); }
+            else if (g >= ngroups) { if (lane == 0) L32(kShCtl) = g; __syncthreads(); }
+        }
         if (g >= ngroups) break;
         // (what the trips for the next group leave behind outlives the entropy phases' scope)
         const bool early = g + gridDim.x < ngroups;
@@ -543,10 +565,11 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
 
         // =============================== the group's files: the compressed bytes -> LDS
         const uint32_t fidx = g * G + f;
-        const bool have = J.have, fits = J.fits;
-        const uint32_t job = J.job, n = J.n, cap = J.cap, jdict = J.jdict;
+        bool have = J.have, fits = J.fits;
+        uint32_t n = J.n, cap = J.cap, jdict = J.jdict;
+        const uint32_t job = J.job;
         const uint8_t* const src = J.src; uint8_t* const dst = J.dst; uint8_t* const dst2 = J.dst2;
-        if (fits) { // 16 bytes per lane: what came ahead, then the rest, four loads in flight
+        if (w0 && fits) { // 16 bytes per lane: what came ahead, then the rest, four loads in flight
 #pragma unroll
             for (int k = 0; k < kPF; k++) { const uint32_t o = 16 * (sub + LPF * (uint32_t)k); if (o < n) lds_sv16(cmp + o, pf[k]); }
             uint32_t k = (sub + LPF * kPF) * 16;
@@ -558,7 +581,18 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
         }
         // (trip 1 for the next group -- only while at least a grid's worth of groups is left behind this one: a wavefront that books its
         //  next group early takes it from one that would have been free sooner, which matters when a launch has about a group per wavefront)
-        if (early) g_next = ticket();
+        if (w0 && early) g_next = ticket();
+        if constexpr (NW > 1) { // the group's input is in LDS: the helper may start (what it needs to know of a file goes along)
+            const uint32_t xo = kShSeqRec + 64 * f;
+            if (w0) {
+                if (leader) lds_sv16(xo, V16{(uint64_t)((have ? 1u : 0u) | (fits ? 2u : 0u)) | ((uint64_t)n << 32), (uint64_t)cap | ((uint64_t)jdict << 32)});
+                if (lane == 0) L32(kShCtl) = g;
+                __syncthreads();
+            } else {
+                const V16 x = lds_v16(xo);
+                have = ((uint32_t)x.a & 1u) != 0; fits = ((uint32_t)x.a & 2u) != 0; n = (uint32_t)(x.a >> 32); cap = (uint32_t)x.b; jdict = (uint32_t)(x.b >> 32);
+            }
+        }
         // the group's dictionary: the first one named (the host sorts the list by dictionary)
         if (DICT) {
             const uint64_t named = __ballot(have && jdict != 0 && jdict <= a.ndicts);
@@ -688,14 +722,16 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
         bool live = ok && !done; // a compressed block to decode
         const uint32_t stored_ck = (ok && has_ck && n >= 4) ? lds_u32(cmp + n - 4) : 0u; // (read now: the windows will lie over the input)
         const uint32_t rle_byte = (ok && done && n != 0 && btype == 1) ? L8(cmp + b0) : 0u; // (an RLE block's byte; a raw block's bytes are taken from the input in HBM when the file's pass comes)
-        const uint32_t job_next = early ? list_entry(g_next) : 0xFFFFFFFFu; // (trip 2)
+        const uint32_t job_next = (w0 && early) ? list_entry(g_next) : 0xFFFFFFFFu; // (trip 2)
         SSTAMP(2);
 
         // =============================== Huffman weights and decode table (one lane per file)
         uint32_t huf_log = di.huf_log, huf_off = dict_off + kDHuf; // treeless: the dictionary's table
-        if (live && lit_type == 2) {
+        if (w0 && live && lit_type == 2) {
             uint32_t good = 0, maxbits_l = 0, nw_l = 0;
-            const uint32_t wts = ringo, wtab = tabo + kWTab, wnorm = tabo + kWNorm;
+            // (the weights: in the ring -- with a helper wavefront, which is writing the sequence tables' counts there meanwhile, in the table
+            //  area's last 256 bytes: a table of more than 9 bits then does not fit beside them, and its file is handed on)
+            const uint32_t wts = NW > 1 ? tabo + a.tab_bytes - 256 : ringo, wtab = tabo + kWTab, wnorm = tabo + kWNorm;
             const uint32_t tp = cmp + tree_off; // the tree description
             const uint32_t hb = L8(tp);
             // FSE-coded weights: their normalized counts (the file's first lane), then their decode table (all its lanes)
@@ -817,7 +853,7 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                 const uint32_t total = bcast<LPF - 1, LPF>(tot);
                 bool g2 = over == 0 && total != 0;
                 const uint32_t maxbits = g2 ? (uint32_t)hibit32(total) + 1 : 1u;
-                g2 = g2 && maxbits <= 11 && (2u << maxbits) <= a.tab_bytes; // (a table that does not fit the slot, a tree of depth 12: the general path takes the file)
+                g2 = g2 && maxbits <= 11 && (2u << maxbits) + (NW > 1 ? 256u : 0u) <= a.tab_bytes; // (a table that does not fit the slot, a tree of depth 12: the general path takes the file)
                 const uint32_t left = (1u << maxbits) - total;
                 g2 = g2 && (left & (left - 1)) == 0;
                 const uint32_t wl = (uint32_t)hibit32(left | 1u) + 1; // the implied last weight, of symbol nw
@@ -884,7 +920,7 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
         // =============================== Huffman streams -> the literal scratch (lane = (file, stream))
         {
             uint32_t lit_bad = 0;
-            if (live && lit_type >= 2 && sub < streams) {
+            if (w0 && live && lit_type >= 2 && sub < streams) {
                 const uint32_t st = sub;
                 const uint32_t seg = (nlit + 3) / 4;
                 const uint32_t sl = streams == 1 ? s_len0 : (st == 0 ? s_len0 : (st == 1 ? s_len1 : (st == 2 ? s_len2 : s_len3)));
@@ -946,7 +982,7 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
             const uint64_t badm = __ballot(lit_bad != 0); // a failed stream condemns its file
             if ((badm >> (f * LPF)) & ((1ull << LPF) - 1)) { ok = false; live = false; why = 3; }
             // RLE literals: the scratch is filled with the byte
-            if (live && lit_type == 1) { const uint32_t v = L8(cmp + lit_off) * 0x01010101u; for (uint32_t k = 4 * sub; k < nlit; k += 4 * LPF) gs32(lit_g + k, v); } // (slack past nlit)
+            if (w0 && live && lit_type == 1) { const uint32_t v = L8(cmp + lit_off) * 0x01010101u; for (uint32_t k = 4 * sub; k < nlit; k += 4 * LPF) gs32(lit_g + k, v); } // (slack past nlit)
         }
         wsync();
         prefetch(Jn, pfn); // (trip 4: in flight from here to the next group's start)
@@ -956,8 +992,9 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
         uint32_t nseq = 0, bs_off = 0, bs_len = 0;
         uint32_t tabL = 0, tabO = 0, tabM = 0, alL = 0, alO = 0, alM = 0; // LDS offset of each table, its log
         uint32_t modes3 = 0, rle_syms = 0, nsyms = 0;
-        if (live) {
-            uint32_t good = 0;
+        uint32_t sq_good = 0;
+        if (live && (NW == 1 || !w0)) { // (with a helper wavefront: its work, beside the Huffman phases above)
+            uint32_t& good = sq_good;
             if (leader) {
                 do {
                     const uint32_t sp = cmp + seq_off;
@@ -1009,16 +1046,40 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                     good = 1;
                 } while (false);
             }
-            const int ld = (int)(f * LPF);
-            good = (uint32_t)__shfl((int)good, ld);
-            nseq = (uint32_t)__shfl((int)nseq, ld); bs_off = (uint32_t)__shfl((int)bs_off, ld); bs_len = (uint32_t)__shfl((int)bs_len, ld);
-            tabL = (uint32_t)__shfl((int)tabL, ld); tabO = (uint32_t)__shfl((int)tabO, ld); tabM = (uint32_t)__shfl((int)tabM, ld);
-            alL = (uint32_t)__shfl((int)alL, ld); alO = (uint32_t)__shfl((int)alO, ld); alM = (uint32_t)__shfl((int)alM, ld);
-            modes3 = (uint32_t)__shfl((int)modes3, ld); rle_syms = (uint32_t)__shfl((int)rle_syms, ld); nsyms = (uint32_t)__shfl((int)nsyms, ld);
-            if (!good) { ok = false; live = false; nseq = 0; why = 4; }
+            if constexpr (NW == 1) {
+                const int ld = (int)(f * LPF);
+                good = (uint32_t)__shfl((int)good, ld);
+                nseq = (uint32_t)__shfl((int)nseq, ld); bs_off = (uint32_t)__shfl((int)bs_off, ld); bs_len = (uint32_t)__shfl((int)bs_len, ld);
+                tabL = (uint32_t)__shfl((int)tabL, ld); tabO = (uint32_t)__shfl((int)tabO, ld); tabM = (uint32_t)__shfl((int)tabM, ld);
+                alL = (uint32_t)__shfl((int)alL, ld); alO = (uint32_t)__shfl((int)alO, ld); alM = (uint32_t)__shfl((int)alM, ld);
+                modes3 = (uint32_t)__shfl((int)modes3, ld); rle_syms = (uint32_t)__shfl((int)rle_syms, ld); nsyms = (uint32_t)__shfl((int)nsyms, ld);
+                if (!good) { ok = false; live = false; nseq = 0; why = 4; }
+            }
+        }
+        if constexpr (NW > 1) { // the parsed header crosses over in LDS (second barrier of the group); every lane of the file reads it
+            const uint32_t xo = kShSeqRec + 64 * f + 16;
+            if (!w0) {
+                if (leader) {
+                    lds_sv16(xo, V16{(uint64_t)sq_good | ((uint64_t)nseq << 32), (uint64_t)bs_off | ((uint64_t)bs_len << 32)});
+                    lds_sv16(xo + 16, V16{(uint64_t)tabL | ((uint64_t)tabO << 32), (uint64_t)tabM | ((uint64_t)(alL | (alO << 8) | (alM << 16)) << 32)});
+                    lds_sv16(xo + 32, V16{(uint64_t)modes3 | ((uint64_t)rle_syms << 32), (uint64_t)nsyms});
+                }
+                __syncthreads();
+            } else {
+                __syncthreads();
+                if (live) {
+                    const V16 x0 = lds_v16(xo), x1 = lds_v16(xo + 16), x2 = lds_v16(xo + 32);
+                    sq_good = (uint32_t)x0.a; nseq = (uint32_t)(x0.a >> 32); bs_off = (uint32_t)x0.b; bs_len = (uint32_t)(x0.b >> 32);
+                    tabL = (uint32_t)x1.a; tabO = (uint32_t)(x1.a >> 32); tabM = (uint32_t)x1.b;
+                    const uint32_t als = (uint32_t)(x1.b >> 32); alL = als & 0xFF; alO = (als >> 8) & 0xFF; alM = (als >> 16) & 0xFF;
+                    modes3 = (uint32_t)x2.a; rle_syms = (uint32_t)(x2.a >> 32); nsyms = (uint32_t)x2.b;
+                    if (!sq_good) { ok = false; live = false; nseq = 0; why = 4; }
+                }
+            }
         }
         wsync();
         SSTAMP(5);
+      if (w0) { // (the helper is through with the group: it waits at the group's last barrier)
 
         // =============================== FSE decode tables (every table by all the lanes of its file: mzd_l_tables.h)
         {
@@ -1143,7 +1204,9 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                     const uint32_t ll = (L32(kShLL + 4 * cL) & 0xFFFFFF) + vL;
                     if (c0 + e0 + sub + 1 == nrun && tL != G0) pbad = 1; // the bitstream must be consumed exactly
                     if (((ll | ml) >> 14) | (cO > 18)) pbad = 1;     // (cannot be right for a window of <= 8 KiB and a dictionary of <= 128 KiB; keeps the packed fields in range)
-                    gs64(seq_g + 8 * (c0 + e0 + sub), (uint64_t)(ll | (ml << 14)) | ((uint64_t)ofv << 32));
+                    const bool small = ll < 127 && ml - 3 < 63; // (every match length is >= 3)
+                    gs32(seq_g + 4 * (c0 + e0 + sub), (small ? ll | ((ml - 3) << 7) : 127u) | (ofv << 13));
+                    if (!small) gs64(seq8_g + 8 * (c0 + e0 + sub), (uint64_t)(ll | (ml << 14)) | ((uint64_t)ofv << 32));
                 }
                 {
                     const uint64_t pm = __ballot(pbad != 0);
@@ -1153,7 +1216,7 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                 GSTAMP(tp_);
             }
 #ifdef MZD_SMALL_STAMPS
-            if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[10] = tw_; a.stamps[11] = tp_; }
+            if (a.stamps && w0 && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[10] = tw_; a.stamps[11] = tp_; }
 #endif
             if (bad) { ok = false; live = false; nrun = 0; why = 6; }
         }
@@ -1174,10 +1237,12 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
         }
         wsync();
         SSTAMP(7);
+      } // (w0)
       }
 #ifdef MZD_SMALL_STAMPS
       if (first_group) wg_te_ = __builtin_amdgcn_s_memrealtime(); // (the entropy phases end)
 #endif
+      if (w0)
       for (uint32_t pass = 0; pass < NX; pass++) {
         // =============================== an execution pass: XG of the group's files, XLPF lanes each (the names of the entropy phases, for this pass's files)
         constexpr uint32_t LPF = XLPF;
@@ -1199,8 +1264,9 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
         const uint8_t* src = nullptr; uint8_t* dst = nullptr; uint8_t* dst2 = nullptr; uint32_t cap = 0;
         if (have) { const DevJob& dj = a.jobs[job]; src = dj.src; dst = dj.dst; dst2 = dj.dst2; cap = (uint32_t)dj.dst_cap; } // (L2: the entropy phases read the entry)
         const uint32_t outo = slots0 + f * (G != XG ? a.out_bytes : stride); // the file's output window
-        uint8_t* const lit_g = a.scratch + (size_t)(blockIdx.x * G + gfile) * ((size_t)a.lit_stride + 8u * (size_t)a.seq_cap);
+        uint8_t* const lit_g = a.scratch + (size_t)(blockIdx.x * G + gfile) * ((size_t)a.lit_stride + 12u * (size_t)a.seq_cap);
         uint8_t* const seq_g = lit_g + a.lit_stride;
+        uint8_t* const seq8_g = seq_g + 4u * (size_t)a.seq_cap;
         const uint8_t* const lit_p = lit_type == 0 ? src + lit_off : lit_g; // the literals: raw where the input has them (HBM), else the scratch
         uint32_t out_len = (ok && done && n != 0) ? bsize : 0u; // the decoded file: out_len bytes at LDS offset res_off
         const uint32_t res_off = outo;
@@ -1240,7 +1306,19 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                 if (h3) { lds_s64(lit_base + q + 3 * S, v3.a); lds_s64(lit_base + q + 3 * S + 8, v3.b); }
             }
             wsync();
-            auto load_rec = [&](uint32_t c0) -> uint64_t { return c0 + sub < nrun ? gu64(seq_g + 8 * (c0 + sub)) : 0ull; };
+            // a step's records: the 4-byte ones are requested three steps ahead; a step ahead of their use (they have arrived) the full
+            // records of the sequences that say so are requested from the second array; spelled as round 4's 8-byte record for what follows
+            auto load_rec4 = [&](uint32_t c0) -> uint32_t { return c0 + sub < nrun ? gu32(seq_g + 4 * (c0 + sub)) : 127u; }; // (past the end: "see the second array", where load_rec8 puts the empty sequence)
+            auto load_rec8 = [&](uint32_t c0, uint32_t r4) -> uint64_t { // (wave-uniform skip: most steps hold no such sequence)
+                const bool big = c0 + sub < nrun && (r4 & 127u) == 127u;
+                if (!__ballot(big)) return 0ull;
+                return big ? gu64(seq8_g + 8 * (c0 + sub)) : 0ull;
+            };
+            auto widen = [&](uint32_t r4, uint64_t r8) -> uint64_t { // (selects, no branches)
+                const lmask big = m_eq(r4 & 127u, 127u);
+                const uint32_t lo = (r4 & 127u) | ((((r4 >> 7) & 63u) + 3u) << 14), hi = r4 >> 13;
+                return (uint64_t)sel(big, (uint32_t)r8, lo) | ((uint64_t)sel(big, (uint32_t)(r8 >> 32), hi) << 32);
+            };
             struct StepA { uint32_t ll, ml, w0, lp, op, chunk_l, chunk_t; };
             auto stage_a = [&](uint64_t rec, StepA& A) {
                 uint32_t ll = (uint32_t)rec & 0x3FFF, ml = ((uint32_t)rec >> 14) & 0x3FFF;
@@ -1261,18 +1339,25 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
 #else
 #define XSTAMP(acc)
 #endif
-            uint64_t recB = load_rec(LPF);
             StepA cur;
-            stage_a(load_rec(0), cur);
+            uint32_t q1 = load_rec4(LPF), q2 = load_rec4(2 * LPF); // the 4-byte records of steps c + 1 and c + 2 ...
+            uint64_t o1;                                            // ... and what step c + 1 has in the second array
+            { const uint32_t r4 = load_rec4(0); const uint64_t r8 = load_rec8(0, r4); o1 = load_rec8(LPF, q1); stage_a(widen(r4, r8), cur); } // (two trips: the three 4-byte records, then what they point at)
             for (uint32_t c0 = 0; c0 < nrun; c0 += LPF) {
-                const uint64_t recC = load_rec(c0 + 2 * LPF);
+                // (what is consumed first, what is requested behind it: the compiler waits for EVERYTHING in flight where the number of loads
+                //  depends on control flow, so nothing younger than a step may be outstanding when a record is used)
+                const uint64_t recB = widen(q1, o1);
+                asm volatile("" ::: "memory");
+                const uint64_t o2 = load_rec8(c0 + 2 * LPF, q2); // (q2 was requested a step ago: it decides here, before the next request goes out)
+                asm volatile("" ::: "memory");
+                const uint32_t q3 = load_rec4(c0 + 3 * LPF);
                 StepA nxt;
 #ifdef MZD_SMALL_STAMPS
                 wg_steps_++;
 #endif
                 XSTAMP(xm_);
                 stage_a(recB, nxt);
-                recB = recC;
+                q1 = q2; q2 = q3; o1 = o2;
                 XSTAMP(xa_);
                 // ---- B(c)
                 uint32_t ll = cur.ll, ml = cur.ml;
@@ -1445,7 +1530,7 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
                 cur = nxt;
             }
 #ifdef MZD_SMALL_STAMPS
-            if (a.stamps && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[18] = xa_; a.stamps[19] = xr_; a.stamps[20] = xl_; a.stamps[21] = xm_; a.stamps[22] = xn_; a.stamps[23] = xf_; a.stamps[24] = xc_; a.stamps[25] = xq_; a.stamps[26] = xrare_; }
+            if (a.stamps && w0 && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[18] = xa_; a.stamps[19] = xr_; a.stamps[20] = xl_; a.stamps[21] = xm_; a.stamps[22] = xn_; a.stamps[23] = xf_; a.stamps[24] = xc_; a.stamps[25] = xq_; a.stamps[26] = xrare_; }
 #endif
             // the literals behind the last sequence
             bool good = !xbad;
@@ -1569,15 +1654,18 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
         wg_groups_++;
 #endif
         first_group = false;
-        if (!early) { g_next = ticket(); Jn = job_entry(list_entry(g_next)); prefetch(Jn, pfn); } // (wave-uniform)
-        g = g_next; J = Jn;
+        wgsync(); // (the group's last barrier: the slots are rewritten by the next group)
+        if (w0) {
+            if (!early) { g_next = ticket(); Jn = job_entry(list_entry(g_next)); prefetch(Jn, pfn); } // (wave-uniform)
+            g = g_next; J = Jn;
 #pragma unroll
-        for (int k = 0; k < kPF; k++) pf[k] = pfn[k];
+            for (int k = 0; k < kPF; k++) pf[k] = pfn[k];
+        }
         wsync(); // the slots are rewritten by the next group
     }
     leave();
 #ifdef MZD_SMALL_STAMPS
-    if (a.stamps && lane == 0 && blockIdx.x < 3072) {
+    if (a.stamps && w0 && lane == 0 && blockIdx.x < 3072) {
         uint64_t* w = a.stamps + 2048 + 16 * blockIdx.x;
         w[0] = wg_t0_; w[1] = __builtin_amdgcn_s_memrealtime();
         w[2] = (uint64_t)(uint32_t)__builtin_amdgcn_s_getreg(63492) | ((uint64_t)(uint32_t)__builtin_amdgcn_s_getreg(63508) << 32); w[3] = (uint64_t)wg_groups_ | ((uint64_t)wg_rounds_ << 16) | ((uint64_t)wg_steps_ << 32) | ((uint64_t)(uint32_t)(wg_te_ - wg_t0_) << 48);
@@ -1588,34 +1676,34 @@ __global__ __launch_bounds__(64, (G == 4 && !DICT) ? 3 : 1) void mzd_lds_kernel(
 } // namespace lw
 
 // wavefronts a CU holds by the kernels' register budgets: three per SIMD for the plain G = 4 kernel (168 registers: __launch_bounds__), two for the others
-uint32_t lds_waves_by_registers(int g, int xg, int with_dict) { (void)xg; return (g == 4 && !with_dict) ? 12u : 8u; }
+uint32_t lds_waves_by_registers(int g, int xg, int with_dict, int nw) { (void)xg; return ((g == 4 || nw > 1) && !with_dict) ? 12u : 8u; } // (a workgroup with a helper wavefront counts twice)
 uint32_t lds_kernel_bytes_per_file(uint32_t tab_bytes, uint32_t comp_bytes) { return tab_bytes + lw::kAux + comp_bytes; } // a file's entropy image
-uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes) {
+uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes, int nw) {
     const uint32_t ent = tab_bytes + lw::kAux + comp_bytes;
     const uint32_t files = g != xg ? std::max<uint32_t>((uint32_t)g * ent, (uint32_t)xg * out_bytes) : (uint32_t)g * std::max(ent, out_bytes);
-    return lw::kShBytes + 32u * (uint32_t)g + (with_dict ? lw::kDictImg : 0u) + files;
+    return lw::kShBytes + 32u * (uint32_t)g + (nw > 1 ? 64u * (uint32_t)g : 0u) + (with_dict ? lw::kDictImg : 0u) + files; // (a helper wavefront: 64 bytes a file between the two)
 }
 // what a slot has left for tables beside its input when the output window, not the input, sets its size (multiple of 16, at most 4 KiB)
 uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes) {
     const uint32_t used = lw::kAux + comp_bytes;
     return out_bytes > used ? std::min<uint32_t>((out_bytes - used) & ~15u, 4096u) : 0u; // (the ring behind the tables holds 16-byte records)
 }
-size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap) { return (size_t)lit_stride + 8u * (size_t)seq_cap; }
+size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap) { return (size_t)lit_stride + 12u * (size_t)seq_cap; } // (4-byte records + the sparse array of full ones)
 
-// every instantiation the host can ask for: (files per wavefront, with a dictionary image, files executed at a time)
-#define MZD_LDS_VARIANTS(X) X(4, false, 4) X(8, false, 8) X(16, false, 16) X(8, false, 4) X(4, false, 2) X(4, true, 4) X(8, true, 8) X(16, true, 16)
+// every instantiation the host can ask for: (files per wavefront, with a dictionary image, files executed at a time, wavefronts per workgroup)
+#define MZD_LDS_VARIANTS(X) X(4, false, 4, 1) X(8, false, 8, 1) X(16, false, 16, 1) X(8, false, 4, 1) X(8, false, 4, 2) X(4, false, 2, 1) X(4, true, 4, 1) X(8, true, 8, 1) X(16, true, 16, 1)
 // The kernels ask for up to 160 KiB of dynamic LDS (the default limit is 64 KiB): the attribute belongs to the CURRENT device's
 // function object, so it is raised once per device, from init_device (mzd_host.cpp), for every instantiation.
 int lds_prepare_device() {
-#define X(GG, DD, XX) if (hipFuncSetAttribute((const void*)lw::mzd_lds_kernel<GG, DD, XX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return MZD_E_DEVICE; }
+#define X(GG, DD, XX, WW) if (hipFuncSetAttribute((const void*)lw::mzd_lds_kernel<GG, DD, XX, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return MZD_E_DEVICE; }
     MZD_LDS_VARIANTS(X)
 #undef X
     return MZD_OK;
 }
-int launch_lds(const LdsArgs& a, uint32_t grid, int g, int xg, int with_dict, void* stream) {
-    const uint32_t bytes = lds_kernel_bytes(g, xg, with_dict, a.tab_bytes, a.comp_bytes, a.out_bytes);
+int launch_lds(const LdsArgs& a, uint32_t grid, int g, int xg, int with_dict, int nw, void* stream) {
+    const uint32_t bytes = lds_kernel_bytes(g, xg, with_dict, a.tab_bytes, a.comp_bytes, a.out_bytes, nw);
     hipStream_t s = (hipStream_t)stream;
-#define X(GG, DD, XX) if (g == GG && xg == XX && (with_dict != 0) == DD) { hipLaunchKernelGGL((lw::mzd_lds_kernel<GG, DD, XX>), dim3(grid), dim3(64), bytes, s, a); return MZD_OK; }
+#define X(GG, DD, XX, WW) if (g == GG && xg == XX && (with_dict != 0) == DD && nw == WW) { hipLaunchKernelGGL((lw::mzd_lds_kernel<GG, DD, XX, WW>), dim3(grid), dim3(64 * WW), bytes, s, a); return MZD_OK; }
     MZD_LDS_VARIANTS(X)
 #undef X
     return MZD_E_PARAM;

@@ -267,17 +267,19 @@ def test_small_files_of_every_class_and_size(kind):
         for level in (1, 3, 19):
             cp = corpus.build_corpus(kind, 77, sizes * 3, level=level)
             srcs = [cp.comp_file(i).tobytes() for i in range(cp.nfiles)]
-            for g, xg in ((0, 0), (8, 4), (4, 2)):  # the library's choice of shape; eight files per wavefront executed four at a time, four executed two at a time (32 lanes a file) (raw and RLE blocks take their bytes from the input again in their pass)
+            for g, xg, nw in ((0, 0, 0), (8, 4, 1), (8, 4, 2), (4, 2, 0)):  # the library's choice of shape; eight files per wavefront executed four at a time, without / with the helper wavefront (raw and RLE blocks take their bytes from the input again in their pass); four executed two at a time (32 lanes a file)
                 mzd.lib().mzd_debug_host_path(0, 4, g)
                 mzd.lib().mzd_debug_host_path(0, 5, xg)
+                mzd.lib().mzd_debug_host_path(0, 9, nw)
                 res = mzd.decode_batch(srcs, [int(s) for s in cp.raw_sizes])
                 for i, (st, out) in enumerate(res):
-                    assert st == 0 and out == cp.raw_file(i).tobytes(), (kind, level, g, xg, int(cp.raw_sizes[i]), st)
+                    assert st == 0 and out == cp.raw_file(i).tobytes(), (kind, level, g, xg, nw, int(cp.raw_sizes[i]), st)
             rc, ref = oracle.decode(srcs[7], cap=int(cp.raw_sizes[7]))
             assert rc == 0 and ref == cp.raw_file(7).tobytes()
     finally:
         mzd.lib().mzd_debug_host_path(0, 4, 0)
         mzd.lib().mzd_debug_host_path(0, 5, 0)
+        mzd.lib().mzd_debug_host_path(0, 9, 0)
         mzd.set_driver(0)
 
 
@@ -390,15 +392,15 @@ def test_the_launch_policy_is_within_ten_percent_of_the_best_forced_choice():
                 auto_name = mzd.last_kernel_name(0)
                 forced = {}
                 mzd.set_driver(1); forced["general"] = run(jobs); mzd.set_driver(3)
-                for g, xg in ((4, 4), (8, 4), (4, 2), (8, 8), (16, 16)):
-                    L.mzd_debug_host_path(0, 4, g); L.mzd_debug_host_path(0, 5, xg)
-                    forced["%d/%d" % (g, xg)] = run(jobs)
-                L.mzd_debug_host_path(0, 4, 0); L.mzd_debug_host_path(0, 5, 0)
+                for g, xg, nw in ((4, 4, 1), (8, 4, 1), (8, 4, 2), (4, 2, 1), (8, 8, 1), (16, 16, 1)):
+                    L.mzd_debug_host_path(0, 4, g); L.mzd_debug_host_path(0, 5, xg); L.mzd_debug_host_path(0, 9, nw)
+                    forced["%d/%d%s" % (g, xg, "+helper" if nw > 1 else "")] = run(jobs)
+                L.mzd_debug_host_path(0, 4, 0); L.mzd_debug_host_path(0, 5, 0); L.mzd_debug_host_path(0, 9, 0)
                 best = min(forced.values())
                 worst.append((auto / best, size, n, auto_name, round(auto, 4), {k: round(v, 4) for k, v in forced.items()}))
                 assert auto <= 1.10 * best + 0.010, worst[-1]
     finally:
-        L.mzd_debug_host_path(0, 4, 0); L.mzd_debug_host_path(0, 5, 0)
+        L.mzd_debug_host_path(0, 4, 0); L.mzd_debug_host_path(0, 5, 0); L.mzd_debug_host_path(0, 9, 0)
         mzd.set_driver(0)
     print("policy sweep, automatic / best forced (worst first):", sorted(worst, reverse=True)[:4])
 

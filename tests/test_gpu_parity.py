@@ -33,13 +33,16 @@ def force_driver():
     def set_(driver):
         parts = driver.split(":")
         mzd.set_driver(3 if parts[0] == "auto" else int(parts[0]))
-        if len(parts) == 3:
+        if len(parts) >= 3:
             mzd.lib().mzd_debug_host_path(0, 4, int(parts[1]))
             mzd.lib().mzd_debug_host_path(0, 5, int(parts[2]))
+        if len(parts) == 4:  # 'auto:8:4:2': with the helper wavefront (mzd_debug_host_path 9)
+            mzd.lib().mzd_debug_host_path(0, 9, int(parts[3]))
     yield set_
     mzd.set_driver(0)
     mzd.lib().mzd_debug_host_path(0, 4, 0)
     mzd.lib().mzd_debug_host_path(0, 5, 0)
+    mzd.lib().mzd_debug_host_path(0, 9, 0)
 
 
 def test_golden_positive_batch():
@@ -242,7 +245,7 @@ def test_both_drivers_decode_every_vector(driver, force_driver):
 
 
 @needs_zstd
-@pytest.mark.parametrize("driver", DRIVERS + ["auto:8:4", "auto:4:2", "auto:8:8", "auto:16:16"])  # (the small-file kernel in every shape it is built in)
+@pytest.mark.parametrize("driver", DRIVERS + ["auto:8:4", "auto:8:4:2", "auto:4:2", "auto:8:8", "auto:16:16"])  # (the small-file kernel in every shape it is built in)
 def test_every_single_byte_mutation_of_small_frames_matches_oracle(driver, force_driver):
     """The fuzz corpus of SURVEY.md row N3 on the device: EVERY byte of several small frames (Huffman + FSE blocks, a
     raw-literal block, an RLE-heavy one, levels 3 and 19) flipped three ways, every truncation, and every output capacity of one frame: ~14 000 cases in one launch.  For each
