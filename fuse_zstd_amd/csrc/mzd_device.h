@@ -171,11 +171,11 @@ struct LdsArgs {
     uint32_t* counter_next;     // null: a general driver's launch follows this one (it takes what is handed on and cleans the next
     uint32_t* handed_on;        // launch's counters).  Else: no launch follows; the last wavefront stores counter[4] here and cleans.
 };
-int launch_lds(const LdsArgs& a, uint32_t grid, int g, int xg, int with_dict, int nw, void* stream); // g files per wavefront, executed xg at a time; nw = 2: with a helper wavefront
+int launch_lds(const LdsArgs& a, uint32_t grid, int g, int xg, int with_dict, int nw, int nd, void* stream); // g files per wavefront, executed xg at a time; nw = 2: with a helper wavefront; nd: decoding wavefronts around one dictionary image
 int lds_prepare_device();   // once per device, with that device current
-uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes, int nw = 1);
+uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes, int nw = 1, int nd = 1);
 uint32_t lds_kernel_bytes_per_file(uint32_t tab_bytes, uint32_t comp_bytes);
-uint32_t lds_waves_by_registers(int g, int xg, int with_dict, int nw = 1);
+uint32_t lds_waves_by_registers(int g, int xg, int with_dict, int nw = 1, int nd = 1);
 size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap);
 uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes);
 

@@ -275,6 +275,7 @@ struct Plan {
     uint32_t lit_stride = 0;   // literal scratch per small file: largest capacity + 64
     int lds_g = 4, lds_xg = 4; // files per wavefront of the small-file kernel (mzd_lds.hip), and how many of them it executes at a time
     int lds_nw = 1;            // its wavefronts per workgroup (2: a helper wavefront parses the sequence headers beside the Huffman phases)
+    int lds_nd = 1;            // decoding wavefronts per workgroup around ONE dictionary image (launches that name a single dictionary)
     uint32_t lds_tab = 0, lds_comp = 0, lds_out = 0; // its slot geometry (LdsArgs)
     uint32_t big_tasks = 0;    // workgroups worth launching for the files that are not small
     uint64_t blocks = 0;       // block tasks of those files, estimated from their capacities
@@ -288,7 +289,8 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
     const int force = g_force_driver.load(std::memory_order_relaxed);
     uint32_t* small = lists;
     uint32_t* big = lists + njobs;
-    bool all_dict = true;
+    bool all_dict = true, one_dict = true;
+    uint32_t first_dict = 0;
     uint64_t tasks = 0;
     size_t maxcap = 0, maxbig = 0, maxbigsrc = 0, minbigsrc = ~(size_t)0;
     // The small-file kernel pays off from about two thousand small files on: its launch lasts as long as one group of files
@@ -303,7 +305,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
         const bool is_small = small_ok && j.dst_cap <= kSmallCap && j.src_len <= kSmallSrcMax;
         if (is_small) {
             small[p.nsmall++] = (uint32_t)i;
-            if (j.dict) p.with_dict = true; else all_dict = false;
+            if (j.dict) { p.with_dict = true; if (!first_dict) first_dict = j.dict; else if (j.dict != first_dict) one_dict = false; } else all_dict = false;
             maxcap = std::max<size_t>(maxcap, j.dst_cap);
             maxsrc = std::max<size_t>(maxsrc, j.src_len);
         } else {
@@ -396,14 +398,25 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
                     else if (maxcap <= 768 && waves_per_cu(8, 8, p.lds_tab) * 8 > w44 * 4) { p.lds_g = 8; p.lds_xg = 8; } // many rounds of tiny files: more of them resident, half the wavefronts (512 B x 40 000: 0.265 against 0.304 ms; from 1 KiB on 4 / 4 is ahead)
                 } else if (need44 > 8 && one_round(8, 8, split_tab) && split_tab == p.lds_tab) { p.lds_g = 8; p.lds_xg = 8; } // one round either way: five wavefronts of eight rather than ten of four
             }
+            if (p.with_dict && all_dict && one_dict && cus && g_small_nw.load(std::memory_order_relaxed) != 1) {
+                // one dictionary in the launch: several decoding wavefronts share its table image (14 KB), one image a workgroup instead of
+                // one a wavefront -- cfg5: five wavefronts of eight records a CU where four fitted (mzd_lds.hip, ND)
+                auto files_per_cu = [&](int nd) -> uint32_t {
+                    const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(8, 8, 1, p.lds_tab, p.lds_comp, p.lds_out, 1, nd), kLdsGranule);
+                    return lds > kLdsPerCu ? 0u : std::min<uint32_t>(lds_waves_by_registers(8, 8, 1, 1, nd) / (uint32_t)nd, kLdsPerCu / lds) * (uint32_t)nd * 8u;
+                };
+                uint32_t best = files_per_cu(1);
+                for (int nd : {5, 8}) { const uint32_t fc = files_per_cu(nd); if (fc > best) { best = fc; p.lds_nd = nd; } }
+            }
             const int dbg_g = g_small_g.load(std::memory_order_relaxed), dbg_xg = g_small_xg.load(std::memory_order_relaxed); // (mzd_debug_host_path 4 / 5)
             if (dbg_g == 4 || dbg_g == 8 || dbg_g == 16) {
+                p.lds_nd = 1;
                 p.lds_g = dbg_g; p.lds_xg = (dbg_xg == 4 && dbg_g == 8 && !p.with_dict) ? 4 : ((dbg_xg == 2 && dbg_g == 4 && !p.with_dict) ? 2 : dbg_g);
                 p.lds_tab = (p.with_dict && all_dict) ? lds_spare_table_bytes(p.lds_comp, p.lds_out) : (maxcap <= 5120 ? 2048u : 4096u);
                 p.lds_nw = (g_small_nw.load(std::memory_order_relaxed) == 2 && p.lds_g == 8 && p.lds_xg == 4) ? 2 : 1;
                 if (p.lds_g != p.lds_xg && one_round(p.lds_g, p.lds_xg, split_tab, p.lds_nw)) p.lds_tab = split_tab;
             }
-            while (p.lds_g > 4 && lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out, p.lds_nw) > kLdsPerCu) { p.lds_g /= 2; p.lds_xg = p.lds_g; p.lds_nw = 1; }
+            while (p.lds_g > 4 && lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out, p.lds_nw, p.lds_nd) > kLdsPerCu) { p.lds_g /= 2; p.lds_xg = p.lds_g; p.lds_nw = 1; p.lds_nd = 1; }
         }
     }
     // Multi-block files in a launch that fills the machine many times over: block tasks keep a workgroup slot waiting while a file's
@@ -475,21 +488,22 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         la.stamps = reinterpret_cast<uint64_t*>(d.debug); // (diagnostic builds: the first debug slot's first bytes; unused otherwise)
         la.counter_next = solo ? l.cnt[l.flip] : nullptr; la.handed_on = solo ? handed_on : nullptr;
         const uint32_t ngroups = (p.nsmall + (uint32_t)p.lds_g - 1) / (uint32_t)p.lds_g;
-        const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out, p.lds_nw), kLdsGranule);
+        const uint32_t lds = (uint32_t)align_up(lds_kernel_bytes(p.lds_g, p.lds_xg, p.with_dict, p.lds_tab, p.lds_comp, p.lds_out, p.lds_nw, p.lds_nd), kLdsGranule);
         // one wavefront per workgroup; as many as the whole device holds, also for a launch on one of the host path's lanes: this
         // kernel uses none of the per-workgroup scratch the lanes divide, and a chunk of small files that gets a quarter of the wave
         // slots takes four rounds of groups where one would do (cfg4 host -> host: 1.5 -> ms)
-        const uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(lds_waves_by_registers(p.lds_g, p.lds_xg, p.with_dict, p.lds_nw) / (uint32_t)p.lds_nw, kLdsPerCu / lds));
+        const uint32_t resident = d.cus * std::max<uint32_t>(1u, std::min<uint32_t>(lds_waves_by_registers(p.lds_g, p.lds_xg, p.with_dict, p.lds_nw, p.lds_nd) / (uint32_t)(p.lds_nw * p.lds_nd), kLdsPerCu / lds)); // (workgroups)
         la.lit_stride = p.lit_stride; la.seq_cap = ((p.lit_stride - 64) / 3 + 3) & ~1u; // (even: the array of full records behind the 4-byte ones is 8-byte aligned)
         la.scratch = l.small_lit;
         if (&l == &d.whole) { d.last_lds_lit_stride = la.lit_stride; d.last_lds_seq_cap = la.seq_cap; }
         const size_t per_wave = (size_t)p.lds_g * lds_scratch_per_file(la.lit_stride, la.seq_cap);
-        const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / per_wave);
+        const uint32_t by_scratch = (uint32_t)std::max<size_t>(1, l.small_lit_bytes / per_wave / (size_t)p.lds_nd);
+        const uint32_t ngroups_wg = (ngroups + (uint32_t)p.lds_nd - 1) / (uint32_t)p.lds_nd; // (a workgroup's decoding wavefronts take a group each)
         const uint32_t dbg_grid = g_small_grid.load(std::memory_order_relaxed); // (mzd_debug_host_path 6: experiments with fewer resident wavefronts)
-        { int lrc = launch_lds(la, std::min(ngroups, std::min(dbg_grid ? dbg_grid : resident, by_scratch)), p.lds_g, p.lds_xg, p.with_dict ? 1 : 0, p.lds_nw, s); if (lrc) return lrc; }
+        { int lrc = launch_lds(la, std::min(ngroups_wg, std::min(dbg_grid ? dbg_grid : resident, by_scratch)), p.lds_g, p.lds_xg, p.with_dict ? 1 : 0, p.lds_nw, p.lds_nd, s); if (lrc) return lrc; }
         if (&l == &d.whole) {
             char small[48];
-            if (p.lds_nw > 1) snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg, p.lds_nw);
+            if (p.lds_nw > 1 || p.lds_nd > 1) snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d,%d,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg, p.lds_nw, p.lds_nd);
             else snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg);
             const char* big = use_tasks ? "mzd_decode_kernel_tasks" : "mzd_decode_kernel_files";
             if (solo) d.set_kernels(small);

@@ -344,7 +344,7 @@ DI uint64_t xxh_tail(uint64_t hh, uint32_t q, uint32_t end) {
 
 // Diagnostic build only (-DMZD_SMALL_STAMPS): cycle counter of workgroup 0 at every phase boundary of its first group.
 #ifdef MZD_SMALL_STAMPS
-#define SSTAMP(k) do { if (a.stamps && w0 && lane == 0 && first_group) { if (blockIdx.x == 0) a.stamps[k] = __builtin_readcyclecounter(); if ((k) < 12 && blockIdx.x < 3072) a.stamps[2048 + 16 * blockIdx.x + 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define SSTAMP(k) do { if (a.stamps && w0 && wv == 0 && lane == 0 && first_group) { if (blockIdx.x == 0) a.stamps[k] = __builtin_readcyclecounter(); if ((k) < 12 && blockIdx.x < 3072) a.stamps[2048 + 16 * blockIdx.x + 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define SSTAMP(k)
 #endif
@@ -458,16 +458,22 @@ struct DictInfo { // the dictionary whose image sits in LDS (wave-uniform)
 // produce, so the helper parses it (on another SIMD) while the first wavefront decodes weights, table and literal streams, and
 // hands the result over in LDS; then it sleeps at the group's last barrier.  Three workgroup barriers a group; the helper
 // learns the group (and the launch's end) from a control word.  Ten wavefronts a CU instead of five: 168 registers.
-template <int G, bool DICT, int XG, int NW = 1>
-__global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) void mzd_lds_kernel(LdsArgs a) {
+// ND > 1 (dictionary launches that name ONE dictionary): ND decoding wavefronts in a workgroup, each with groups, slots, dump area and
+// records of its own -- nothing crosses between them, no barrier -- that SHARE the dictionary's table image (14 KB) and the code
+// tables: one image a CU instead of one a wavefront is what lets a fifth wavefront's slots fit (cfg5: 32 -> 40 files a CU).  Every
+// wavefront writes the image itself before it reads it (the same bytes from all of them).
+template <int G, bool DICT, int XG, int NW = 1, int ND = 1>
+__global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (ND > 4 ? 2 : 1)) void mzd_lds_kernel(LdsArgs a) {
     constexpr uint32_t LPF = 64 / G; // lanes per file in the entropy phases
     constexpr uint32_t XLPF = 64 / XG, NX = G / XG; // lanes per file = sequences per plan step in the execution; passes
     static_assert(LPF >= 4, "four Huffman streams");
     static_assert(XLPF >= 4 && XLPF <= 32 && G % XG == 0, "four XXH64 accumulators; a file's lanes inside one DPP row, or two (the scans carry over)");
     static_assert(NW == 1 || (NW == 2 && !DICT), "the helper wavefront: files without a dictionary");
+    static_assert(ND == 1 || (DICT && NW == 1), "several decoding wavefronts around one dictionary image");
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = NW > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+    const uint32_t wv = NW * ND > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
     const bool w0 = NW == 1 || wv == 0; // the decoding wavefront (wave-uniform)
+    const uint32_t wslot = blockIdx.x * ND + (ND > 1 ? wv : 0u), nwslots = gridDim.x * ND; // this decoding wavefront among the launch's
     const uint32_t f = lane / LPF, sub = lane % LPF;
     const bool leader = sub == 0;
     // the files' records behind the wavefront's tables; (NW = 2) 64 bytes a file between the two wavefronts: {flags, n, cap, dict} from
@@ -478,7 +484,11 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
     const uint32_t dict_off = kShAll;
     const uint32_t ent = a.tab_bytes + kAux + a.comp_bytes;                // the entropy phase's image of a file ...
     const uint32_t stride = G != XG ? ent : (ent > a.out_bytes ? ent : a.out_bytes); // ... and (XG == G) its output window share the slot
-    const uint32_t slots0 = kShAll + (DICT ? kDictImg : 0u);
+    // the wavefront's own part of the image: dump area, records, slots (wavefront 0's lie around the shared dictionary image as ever;
+    // the others' behind its slots)
+    const uint32_t wpriv = (ND > 1 && wv) ? kShAll + kDictImg + G * stride + (wv - 1) * (512 + 32 * G + G * stride) : 0u;
+    const uint32_t shDump = wpriv ? wpriv : kShDump, shRec = wpriv ? wpriv + 512 : kShRec;
+    const uint32_t slots0 = wpriv ? wpriv + 512 + 32 * G : kShAll + (DICT ? kDictImg : 0u);
     // the file's slot: [ counts, later walk records | tables | compressed input ].  The tables sit right in front of the input: the
     // sequence tables are built when the literals are decoded, so they may grow over the input's dead front -- everything up to
     // the sequences section -- and a launch whose slots leave less than three full tables' room still keeps its files
@@ -488,7 +498,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
     // (6) | offset value (19); a sequence that does not fit (a literal run of 127 bytes or more, a match of 66 or more) says so in
     // its literal-length field and has its full 8-byte record in a second array at the same index, touched by those sequences only
     // (round 4 wrote 8 bytes a sequence: 27 of the 108 MB a launch of 10 000 files moved)
-    uint8_t* const lit_g = a.scratch + (size_t)(blockIdx.x * G + f) * ((size_t)a.lit_stride + 12u * (size_t)a.seq_cap);
+    uint8_t* const lit_g = a.scratch + (size_t)(wslot * G + f) * ((size_t)a.lit_stride + 12u * (size_t)a.seq_cap);
     uint8_t* const seq_g = lit_g + a.lit_stride;
     uint8_t* const seq8_g = seq_g + 4u * (size_t)a.seq_cap; // (seq_cap is even: 8-byte aligned)
 
@@ -506,13 +516,13 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
     // A launch without a general driver behind it (LdsArgs::counter_next): the last wavefront to leave publishes how many files were
     // handed on -- the host decodes them when it collects the launch -- and zeroes the counter block of the lane's next launch.
     auto leave = [&]() {
-        if (a.counter_next && w0 && lane == 0 && atomicAdd(&a.counter[6], 1u) == gridDim.x - 1) { // (a wavefront's additions to word 4 have returned by now)
+        if (a.counter_next && w0 && lane == 0 && atomicAdd(&a.counter[6], 1u) == nwslots - 1) { // (a wavefront's additions to word 4 have returned by now)
             *a.handed_on = atomicAdd(&a.counter[4], 0u);
             for (uint32_t k = 0; k < kCounterWords; k++) a.counter_next[k] = 0;
         }
     };
     if (!lds_at_zero) { // cannot be (this kernel has no other LDS object); if it ever is, the general driver decodes everything
-        if (w0) for (uint32_t i = blockIdx.x * 64 + lane; i < a.n; i += gridDim.x * 64) a.redo_list[atomicAdd(&a.counter[4], 1u)] = a.list[i];
+        if (w0) for (uint32_t i = wslot * 64 + lane; i < a.n; i += nwslots * 64) a.redo_list[atomicAdd(&a.counter[4], 1u)] = a.list[i];
         leave();
         return;
     }
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
         }
         if (g >= ngroups) break;
         // (what the trips for the next group leave behind outlives the entropy phases' scope)
-        const bool early = g + gridDim.x < ngroups;
+        const bool early = g + nwslots < ngroups;
         uint32_t g_next = 0xFFFFFFFFu;
         JobRegs Jn;
         V16 pfn[kPF];
@@ -746,7 +756,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
             }
             wsync();
             SSTAMP(13);
-            const bool w_tab = build_fse_file<3, (int)LPF>(w_hdr != 0, wtab, wnorm, w_nsym, w_log, kShDump + 8 * LPF * f, sub);
+            const bool w_tab = build_fse_file<3, (int)LPF>(w_hdr != 0, wtab, wnorm, w_nsym, w_log, shDump + 8 * LPF * f, sub);
             // the weights' bitstream (<= 127 bytes, read backwards) is staged behind 16 zero bytes: fields that reach below the stream's
             // start read zeros there (A.4) without a mask in the loop
             const uint32_t wstage = tabo + kWStage;
@@ -826,7 +836,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
             // Work memory: the file's share of the dump area (24 + 12 * LPF / 8 bytes of its 8 * LPF).
             if (good) {
                 constexpr uint32_t NCL = (12 + LPF - 1) / LPF;
-                const uint32_t hist = kShDump + 8 * LPF * f, hmask = hist + 24;
+                const uint32_t hist = shDump + 8 * LPF * f, hmask = hist + 24;
                 constexpr uint32_t kHistBytes = (24 + (12 * LPF + 7) / 8 + 3) & ~3u; // twelve 16-bit counters, twelve lane masks of LPF bits
                 static_assert(kHistBytes <= 8 * LPF, "the histogram and the lane masks stay inside the file's share of the dump area");
                 for (uint32_t o = 4 * sub; o < kHistBytes; o += 4 * LPF) L32(hist + o) = 0;
@@ -1095,7 +1105,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
                     L64(tab) = fse_entry(tab, 0, 0, s, extra);
                 }
             }
-            const uint32_t work = kShDump + 8 * LPF * f; // (the lane masks: the file's share of the dump area, idle until the execution)
+            const uint32_t work = shDump + 8 * LPF * f; // (the lane masks: the file's share of the dump area, idle until the execution)
             bool tg = build_fse_file<0, (int)LPF>(tables && (mL == 0 || mL == 2), tabL, ringo, nsyms & 0xFF, alL, work, sub);
             tg &= build_fse_file<1, (int)LPF>(tables && (mO == 0 || mO == 2), tabO, ringo + 72, (nsyms >> 8) & 0xFF, alO, work, sub);
             tg &= build_fse_file<2, (int)LPF>(tables && (mM == 0 || mM == 2), tabM, ringo + 136, (nsyms >> 16) & 0xFF, alM, work, sub);
@@ -1216,7 +1226,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
                 GSTAMP(tp_);
             }
 #ifdef MZD_SMALL_STAMPS
-            if (a.stamps && w0 && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[10] = tw_; a.stamps[11] = tp_; }
+            if (a.stamps && w0 && wv == 0 && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[10] = tw_; a.stamps[11] = tp_; }
 #endif
             if (bad) { ok = false; live = false; nrun = 0; why = 6; }
         }
@@ -1231,7 +1241,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
         if (leader) {
             const uint32_t fl = (have ? 1u : 0u) | (ok ? 2u : 0u) | (live ? 4u : 0u) | (done ? 8u : 0u) | (btype << 4) | (lit_type << 6) | (has_fcs << 8) | (has_ck << 9) |
                                 (with_d ? 1u << 10 : 0u) | (n != 0 ? 1u << 11 : 0u) | (why << 16);
-            const uint32_t ro = kShRec + 32 * f;
+            const uint32_t ro = shRec + 32 * f;
             lds_sv16(ro, V16{(uint64_t)fl | ((uint64_t)job << 32), (uint64_t)nlit | ((uint64_t)nrun << 32)});
             lds_sv16(ro + 16, V16{(uint64_t)fcs | ((uint64_t)stored_ck << 32), (uint64_t)((bsize & 0xFFFF) | (b0 << 16)) | ((uint64_t)((lit_off & 0xFFFF) | (rle_byte << 16)) << 32)});
         }
@@ -1251,7 +1261,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
         const uint32_t gfile = pass * XG + f; // the file's place in its group
         const uint32_t fidx = g * G + gfile;
         (void)fidx;
-        const V16 r0_ = lds_v16(kShRec + 32 * gfile), r1_ = lds_v16(kShRec + 32 * gfile + 16);
+        const V16 r0_ = lds_v16(shRec + 32 * gfile), r1_ = lds_v16(shRec + 32 * gfile + 16);
         const uint32_t rfl = (uint32_t)r0_.a, job = (uint32_t)(r0_.a >> 32), nlit = (uint32_t)r0_.b;
         uint32_t nrun = (uint32_t)(r0_.b >> 32);
         const uint32_t fcs = (uint32_t)r1_.a, stored_ck = (uint32_t)(r1_.a >> 32);
@@ -1264,7 +1274,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
         const uint8_t* src = nullptr; uint8_t* dst = nullptr; uint8_t* dst2 = nullptr; uint32_t cap = 0;
         if (have) { const DevJob& dj = a.jobs[job]; src = dj.src; dst = dj.dst; dst2 = dj.dst2; cap = (uint32_t)dj.dst_cap; } // (L2: the entropy phases read the entry)
         const uint32_t outo = slots0 + f * (G != XG ? a.out_bytes : stride); // the file's output window
-        uint8_t* const lit_g = a.scratch + (size_t)(blockIdx.x * G + gfile) * ((size_t)a.lit_stride + 12u * (size_t)a.seq_cap);
+        uint8_t* const lit_g = a.scratch + (size_t)(wslot * G + gfile) * ((size_t)a.lit_stride + 12u * (size_t)a.seq_cap);
         uint8_t* const seq_g = lit_g + a.lit_stride;
         uint8_t* const seq8_g = seq_g + 4u * (size_t)a.seq_cap;
         const uint8_t* const lit_p = lit_type == 0 ? src + lit_off : lit_g; // the literals: raw where the input has them (HBM), else the scratch
@@ -1288,7 +1298,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
             const uint8_t* const dict_end = with_d ? di.content + di.content_len : nullptr;
             uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
             if (with_d && di.formatted) { rep0 = di.rep[0]; rep1 = di.rep[1]; rep2 = di.rep[2]; }
-            const uint32_t dump = kShDump + 8 * lane; // where the stores of lanes that have nothing to store go
+            const uint32_t dump = shDump + 8 * lane; // where the stores of lanes that have nothing to store go
             bool xbad = false;
             uint32_t lpos = 0, opos = 0; // literals consumed / output produced before the step that A() looks at
             // the literals: from the scratch (raw ones: from the input) into the TAIL of the window (cap - nlit ..), 16 bytes per lane.
@@ -1530,7 +1540,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
                 cur = nxt;
             }
 #ifdef MZD_SMALL_STAMPS
-            if (a.stamps && w0 && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[18] = xa_; a.stamps[19] = xr_; a.stamps[20] = xl_; a.stamps[21] = xm_; a.stamps[22] = xn_; a.stamps[23] = xf_; a.stamps[24] = xc_; a.stamps[25] = xq_; a.stamps[26] = xrare_; }
+            if (a.stamps && w0 && wv == 0 && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[18] = xa_; a.stamps[19] = xr_; a.stamps[20] = xl_; a.stamps[21] = xm_; a.stamps[22] = xn_; a.stamps[23] = xf_; a.stamps[24] = xc_; a.stamps[25] = xq_; a.stamps[26] = xrare_; }
 #endif
             // the literals behind the last sequence
             bool good = !xbad;
@@ -1665,7 +1675,7 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
     }
     leave();
 #ifdef MZD_SMALL_STAMPS
-    if (a.stamps && w0 && lane == 0 && blockIdx.x < 3072) {
+    if (a.stamps && w0 && wv == 0 && lane == 0 && blockIdx.x < 3072) {
         uint64_t* w = a.stamps + 2048 + 16 * blockIdx.x;
         w[0] = wg_t0_; w[1] = __builtin_amdgcn_s_memrealtime();
         w[2] = (uint64_t)(uint32_t)__builtin_amdgcn_s_getreg(63492) | ((uint64_t)(uint32_t)__builtin_amdgcn_s_getreg(63508) << 32); w[3] = (uint64_t)wg_groups_ | ((uint64_t)wg_rounds_ << 16) | ((uint64_t)wg_steps_ << 32) | ((uint64_t)(uint32_t)(wg_te_ - wg_t0_) << 48);
@@ -1676,12 +1686,13 @@ __global__ __launch_bounds__(64 * NW, ((G == 4 || NW > 1) && !DICT) ? 3 : 1) voi
 } // namespace lw
 
 // wavefronts a CU holds by the kernels' register budgets: three per SIMD for the plain G = 4 kernel (168 registers: __launch_bounds__), two for the others
-uint32_t lds_waves_by_registers(int g, int xg, int with_dict, int nw) { (void)xg; return ((g == 4 || nw > 1) && !with_dict) ? 12u : 8u; } // (a workgroup with a helper wavefront counts twice)
+uint32_t lds_waves_by_registers(int g, int xg, int with_dict, int nw, int nd) { (void)xg; return ((g == 4 || nw > 1) && !with_dict) ? 12u : ((with_dict && nd <= 4) ? 4u : 8u); } // (a workgroup with a helper wavefront counts twice; the dictionary kernels take 267 registers -- one wavefront a SIMD -- unless built for five or more around an image: 256)
 uint32_t lds_kernel_bytes_per_file(uint32_t tab_bytes, uint32_t comp_bytes) { return tab_bytes + lw::kAux + comp_bytes; } // a file's entropy image
-uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes, int nw) {
+uint32_t lds_kernel_bytes(int g, int xg, int with_dict, uint32_t tab_bytes, uint32_t comp_bytes, uint32_t out_bytes, int nw, int nd) {
     const uint32_t ent = tab_bytes + lw::kAux + comp_bytes;
     const uint32_t files = g != xg ? std::max<uint32_t>((uint32_t)g * ent, (uint32_t)xg * out_bytes) : (uint32_t)g * std::max(ent, out_bytes);
-    return lw::kShBytes + 32u * (uint32_t)g + (nw > 1 ? 64u * (uint32_t)g : 0u) + (with_dict ? lw::kDictImg : 0u) + files; // (a helper wavefront: 64 bytes a file between the two)
+    const uint32_t one = lw::kShBytes + 32u * (uint32_t)g + (nw > 1 ? 64u * (uint32_t)g : 0u) + (with_dict ? lw::kDictImg : 0u) + files; // (a helper wavefront: 64 bytes a file between the two)
+    return one + (nd > 1 ? (uint32_t)(nd - 1) * (512u + 32u * (uint32_t)g + files) : 0u); // (further decoding wavefronts around the one dictionary image: dump area, records, slots)
 }
 // what a slot has left for tables beside its input when the output window, not the input, sets its size (multiple of 16, at most 4 KiB)
 uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes) {
@@ -1691,19 +1702,19 @@ uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes) {
 size_t lds_scratch_per_file(uint32_t lit_stride, uint32_t seq_cap) { return (size_t)lit_stride + 12u * (size_t)seq_cap; } // (4-byte records + the sparse array of full ones)
 
 // every instantiation the host can ask for: (files per wavefront, with a dictionary image, files executed at a time, wavefronts per workgroup)
-#define MZD_LDS_VARIANTS(X) X(4, false, 4, 1) X(8, false, 8, 1) X(16, false, 16, 1) X(8, false, 4, 1) X(8, false, 4, 2) X(4, false, 2, 1) X(4, true, 4, 1) X(8, true, 8, 1) X(16, true, 16, 1)
+#define MZD_LDS_VARIANTS(X) X(4, false, 4, 1, 1) X(8, false, 8, 1, 1) X(16, false, 16, 1, 1) X(8, false, 4, 1, 1) X(8, false, 4, 2, 1) X(4, false, 2, 1, 1) X(4, true, 4, 1, 1) X(8, true, 8, 1, 1) X(16, true, 16, 1, 1) X(8, true, 8, 1, 5) X(8, true, 8, 1, 8)
 // The kernels ask for up to 160 KiB of dynamic LDS (the default limit is 64 KiB): the attribute belongs to the CURRENT device's
 // function object, so it is raised once per device, from init_device (mzd_host.cpp), for every instantiation.
 int lds_prepare_device() {
-#define X(GG, DD, XX, WW) if (hipFuncSetAttribute((const void*)lw::mzd_lds_kernel<GG, DD, XX, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return MZD_E_DEVICE; }
+#define X(GG, DD, XX, WW, NN) if (hipFuncSetAttribute((const void*)lw::mzd_lds_kernel<GG, DD, XX, WW, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return MZD_E_DEVICE; }
     MZD_LDS_VARIANTS(X)
 #undef X
     return MZD_OK;
 }
-int launch_lds(const LdsArgs& a, uint32_t grid, int g, int xg, int with_dict, int nw, void* stream) {
-    const uint32_t bytes = lds_kernel_bytes(g, xg, with_dict, a.tab_bytes, a.comp_bytes, a.out_bytes, nw);
+int launch_lds(const LdsArgs& a, uint32_t grid, int g, int xg, int with_dict, int nw, int nd, void* stream) {
+    const uint32_t bytes = lds_kernel_bytes(g, xg, with_dict, a.tab_bytes, a.comp_bytes, a.out_bytes, nw, nd);
     hipStream_t s = (hipStream_t)stream;
-#define X(GG, DD, XX, WW) if (g == GG && xg == XX && (with_dict != 0) == DD && nw == WW) { hipLaunchKernelGGL((lw::mzd_lds_kernel<GG, DD, XX, WW>), dim3(grid), dim3(64 * WW), bytes, s, a); return MZD_OK; }
+#define X(GG, DD, XX, WW, NN) if (g == GG && xg == XX && (with_dict != 0) == DD && nw == WW && nd == NN) { hipLaunchKernelGGL((lw::mzd_lds_kernel<GG, DD, XX, WW, NN>), dim3(grid), dim3(64 * WW * NN), bytes, s, a); return MZD_OK; }
     MZD_LDS_VARIANTS(X)
 #undef X
     return MZD_E_PARAM;
