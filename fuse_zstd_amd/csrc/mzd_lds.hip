@@ -288,7 +288,8 @@ DI uint32_t read_ncount_lane(uint32_t src_off, uint32_t n, int max_log, int max_
     int32_t bit = 4, bc = 0, remaining = 1 << al, sym = 0;
     uint32_t rep = 0; // the next field continues a zero run
     for (;;) {
-        if (!(sym <= lim && (rep != 0 || (remaining > 0 && sym < lim)))) break;
+        const bool go = (sym <= lim) & ((rep != 0) | ((remaining > 0) & (sym < lim))); // (no short circuits: each one was an exec-mask region of its own, twenty scalar instructions a round)
+        if (!go) break;
         const int32_t bn = bit & ~7;
         const uint64_t wn = lds_u64(src_off + ((uint32_t)bn >> 3));
         const uint32_t x = (uint32_t)(wc >> (bit - bc));
