@@ -50,7 +50,7 @@ constexpr uint32_t kMaxDicts = 64;
 constexpr size_t kMaxChunks = 16;               // ... and at most this many chunks per call
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
-std::atomic<int> g_small_g{0}, g_small_xg{0}, g_small_nw{0}, g_trace_t2{0}, g_keep_behind{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
+std::atomic<int> g_small_g{0}, g_small_xg{0}, g_small_nw{0}, g_trace_t2{0}, g_keep_behind{0}, g_resolve{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
 std::atomic<unsigned> g_small_grid{0};               // mzd_debug_host_path 6: its grid (0: as many wavefronts as the device holds)
 constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 1280u; // (a workgroup's LDS is allocated in steps of 320 dwords: tools/micro/lds_granule_micro.hip -- five workgroups of 32 000 bytes share a CU, five of 32 640 do not, and the occupancy API says they do)
 std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic with the
@@ -473,10 +473,14 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     // few tasks for the lane's workgroups: the in-order copy stage is the critical path -- resolve blocks ahead (mzd_k_resolve.h)
     const int force = g_force_driver.load(std::memory_order_relaxed);
     ka.resolve_map = d.resolve_map;
-    // 1: every task after a file's first resolves ahead (up to ~8 blocks per workgroup slot -- the measured crossover on cfg4lu --
-    // or a few very big files, which are chains however many blocks they have); 2: only tasks whose predecessor is still
-    // running when they start (launches with more tasks than that)
-    ka.resolve = !use_tasks || force == 5 || !d.resolve_map ? 0u : ((force == 4 || p.blocks <= 8ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : 2u);
+    // 1: every task after a file's first resolves ahead -- launches of few multi-block files (chains however many blocks they have: one
+    // 64 MiB file is 500 blocks) or of up to two block tasks per workgroup slot; 0: in order -- half as many multi-block files as slots or
+    // more (3 / 8 of them): the files themselves are the parallelism, and a block that runs its copier beside its walk costs no byte map; 2: only tasks
+    // whose predecessor is still running when they start -- what lies between.  Measured (tools/big_resolve.py, profiles/r05_big_resolve.txt;
+    // 1 MiB JSON files, kernel ms, all ahead / behind a running predecessor / in order): 100 files 1.61 / 1.69 / 4.26, 200: 2.54 / 2.52 /
+    // 4.41, 400: 4.72 / 4.56 / 4.58, 800: 9.02 / 7.84 / 5.39 (round 4 resolved every task ahead up to eight tasks a slot: 800 files 9.03).
+    ka.resolve = !use_tasks || force == 5 || !d.resolve_map ? 0u : ((force == 4 || p.blocks <= 2ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : (p.nmulti >= l.nwg * 3 / 8 ? 0u : 2u)); // (400 files: in order within 1 % of the best, and a third of the traffic)
+    if (const int fr = g_resolve.load(std::memory_order_relaxed); fr && use_tasks && d.resolve_map) ka.resolve = (uint32_t)(fr - 1); // (mzd_debug_host_path 10: 1 in order, 2 every task ahead, 3 only behind a running predecessor)
     if (ev0) HIPCHK(hipEventRecord(ev0, s)); // (null: an untimed launch -- mzd_batch_launch_ex)
     uint32_t grid;
     if (p.nsmall) {
@@ -1057,7 +1061,8 @@ int mzd_debug_host_path(int device, int what, int value) {
     if (what == 6) { g_small_grid.store(value < 0 ? 0u : (unsigned)value); return MZD_OK; }
     if (what == 7) { g_trace_t2.store(value); return MZD_OK; }
     if (what == 8) { g_keep_behind.store(value); return MZD_OK; }
-    if (what == 9) { g_small_nw.store(value); return MZD_OK; } // (the small-file kernel's wavefronts per workgroup: 0 the library's choice, 1 never a helper wavefront, 2 with the 8 / 4 shape always) // (the general driver's launch behind a launch of small files alone stays: A/B)
+    if (what == 9) { g_small_nw.store(value); return MZD_OK; }
+    if (what == 10) { g_resolve.store(value); return MZD_OK; } // (the small-file kernel's wavefronts per workgroup: 0 the library's choice, 1 never a helper wavefront, 2 with the 8 / 4 shape always) // (the general driver's launch behind a launch of small files alone stays: A/B)
     return MZD_E_PARAM;
 }
 void* mzd_host_alloc(size_t n) {
