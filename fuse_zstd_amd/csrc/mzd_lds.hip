@@ -170,36 +170,20 @@ template <int LPF> DI uint32_t rep_before(uint32_t P, uint32_t sub) {
     return sub >= 1u ? t : kRepId;
 }
 
-// n (<= 31) bytes, held in d[0..7], to LDS offset `at`: exact pieces of 16 / 8 / 4 / 2 / 1; a lane without a piece stores to `dump`
-DI void store_exact31(uint32_t at, uint32_t n, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t d4, uint32_t d5, uint32_t d6, uint32_t d7, uint32_t dump) {
-    const lmask m16 = m_ne(n & 16, 0), m8 = m_ne(n & 8, 0), m4 = m_ne(n & 4, 0), m2 = m_ne(n & 2, 0), m1 = m_ne(n & 1, 0);
-    const uint32_t a16 = sel(m16, at, dump);
-    lds_s64(a16, (uint64_t)d0 | ((uint64_t)d1 << 32)); lds_s64(sel(m16, at + 8, dump), (uint64_t)d2 | ((uint64_t)d3 << 32));
-    d0 = sel(m16, d4, d0); d1 = sel(m16, d5, d1); d2 = sel(m16, d6, d2); d3 = sel(m16, d7, d3); at += n & 16;
-    lds_s64(sel(m8, at, dump), (uint64_t)d0 | ((uint64_t)d1 << 32));
-    d0 = sel(m8, d2, d0); d1 = sel(m8, d3, d1); at += n & 8;
-    lds_s32(sel(m4, at, dump), d0);
-    d0 = sel(m4, d1, d0); at += n & 4;
-    lds_s16(sel(m2, at, dump), d0);
-    d0 = sel(m2, d0 >> 16, d0); at += n & 2;
-    L8(sel(m1, at, dump)) = (uint8_t)d0;
-}
-// the same in two parts, so that a wavefront none of whose lanes holds 16 bytes or more skips the upper read and the first two stores:
+// n (<= 31) bytes to LDS offset `at` in exact pieces of 16 / 8 / 4 / 2 / 1, in two parts, so that a wavefront none of whose lanes holds 16 bytes or more skips the upper read and the first two stores:
 // store_piece16 takes the 16-byte piece (n & 16) from lo and moves hi down; store_exact15 stores n & 15 bytes held in d[0..3]
-DI void store_piece16(uint32_t& at, uint32_t n, uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3, uint32_t dump) {
-    const lmask m16 = m_ne(n & 16, 0);
-    lds_s64(sel(m16, at, dump), (uint64_t)d0 | ((uint64_t)d1 << 32)); lds_s64(sel(m16, at + 8, dump), (uint64_t)d2 | ((uint64_t)d3 << 32));
-    d0 = sel(m16, h0, d0); d1 = sel(m16, h1, d1); d2 = sel(m16, h2, d2); d3 = sel(m16, h3, d3); at += n & 16;
+// (Round 5: the stores are EXEC-MASKED -- `if (n & 8) store` -- where round 4 aimed the idle lanes' stores at a dump area to save the
+//  exec-mask bookkeeping: an LDS instruction is served in groups of 16 lanes (a file's lanes are one group) and a group without an
+//  active lane costs the LDS pipeline nothing, while a store to the dump costs it as much as a real one -- and the CU's LDS pipeline,
+//  shared by all its wavefronts, is what the execution is short of: cfg4 -3.4 %, cfg4x4 -7.8 %, cfg5 -4 %.)
+DI void store_piece16(uint32_t& at, uint32_t n, uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3) {
+    if (n & 16) { lds_s64(at, (uint64_t)d0 | ((uint64_t)d1 << 32)); lds_s64(at + 8, (uint64_t)d2 | ((uint64_t)d3 << 32)); d0 = h0; d1 = h1; d2 = h2; d3 = h3; at += 16; }
 }
-DI void store_exact15(uint32_t at, uint32_t n, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t dump) {
-    const lmask m8 = m_ne(n & 8, 0), m4 = m_ne(n & 4, 0), m2 = m_ne(n & 2, 0), m1 = m_ne(n & 1, 0);
-    lds_s64(sel(m8, at, dump), (uint64_t)d0 | ((uint64_t)d1 << 32));
-    d0 = sel(m8, d2, d0); d1 = sel(m8, d3, d1); at += n & 8;
-    lds_s32(sel(m4, at, dump), d0);
-    d0 = sel(m4, d1, d0); at += n & 4;
-    lds_s16(sel(m2, at, dump), d0);
-    d0 = sel(m2, d0 >> 16, d0); at += n & 2;
-    L8(sel(m1, at, dump)) = (uint8_t)d0;
+DI void store_exact15(uint32_t at, uint32_t n, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
+    if (n & 8) { lds_s64(at, (uint64_t)d0 | ((uint64_t)d1 << 32)); d0 = d2; d1 = d3; at += 8; }
+    if (n & 4) { lds_s32(at, d0); d0 = d1; at += 4; }
+    if (n & 2) { lds_s16(at, d0); d0 >>= 16; at += 2; }
+    if (n & 1) L8(at) = (uint8_t)d0;
 }
 // the minimum over the file's lanes, in all of them: DPP swaps inside quads, half rows and rows (no trip through the LDS crossbar
 // but for the second row of 32 lanes)
@@ -214,15 +198,14 @@ template <int LPF> DI uint32_t seg_min(uint32_t x, uint32_t lane) { // (the DPP 
 }
 // n bytes from LDS offset src to dst <= src by the file's LPF lanes, four bytes a lane and round (ascending rounds, every round reads
 // before it writes: a round's stores end below the next round's reads); the run's last 1..3 bytes in exact pieces
-template <int LPF> DI void copy_run_lanes(uint32_t dst, uint32_t src, uint32_t n, uint32_t sub, uint32_t dump) {
+template <int LPF> DI void copy_run_lanes(uint32_t dst, uint32_t src, uint32_t n, uint32_t sub) {
     for (uint32_t q = 4 * sub; q < n + 4 * sub; q += 4 * LPF) { // (the same number of rounds for all the file's lanes)
         const uint32_t left = q < n ? n - q : 0u;
-        const uint32_t v = lds_u32(left ? src + q : dump);
+        uint32_t v = 0;
+        if (left) v = lds_u32(src + q);
         asm volatile("" ::: "memory");
-        const lmask m4 = m_ge(left, 4), m2 = m_lt(left, 4) & m_ne(left & 2, 0), m1 = m_lt(left, 4) & m_ne(left & 1, 0);
-        lds_s32(sel(m4, dst + q, dump), v);
-        lds_s16(sel(m2, dst + q, dump), v);
-        L8(sel(m1, dst + q + (left & 2), dump)) = (uint8_t)(v >> (8 * (left & 2)));
+        if (left >= 4) lds_s32(dst + q, v);
+        else { if (left & 2) lds_s16(dst + q, v); if (left & 1) L8(dst + q + (left & 2)) = (uint8_t)(v >> (8 * (left & 2))); }
         asm volatile("" ::: "memory");
     }
 }
@@ -1431,9 +1414,9 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                     const uint32_t sa = lit_base + lp;
                     const uint32_t ls = ll < 32 ? ll : 0u; // (what this lane stores itself)
                     const bool lit_hi = __ballot(ls >= 16) != 0; // (wave-uniform: half the steps have no run of 16..31 literals)
-                    const V16 AB_ = lds_u128(sa);
-                    V16 CD_ = {0, 0};
-                    if (lit_hi) CD_ = lds_u128(sa + 16);
+                    V16 AB_ = {0, 0}, CD_ = {0, 0};
+                    if (ls) AB_ = lds_u128(sa); // (two thirds of the sequences bring no literals: their lanes stay out of the read)
+                    if (ls >= 16) CD_ = lds_u128(sa + 16);
                     asm volatile("" ::: "memory");
                     // (this loop runs per file: the lanes of files that are through are not here)
                     uint32_t big = file_bits<LPF>(__ballot(ll >= 32), f);
@@ -1441,15 +1424,20 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                         const uint32_t bl4 = ((lane & ~(LPF - 1)) + (uint32_t)__builtin_ctz(big)) * 4;
                         big &= big - 1;
                         const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bl4, (int)ll), o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bl4, (int)op), s2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bl4, (int)sa);
-                        copy_run_lanes<LPF>(outo + o2, s2, n2, sub, dump); // (destination at or below the source)
+                        copy_run_lanes<LPF>(outo + o2, s2, n2, sub); // (destination at or below the source)
                     }
                     {
                         uint32_t at = outo + op, d0 = (uint32_t)AB_.a, d1 = (uint32_t)(AB_.a >> 32), d2 = (uint32_t)AB_.b, d3 = (uint32_t)(AB_.b >> 32);
-                        if (lit_hi) store_piece16(at, ls, d0, d1, d2, d3, (uint32_t)CD_.a, (uint32_t)(CD_.a >> 32), (uint32_t)CD_.b, (uint32_t)(CD_.b >> 32), dump);
-                        store_exact15(at, ls, d0, d1, d2, d3, dump);
+                        if (lit_hi) store_piece16(at, ls, d0, d1, d2, d3, (uint32_t)CD_.a, (uint32_t)(CD_.a >> 32), (uint32_t)CD_.b, (uint32_t)(CD_.b >> 32));
+                        store_exact15(at, ls, d0, d1, d2, d3);
                     }
                     if (DICT) {
-                        store_exact31(outo + mp, dfull ? ml : 0u, (uint32_t)D0.a, (uint32_t)(D0.a >> 32), (uint32_t)D0.b, (uint32_t)(D0.b >> 32), (uint32_t)D1.a, (uint32_t)(D1.a >> 32), (uint32_t)D1.b, (uint32_t)(D1.b >> 32), dump);
+                        {
+                            const uint32_t dn = dfull ? ml : 0u;
+                            uint32_t at = outo + mp, d0 = (uint32_t)D0.a, d1 = (uint32_t)(D0.a >> 32), d2 = (uint32_t)D0.b, d3 = (uint32_t)(D0.b >> 32);
+                            store_piece16(at, dn, d0, d1, d2, d3, (uint32_t)D1.a, (uint32_t)(D1.a >> 32), (uint32_t)D1.b, (uint32_t)(D1.b >> 32));
+                            store_exact15(at, dn, d0, d1, d2, d3);
+                        }
                         if (dfull) ml = 0; // done
                     }
                 }
@@ -1492,15 +1480,15 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                             const uint32_t F = K >> 18;
                             const bool ready = pending & simple & (send <= F);
                             const uint32_t n = ready ? m : 0u;
-                            const uint32_t ra = ready ? outo + mp - off : dump;
+                            const uint32_t ra = outo + mp - off;
                             const bool hi = __ballot(n >= 16) != 0;
-                            const V16 AB_ = lds_u128(ra);
-                            V16 CD_ = {0, 0};
-                            if (hi) CD_ = lds_u128(ra + 16);
+                            V16 AB_ = {0, 0}, CD_ = {0, 0};
+                            if (ready) AB_ = lds_u128(ra); // (only the lanes that copy take part in the reads)
+                            if (n >= 16) CD_ = lds_u128(ra + 16);
                             asm volatile("" ::: "memory");
                             uint32_t at = outo + mp, d0 = (uint32_t)AB_.a, d1 = (uint32_t)(AB_.a >> 32), d2 = (uint32_t)AB_.b, d3 = (uint32_t)(AB_.b >> 32);
-                            if (hi) store_piece16(at, n, d0, d1, d2, d3, (uint32_t)CD_.a, (uint32_t)(CD_.a >> 32), (uint32_t)CD_.b, (uint32_t)(CD_.b >> 32), dump);
-                            store_exact15(at, n, d0, d1, d2, d3, dump);
+                            if (hi) store_piece16(at, n, d0, d1, d2, d3, (uint32_t)CD_.a, (uint32_t)(CD_.a >> 32), (uint32_t)CD_.b, (uint32_t)(CD_.b >> 32));
+                            store_exact15(at, n, d0, d1, d2, d3);
                             asm volatile("" ::: "memory");
                             pending = pending & !ready;
                         } else { // the first waiting match of every file, by the file's lanes: bytes sub, sub + LPF, ... (its source ends at or below its own start: complete)
@@ -1509,10 +1497,10 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                             constexpr int NB = LPF >= 32 ? 1 : 32 / (int)LPF; // bytes per lane: sub, sub + LPF, ... (< 32)
                             uint32_t vb[NB];
 #pragma unroll
-                            for (int j = 0; j < NB; j++) vb[j] = L8(sub + (uint32_t)j * LPF < km ? ks + sub + (uint32_t)j * LPF : dump);
+                            for (int j = 0; j < NB; j++) { vb[j] = 0; if (sub + (uint32_t)j * LPF < km) vb[j] = L8(ks + sub + (uint32_t)j * LPF); }
                             asm volatile("" ::: "memory");
 #pragma unroll
-                            for (int j = 0; j < NB; j++) L8(sub + (uint32_t)j * LPF < km ? kd + sub + (uint32_t)j * LPF : dump) = (uint8_t)vb[j];
+                            for (int j = 0; j < NB; j++) if (sub + (uint32_t)j * LPF < km) L8(kd + sub + (uint32_t)j * LPF) = (uint8_t)vb[j];
                             asm volatile("" ::: "memory");
                             pending = pending & !(is_first & simple);
                         }
@@ -1550,7 +1538,7 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                 const uint32_t rest = nlit - lend;
                 good = rest <= cap - oend;
                 if (good) {
-                    copy_run_lanes<LPF>(outo + oend, lit_base + lend, rest, sub, dump); // (destination at or below the source)
+                    copy_run_lanes<LPF>(outo + oend, lit_base + lend, rest, sub); // (destination at or below the source)
                     out_len = oend + rest;
                     good = !(has_fcs && out_len != fcs);
                 }
