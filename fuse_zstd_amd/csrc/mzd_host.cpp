@@ -395,6 +395,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
                     if (g_small_nw.load(std::memory_order_relaxed) == 2 && one_round(8, 4, split_tab, 2)) { p.lds_g = 8; p.lds_xg = 4; p.lds_nw = 2; p.lds_tab = split_tab; }
                     else if (one_round(8, 4, split_tab)) { p.lds_g = 8; p.lds_xg = 4; p.lds_tab = split_tab; }
                     else if (one_round(4, 2, split_tab)) { p.lds_g = 4; p.lds_xg = 2; p.lds_tab = split_tab; }
+                    else if (const uint64_t cap42 = (uint64_t)cus * waves_per_cu(4, 2, p.lds_tab) * 4; cap42 && 5 * ((p.nsmall + cap42 - 1) / cap42) <= 4 * ((p.nsmall + cap44 - 1) / cap44)) { p.lds_g = 4; p.lds_xg = 2; } // big windows: two windows a wavefront at a time let a fifth wavefront in -- a fifth fewer rounds or better (10 000 x 8 KiB: two rounds instead of three, 0.677 against 0.766 ms)
                     else if (maxcap <= 768 && waves_per_cu(8, 8, p.lds_tab) * 8 > w44 * 4) { p.lds_g = 8; p.lds_xg = 8; } // many rounds of tiny files: more of them resident, half the wavefronts (512 B x 40 000: 0.265 against 0.304 ms; from 1 KiB on 4 / 4 is ahead)
                 } else if (need44 > 8 && one_round(8, 8, split_tab) && split_tab == p.lds_tab) { p.lds_g = 8; p.lds_xg = 8; } // one round either way: five wavefronts of eight rather than ten of four
             }
