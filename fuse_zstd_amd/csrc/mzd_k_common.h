@@ -100,6 +100,10 @@ struct __attribute__((aligned(16))) Shared {
 #if defined(MZD_STAMPS) || defined(MZD_TFIN)
     uint64_t ttask, tstart, tabs, tfin[12]; // block start; finish of walker / copier / hasher / planner; literals ready; tables ready
 #endif
+#ifdef MZD_EXP_STREAMSTAMP
+    uint64_t sst[8]; // (diagnostic: take time << 2 | wavefront of streams 0..3, then their finish times)
+    uint64_t swv[16]; // (per wavefront: role entry, past the wait for the Huffman table, in front of the stream queue, first stream taken)
+#endif
     uint16_t huf[kHufEntries]; // sym | len << 8 (mzd_device.h: kHufEntries)
     int16_t norm[3][64];
     uint16_t next[3][64];

@@ -58,17 +58,26 @@ template <bool TASKS> struct BlockRun {
             uint32_t st = __atomic_fetch_add(&c.next_stream, lane == 0 ? 1u : 0u, __ATOMIC_RELAXED);
             st = (uint32_t)__builtin_amdgcn_readfirstlane(st);
             if (st >= streams || st >= 4) break;
+#ifdef MZD_EXP_STREAMSTAMP // (diagnostic: when which wavefront takes stream st, and when it is done -- slots 0..3 and 4, 5, 6, 9)
+            if (lane == 0) { S.sst[st] = ((__builtin_readcyclecounter() - S.tstart) << 2) | (uint64_t)wave; if (took == 0) S.swv[4 * wave + 3] = __builtin_readcyclecounter() - S.tstart; }
+#endif
             int r = 0;
             if (!__atomic_load_n(&c.err, __ATOMIC_RELAXED))
                 r = huf_stream_wave(b.blk + c.s_off[st], c.s_len[st], lbase + c.s_out[st], c.s_n[st], hl, hseg(), (wave == 2 && kSeg2Bytes < 2048) ? kSegBitsHalf : kSegBits, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) { post_err(&c.err, r); __atomic_fetch_or(&c.streams_mask, 1u << st, __ATOMIC_RELAXED); __atomic_fetch_add(&c.streams_done, 1u, __ATOMIC_RELAXED); }
+#ifdef MZD_EXP_STREAMSTAMP
+            if (lane == 0) S.sst[4 + st] = __builtin_readcyclecounter() - S.tstart;
+#endif
         }
     }
     // wavefronts 0 and 3 decode literals too once their own role is over (at once in a block without sequences)
     __device__ __forceinline__ void huf_helper() {
         Ctl& c = S.c;
         if (lit_type < 2) return;
+#ifdef MZD_EXP_STREAMSTAMP
+        if (lane == 0) S.swv[4 * wave + 2] = __builtin_readcyclecounter() - S.tstart;
+#endif
         if ((TASKS || lit_type == 2) && !spin_ge(&c.huf_fill, 2, &c.err)) return; // (a task fetches even an inherited table)
         if (!get_seq()) return;
         huf_streams(4);
@@ -88,12 +97,21 @@ __device__ __noinline__ void role_walk(BlockRun<TASKS> r) {
     Ctl& c = S.c;
     const BlockArgs& b = r.b;
     const int lane = r.lane;
+#ifdef MZD_EXP_STREAMSTAMP
+    if (lane == 0) S.swv[0] = __builtin_readcyclecounter() - S.tstart;
+#endif
     MZD_SETPRIO(MZD_PRIO_WALK); // header parse, tables and walk are one serial chain: the block's critical path
     if (lane == 0 && !b.block_pre) parse_seq_header(c, S.stage + 256, r.seq_len, 256);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) flag_store(&c.seq_parsed, 1);
     TFIN(6);
+#ifdef MZD_EXP_STREAMSTAMP
+    const bool gs_ = r.get_seq();
+    if (lane == 0) S.swv[1] = __builtin_readcyclecounter() - S.tstart;
+    if (gs_ && r.nseq) {
+#else
     if (r.get_seq() && r.nseq) {
+#endif
         int rc = 0;
         if (TASKS) {
             const bool inherit = !b.frame_first && (c.mode[0] == 3 || c.mode[1] == 3 || c.mode[2] == 3);
@@ -140,7 +158,13 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
     Ctl& c = S.c;
     const BlockArgs& b = r.b;
     const int lane = r.lane;
+#ifdef MZD_EXP_STREAMSTAMP
+    if (lane == 0) S.swv[12] = __builtin_readcyclecounter() - S.tstart;
+#endif
     const bool seq_ok = r.get_seq();
+#ifdef MZD_EXP_STREAMSTAMP
+    if (lane == 0) S.swv[13] = __builtin_readcyclecounter() - S.tstart;
+#endif
     if (TASKS && seq_ok && !b.is_final) {
         // the successor's inheritance: once this block's tables are final (and whatever it inherits itself has been read),
         // the kinds it rebuilt go to the file's table area and the version moves on (a file's last task has nobody to publish for)
@@ -236,7 +260,13 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
             if (lane == 0) flag_store(&c.huf_fill, 2);
             TFIN(8);
         }
+#ifdef MZD_EXP_STREAMSTAMP
+        if (lane == 0 && wave == 2) S.swv[4 * wave + 0] = __builtin_readcyclecounter() - S.tstart;
+#endif
         spin_ge(&c.huf_fill, 2, &c.err);
+#ifdef MZD_EXP_STREAMSTAMP
+        if (lane == 0) S.swv[4 * wave + 1] = __builtin_readcyclecounter() - S.tstart;
+#endif
     }
     const bool failed = __atomic_load_n(&c.err, __ATOMIC_RELAXED) != 0;
     if (lit_type == 1) { // RLE literals

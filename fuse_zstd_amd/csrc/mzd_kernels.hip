@@ -76,7 +76,14 @@ namespace mzd {
 #define TTASK_END() do { if (tid == 0) S.tfin[11] = __builtin_readcyclecounter() - S.ttask; } while (0)
 #endif
 #define TCOUNT(k, v) do { if (lane == 0) atomicAdd((unsigned long long*)&S.tfin[k], (unsigned long long)(v)); } while (0)
+#ifdef MZD_EXP_STREAMSTAMP
+#define TFIN_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 12; k_++) a.debug[a.wg0 + blockIdx.x].tfin[k_] = S.tfin[k_]; \
+    for (int k_ = 0; k_ < 4; k_++) a.debug[a.wg0 + blockIdx.x].tfin[k_] = S.sst[k_]; \
+    a.debug[a.wg0 + blockIdx.x].tfin[4] = (S.swv[0] << 32) | (S.swv[1] & 0xFFFFFFFFull); a.debug[a.wg0 + blockIdx.x].tfin[5] = (S.swv[2] << 32) | (S.swv[3] & 0xFFFFFFFFull); \
+    a.debug[a.wg0 + blockIdx.x].tfin[6] = (S.swv[12] << 32) | (S.swv[13] & 0xFFFFFFFFull); a.debug[a.wg0 + blockIdx.x].tfin[7] = (S.swv[14] << 32) | (S.swv[15] & 0xFFFFFFFFull); } } while (0)
+#else
 #define TFIN_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 12; k_++) a.debug[a.wg0 + blockIdx.x].tfin[k_] = S.tfin[k_]; } } while (0)
+#endif
 #else
 #define TFIN(k)
 #define TCOUNT(k, v)

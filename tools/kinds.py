@@ -19,7 +19,9 @@ for kind in corpus.KINDS:
         torch.cuda.synchronize()
     got = dout.cpu().numpy()
     ok = all(j.status == 0 for j in jobs) and all(bytes(got[int(cp.raw_offs[i]):int(cp.raw_offs[i]) + size]) == cp.raw_file(i).tobytes() for i in range(0, n, 17))
-    rc, out, blocks = oracle.decode(srcs[0], cap=size, want_trace=True)
-    b = blocks[0]
-    print("%-8s ok=%s kernel %.3f ms  ratio %.2f  block0: type %d lit_type %d nlit %d nseq %d" % (
-        kind, ok, mzd.last_kernel_ms(0), size * n / cp.comp_sizes.sum(), b["block_type"], b["lit_type"], b["n_lit"], b["n_seq"]), flush=True)
+    # the first block of 24 of the files (ONE file's says little: an `xray` file has anything from 0 to 4 500 sequences)
+    import numpy as np
+    bs = [oracle.decode(srcs[i], cap=size, want_trace=True)[2][0] for i in range(0, n, max(1, n // 24))]
+    nl = np.array([b["n_lit"] for b in bs]); ns = np.array([b["n_seq"] for b in bs])
+    print("%-8s ok=%s kernel %.3f ms  ratio %.2f  first blocks: type %d lit_type %d; literals min %d median %d max %d; sequences min %d median %d max %d" % (
+        kind, ok, mzd.last_kernel_ms(0), size * n / cp.comp_sizes.sum(), bs[0]["block_type"], bs[0]["lit_type"], nl.min(), np.median(nl), nl.max(), ns.min(), np.median(ns), ns.max()), flush=True)
