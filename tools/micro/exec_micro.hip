@@ -38,7 +38,7 @@ int main() {
                    waves, waves / 4, active, (double)c / (iters * 64.0 * 4), (double)c / (iters * 64.0 * 4) / (waves / 4));
         }
     // the same with the active lanes spread over the four 16-lane passes of the wavefront
-    struct { const char* what; uint64_t m; } pats[] = {{"lanes 0,16,32,48", 0x0001000100010001ull}, {"lanes 0-3 of every 16", 0x000F000F000F000Full}, {"lanes 0-7", 0xFFull}, {"lanes 0-3", 0xFull}, {"lanes 0-15", 0xFFFFull}, {"lanes 0-7 and 32-39", 0x000000FF000000FFull}};
+    struct { const char* what; uint64_t m; } pats[] = {{"lanes 0,16,32,48", 0x0001000100010001ull}, {"lanes 0-3 of every 16", 0x000F000F000F000Full}, {"lanes 0-7", 0xFFull}, {"lanes 0-3", 0xFull}, {"lanes 0-15", 0xFFFFull}, {"lanes 0-7 and 32-39", 0x000000FF000000FFull}, {"one lane in every 8", 0x0101010101010101ull}, {"lanes 0-1 of every 8", 0x0303030303030303ull}, {"lanes 0-3 of every 8", 0x0F0F0F0F0F0F0F0Full}, {"one lane in every 4", 0x1111111111111111ull}, {"one lane in every 32", 0x0000000100000001ull}, {"lanes 0-3 of every 32", 0x0000000F0000000Full}, {"lane 0 alone", 0x1ull}};
     for (int waves : {4, 8, 16})
         for (auto& p : pats) {
             hipLaunchKernelGGL(k, dim3(1), dim3(64 * waves), 0, 0, 8u, 0, d_out, d_cyc, iters, p.m);
