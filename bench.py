@@ -596,7 +596,7 @@ def main():
                                 "algorithmic_bytes_per_launch": ow.C + ow.U, "traffic": recorded_traffic(name), "buffer_sets_rotated": ow.nsets, "byte_exact": True, "steps": steps}
                 if name in ("cfg4", "cfg2") and not args.no_t2:
                     others[name]["t2_end_to_end"] = t2_end_to_end(ow, mzd, reps=3)
-                if name in ("cfg4", "cfg5") and not args.no_cpu_baseline:  # the north_star's many-small-files corpora: the CPU beside them (short samples)
+                if name in ("cfg2", "cfg4", "cfg5") and not args.no_cpu_baseline:  # the CPU beside them (short samples): the many-small-files corpora, and configs[1], whose host -> host rate INTEGRATION.md compares with it
                     others[name]["cpu_baseline"] = cpu_baseline(ow.cp, 2.0) if ow.dictionary is None else cpu_baseline_dict(ow.cp, ow.dictionary, 3.0)
                 ow.free()
                 del ow

@@ -778,6 +778,22 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                             s2 = wtab + 8 * bfe(y, 0, log); s1 = wtab + 8 * bfe(y, log, log);
                             Gw -= 2 * log;
                         }
+                        // While neither state can run the stream out in a round (a state takes at most `log` bits): rounds without the
+                        // over-read bookkeeping, which is half of a round's instruction slots (a lone wavefront pays every slot in full).
+                        while (Gw >= Gw0 + 2 * log && nw <= 250) {
+                            const uint64_t e1 = L64(s1), e2 = L64(s2);
+                            const uint32_t bn = 8 * ((Gw >> 3) - 7);
+                            const uint64_t wn = lds_u64(bn >> 3);
+                            const uint32_t h1 = (uint32_t)(e1 >> 32), h2 = (uint32_t)(e2 >> 32);
+                            const uint32_t n1 = h1 & 0xFF, n2 = h2 & 0xFF;
+                            const uint32_t low = Gw - n1 - n2;
+                            const uint32_t y = (uint32_t)(wc >> (low - bc));
+                            L16(wts + nw) = (uint16_t)(((h1 >> 16) & 0xFF) | ((h2 >> 8) & 0xFF00));
+                            s1 = (uint32_t)e1 + 8 * bfe(y, n2, n1);
+                            s2 = (uint32_t)e2 + 8 * bfe(y, 0, n2);
+                            Gw = low; nw += 2;
+                            wc = wn; bc = bn;
+                        }
                         // (ONE exit from the loop, sorted out behind it: with an exit per case the exec-mask bookkeeping was longer than the round)
                         bool over1, over2;
                         do {
