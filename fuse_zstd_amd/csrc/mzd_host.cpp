@@ -480,8 +480,11 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     // whose predecessor is still running when they start -- what lies between.  Measured (tools/big_resolve.py, profiles/r05_big_resolve.txt;
     // 1 MiB JSON files, kernel ms, all ahead / behind a running predecessor / in order): 100 files 1.61 / 1.69 / 4.26, 200: 2.54 / 2.52 /
     // 4.41, 400: 4.72 / 4.56 / 4.58, 800: 9.02 / 7.84 / 5.39 (round 4 resolved every task ahead up to eight tasks a slot: 800 files 9.03).
-    ka.resolve = !use_tasks || force == 5 || !d.resolve_map ? 0u : ((force == 4 || p.blocks <= 2ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : (p.nmulti >= l.nwg * 3 / 8 ? 0u : 2u)); // (400 files: in order within 1 % of the best, and a third of the traffic)
-    if (const int fr = g_resolve.load(std::memory_order_relaxed); fr && use_tasks && d.resolve_map) ka.resolve = (uint32_t)(fr - 1); // (mzd_debug_host_path 10: 1 in order, 2 every task ahead, 3 only behind a running predecessor)
+    // Between the two, 5 / 16 .. 15 / 32 of the slots in multi-block files (320 .. 480 of 1 024), every OTHER task resolves ahead (3): the chain of in-order
+    // copies is half as long and so is the byte maps' work -- 350 files 3.99 -> 3.81 ms, 400: 4.49 -> 4.12, 450: 4.64 -> 4.45; 300: 3.49 / 3.53, 500: 4.71 / 4.78
+    // (profiles/r05_big_resolve.txt).
+    ka.resolve = !use_tasks || force == 5 || !d.resolve_map ? 0u : ((force == 4 || p.blocks <= 2ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : (p.nmulti >= l.nwg * 15 / 32 ? 0u : (p.nmulti >= l.nwg * 5 / 16 ? 3u : 2u)));
+    if (const int fr = g_resolve.load(std::memory_order_relaxed); fr && use_tasks && d.resolve_map) ka.resolve = (uint32_t)(fr - 1); // (mzd_debug_host_path 10: 1 in order, 2 every task ahead, 3 only behind a running predecessor, 4 every other task)
     if (ev0) HIPCHK(hipEventRecord(ev0, s)); // (null: an untimed launch -- mzd_batch_launch_ex)
     uint32_t grid;
     if (p.nsmall) {

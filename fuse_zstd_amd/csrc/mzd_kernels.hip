@@ -586,7 +586,9 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_tasks(Ker
             //  wait for: its copier and hasher follow its walker as they always do, and the file's checksum chain starts early)
             // resolve == 2 (a launch with many tasks per workgroup slot): only a task whose predecessor is NOT done yet resolves ahead --
             // one that can copy at once is better off with the streaming copier, which runs beside the walk.
-            const bool resolving = a.resolve != 0 && t != 0 && !(a.resolve == 2 && pred_done);
+            // resolve == 3 (what lies between the two): every other task of a file -- the odd ones -- resolves ahead: the chain of in-order copies
+            // is half as long, and so is the work the byte maps cost.
+            const bool resolving = a.resolve != 0 && t != 0 && !(a.resolve == 2 && pred_done) && !(a.resolve == 3 && !(t & 1));
             if (tid == 0) { S.ba = BlockArgs{src, n, dst, cap, dst2, src + pos0, bsize, pos0, 0, lit_buf, seqs, walk, last, hashing, false, t, frame_first, is_final, fs, ta, j, &a}; }
             __syncthreads();
             const BlockArgs& ba = S.ba; // (in LDS: see driver 1)

@@ -156,13 +156,14 @@ def test_many_multi_block_files_in_a_launch_that_fills_the_machine(mode):
 
 
 @needs_zstd
-@pytest.mark.parametrize("mode", [2, 4, 5])
+@pytest.mark.parametrize("mode", [2, 4, 5, "odd"])
 def test_hand_overs_between_block_tasks_hold_under_repetition_on_a_machine_filling_mix(mode):
     """The runs that showed round 3's one real defect (a hand-over flag published without an agent-scope release: right bytes,
     wrong digest, once in a hundred runs of ONE shape under load) as a test: 2 000 files log-uniform 4 KiB .. 1 MiB -- a machine-
     filling mix of single-block files and chains of up to eight block tasks, every file with a content checksum, so a stale
     hand-over of the XXH64 state fails its file -- decoded 200 times under each block-task driver (2: automatic resolve-ahead,
-    4: every task after a file's first resolves ahead, 5: none does), statuses and every output byte checked after every
+    4: every task after a file's first resolves ahead, 5: none does, "odd": every other task does -- KernelArgs::resolve = 3, resolving
+    and streaming tasks hand over to each other along every file), statuses and every output byte checked after every
     repetition; then `window_log10` (586 one-KiB blocks, each handing four things to its successor) 300 times.  HBM -> HBM, bytes
     compared on the device."""
     torch = pytest.importorskip("torch")
@@ -180,7 +181,9 @@ def test_hand_overs_between_block_tasks_hold_under_repetition_on_a_machine_filli
     wl_want = torch.from_numpy(np.frombuffer(wl.expected(), dtype=np.uint8).copy()).to(dev)
     wl_out = torch.zeros(wl.out_len + 64, dtype=torch.uint8, device=dev)
     wl_jobs = mzd.api.make_jobs([wl_comp.data_ptr()], [len(wl.comp)], [wl_out.data_ptr()], [wl.out_len])
-    mzd.set_driver(mode)
+    mzd.set_driver(2 if mode == "odd" else mode)
+    if mode == "odd":
+        mzd.api.lib().mzd_debug_host_path(0, 10, 4)
     try:
         for rep in range(200):
             out.zero_()
@@ -196,11 +199,12 @@ def test_hand_overs_between_block_tasks_hold_under_repetition_on_a_machine_filli
             res = mzd.decode_batch_device(0, wl_jobs)
             assert res[0] == (0, wl.out_len) and torch.equal(wl_out[:wl.out_len], wl_want), (mode, rep, res[0])
     finally:
+        mzd.api.lib().mzd_debug_host_path(0, 10, 0)
         mzd.set_driver(0)
 
 
 @needs_zstd
-@pytest.mark.parametrize("mode", [0, 3, 2, 4, 5])
+@pytest.mark.parametrize("mode", [0, 3, 2, 4, 5, "odd"])
 def test_a_batch_of_corrupted_multi_block_files_holds_under_repetition(mode):
     """Round 4's one real defect as a test: the 512 mutated, truncated and too-small multi-block files of
     tests/test_gpu_parity.py::test_corrupted_multi_block_files_report_the_oracles_error, decoded 40 times under each
@@ -225,7 +229,9 @@ def test_a_batch_of_corrupted_multi_block_files_holds_under_repetition(mode):
             cases.append((good, cap))
     want = [oracle.decode(c, cap=cap)[0] for c, cap in cases]
     comps, caps = [c for c, _ in cases], [cap for _, cap in cases]
-    mzd.set_driver(mode)
+    mzd.set_driver(2 if mode == "odd" else mode)  # ("odd": block tasks, every other one resolved ahead -- KernelArgs::resolve = 3)
+    if mode == "odd":
+        mzd.api.lib().mzd_debug_host_path(0, 10, 4)
     try:
         mzd.decode_batch(comps, caps)  # (buffers, lanes)
         for rep in range(40):
@@ -236,6 +242,7 @@ def test_a_batch_of_corrupted_multi_block_files_holds_under_repetition(mode):
             assert not bad, (mode, rep, bad[:5])
             assert wall < 2.0, (mode, rep, wall)  # (~0.05 s; the shortest of the kernels' bounded waits takes 4 s to run out)
     finally:
+        mzd.api.lib().mzd_debug_host_path(0, 10, 0)
         mzd.set_driver(0)
 
 
