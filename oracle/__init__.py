@@ -66,6 +66,8 @@ def lib():
         L.ozs_xxh64.restype = C.c_uint64
         L.ozs_xxh64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
         L.ozs_last_verdict_unpinned.restype = C.c_int
+        L.ozs_last_verdict_inexact.restype = C.c_int
+        L.ozs_last_verdict_lit_inexact.restype = C.c_int
         L.ozs_strerror.restype = C.c_char_p
         L.ozs_strerror.argtypes = [C.c_int]
         _lib = L
@@ -110,6 +112,18 @@ def last_verdict_unpinned():
     """The last decode() rejected its input because a sequence bitstream ran out inside a block: libzstd rejects it too, with the
     class its bit container's leftovers lead to (zstd_oracle.h)."""
     return bool(lib().ozs_last_verdict_unpinned())
+
+
+def last_verdict_inexact():
+    """True when the last decode() failed because a block's sequence bitstream was not consumed exactly (its sequences all executed):
+    libzstd older than 1.5.4 does not look at that and reports what comes next."""
+    return bool(lib().ozs_last_verdict_inexact())
+
+
+def last_verdict_lit_inexact():
+    """True when the last decode() failed because a Huffman literal stream was not consumed exactly: corrupt by RFC 8878 and for
+    libzstd 1.4; libzstd 1.5 decodes on and leaves it to the content checksum."""
+    return bool(lib().ozs_last_verdict_lit_inexact())
 
 
 def content_size(src):

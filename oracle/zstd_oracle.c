@@ -259,6 +259,8 @@ static int huf_read_table(huf_tab* t, const uint8_t* src, size_t n) {
 }
 
 /* ------------------------------------------------------------------ K2: Huffman literals (A.4) */
+static int g_lit_inexact; /* the last verdict was "a Huffman literal stream was not consumed exactly" */
+int ozs_last_verdict_lit_inexact(void) { return g_lit_inexact; }
 static int huf_decode_stream(const huf_tab* t, const uint8_t* src, size_t n, uint8_t* out, size_t nout) {
     bbr b; int rc = bbr_init(&b, src, n);
     if (rc) return rc;
@@ -267,7 +269,7 @@ static int huf_decode_stream(const huf_tab* t, const uint8_t* src, size_t n, uin
         out[i] = t->sym[idx];
         b.pos -= t->len[idx];
     }
-    CHECK(b.pos == 0, OZS_E_CORRUPT); /* must end exactly at bit 0 */
+    if (b.pos != 0) { g_lit_inexact = 1; return OZS_E_CORRUPT; } /* must end exactly at bit 0 (RFC 8878 4.2.2; libzstd 1.5's fast loops do not look: ozs_last_verdict_lit_inexact) */
     return 0;
 }
 
@@ -364,6 +366,8 @@ static int seq_table(fse_tab* t, int mode, const uint8_t* p, size_t n, int max_l
  * *stream_bad = the stream was over-read or not consumed exactly.  execute_sequences() turns that into the verdict. */
 static int g_unpinned; /* the last verdict came from "the bitstream was over-read before the block's sequences were executed" */
 int ozs_last_verdict_unpinned(void) { return g_unpinned; }
+static int g_inexact; /* the last verdict was "the sequence bitstream was not consumed exactly" (every sequence executed): libzstd older than 1.5.4 does not look */
+int ozs_last_verdict_inexact(void) { return g_inexact; }
 static int decode_sequences(dctx* d, scratch* sc, const uint8_t* src, size_t n, uint32_t* nseq_out, uint32_t* valid_out, int* stream_bad, ozs_block_info* bi) {
     CHECK(n >= 1, OZS_E_CORRUPT);
     const uint8_t* p = src; const uint8_t* end = src + n;
@@ -448,7 +452,7 @@ static int execute_sequences(const dctx* d, const scratch* sc, uint32_t nlit, ui
         for (uint32_t k = 0; k < ml; k++) { op[k] = op[(ptrdiff_t)k - (ptrdiff_t)off]; }
         op += ml;
     }
-    CHECK(!stream_bad, OZS_E_CORRUPT);                          /* not consumed exactly: checked behind the loop (libzstd >= 1.5.4) */
+    if (stream_bad) { g_inexact = 1; return OZS_E_CORRUPT; }    /* not consumed exactly: checked behind the loop (libzstd >= 1.5.4) */
     uint32_t rest = nlit - lpos;
     CHECK((size_t)(oend - op) >= rest, OZS_E_DSTSIZE);
     CHECK((size_t)(op - block_start) + rest <= OZS_BLOCK_MAX, OZS_E_CORRUPT);
@@ -596,7 +600,7 @@ int ozs_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* o
     scratch sc; sc.lit = (uint8_t*)malloc(OZS_BLOCK_MAX + 32); sc.seq = (ozs_seq*)malloc(sizeof(ozs_seq) * (OZS_MAX_SEQ + 1));
     int rc = OZS_E_CORRUPT;
     size_t pos = 0, out = 0;
-    g_unpinned = 0; /* (per call: a decode that fails before any sequence is executed must not inherit the previous call's flag) */
+    g_unpinned = 0; g_inexact = 0; g_lit_inexact = 0; /* (per call: a decode that fails before any sequence is executed must not inherit the previous call's flags) */
     if (trace) trace->n = 0;
     if (!ds || !sc.lit || !sc.seq) goto done;
     rc = load_dict(ds, dict, dict_len);

@@ -83,6 +83,12 @@ const char* ozs_strerror(int code);
  * executed: libzstd rejects such input too, but with whatever class the garbage it then decodes leads to -- not a property of
  * the format, so tests that pin error CLASSES against ZSTD_getErrorCode skip those inputs.  Not thread-safe (test hook). */
 int ozs_last_verdict_unpinned(void);
+/* 1 when the last ozs_decode() rejected its input because a block's sequence bitstream was not consumed exactly (all of its sequences
+ * executed without an error): libzstd older than 1.5.4 does not check that and reports whatever comes next. */
+int ozs_last_verdict_inexact(void);
+/* 1 when the last ozs_decode() rejected its input because a Huffman literal stream was not consumed exactly (RFC 8878 4.2.2 calls
+ * that corrupt, and so does libzstd 1.4; libzstd 1.5 decodes on and leaves the garbage to the content checksum, if there is one). */
+int ozs_last_verdict_lit_inexact(void);
 
 #ifdef __cplusplus
 }
