@@ -413,6 +413,39 @@ def test_the_launch_policy_is_within_ten_percent_of_the_best_forced_choice():
 
 
 @needs_zstd
+def test_the_block_task_policy_is_within_ten_percent_of_the_best_way_of_executing_blocks():
+    """The same guard for the block tasks' four ways of executing a file's blocks (KernelArgs::resolve, mzd_host.cpp: enqueue): n files of
+    1 MiB (eight blocks each) under the library's choice and with every way forced (in order / every task resolved ahead / only behind a
+    running predecessor / every other task); the automatic choice must be within 10 % of the best, byte-exact.  The crossovers lie at
+    a quarter, 5/16 and 15/32 of the workgroup slots in multi-block files (tools/big_resolve.py, profiles/r05_big_resolve.txt)."""
+    import torch
+    dev = torch.device("cuda:0")
+    L = mzd.lib()
+    try:
+        for n in (60, 240, 300, 400, 560):
+            cp = corpus.build_corpus("json", 1, [1 << 20] * n)
+            comp = torch.from_numpy(cp.comp).to(dev)
+            end = int(cp.raw_offs[-1] + cp.raw_sizes[-1])
+            out = torch.zeros(end + 64, dtype=torch.uint8, device=dev)
+            jobs = mzd.api.make_jobs([comp.data_ptr() + int(o) for o in cp.comp_offs], cp.comp_sizes, [out.data_ptr() + int(o) for o in cp.raw_offs], cp.raw_sizes)
+            ms = {}
+            for way in (0, 1, 2, 3, 4):
+                L.mzd_debug_host_path(0, 10, way)
+                best = 1e9
+                for _ in range(3):
+                    out.zero_()
+                    torch.cuda.synchronize()
+                    res = mzd.decode_batch_device(0, jobs)
+                    assert all(st == 0 for st, _ in res), (n, way)
+                    best = min(best, mzd.last_kernel_ms(0))
+                assert mzd.last_kernel_name(0) == "mzd_decode_kernel_tasks" and bytes(out.cpu().numpy()[:end]) == cp.raw[:end].tobytes(), (n, way)
+                ms[way] = best
+            assert ms[0] <= 1.10 * min(ms[w] for w in (1, 2, 3, 4)), (n, {k: round(v, 3) for k, v in ms.items()})
+    finally:
+        L.mzd_debug_host_path(0, 10, 0)
+
+
+@needs_zstd
 def test_host_path_pinned_pageable_and_concurrent_calls():
     """mzd_decode_batch is a pipeline of chunks per device; buffers from mzd_host_alloc cross the link without a staging copy.
     Same bytes either way, also with several calls in flight from different threads (each on its own files)."""
