@@ -327,6 +327,12 @@ DI uint64_t xxh_tail(uint64_t hh, uint32_t q, uint32_t end) {
 }
 
 // Diagnostic build only (-DMZD_SMALL_STAMPS): cycle counter of workgroup 0 at every phase boundary of its first group.
+// -DMZD_SMALL_STAMPS_LIGHT: the same without the cycle ACCUMULATORS inside the walk and the execution (their registers put the 8 / 4
+// kernel past 256 and halve its residency: a cfg4 launch then takes two rounds) -- the per-workgroup clock values alone, in the product's shape.
+#ifdef MZD_SMALL_STAMPS_LIGHT
+#define MZD_SMALL_STAMPS
+#define MZD_SS_NOACC
+#endif
 #ifdef MZD_SMALL_STAMPS
 #define SSTAMP(k) do { if (a.stamps && w0 && wv == 0 && lane == 0 && first_group) { if (blockIdx.x == 0) a.stamps[k] = __builtin_readcyclecounter(); if ((k) < 12 && blockIdx.x < 3072) a.stamps[2048 + 16 * blockIdx.x + 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
@@ -447,7 +453,12 @@ struct DictInfo { // the dictionary whose image sits in LDS (wave-uniform)
 // tables: one image a CU instead of one a wavefront is what lets a fifth wavefront's slots fit (cfg5: 32 -> 40 files a CU).  Every
 // wavefront writes the image itself before it reads it (the same bytes from all of them).
 template <int G, bool DICT, int XG, int NW = 1, int ND = 1>
-__global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (ND > 4 ? 2 : 1)) void mzd_lds_kernel(LdsArgs a) {
+#ifdef MZD_SS_NOACC // (the light stamps build must keep the product's residency: two wavefronts a SIMD at least)
+#define MZD_LDS_MINWAVES(G, DICT, NW, ND) (((G == 4 || NW > 1) && !DICT) ? 3 : 2)
+#else
+#define MZD_LDS_MINWAVES(G, DICT, NW, ND) (((G == 4 || NW > 1) && !DICT) ? 3 : (ND > 4 ? 2 : 1))
+#endif
+__global__ __launch_bounds__(64 * NW * ND, MZD_LDS_MINWAVES(G, DICT, NW, ND)) void mzd_lds_kernel(LdsArgs a) {
     constexpr uint32_t LPF = 64 / G; // lanes per file in the entropy phases
     constexpr uint32_t XLPF = 64 / XG, NX = G / XG; // lanes per file = sequences per plan step in the execution; passes
     static_assert(LPF >= 4, "four Huffman streams");
@@ -1136,7 +1147,7 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                 Gh -= need;
             }
             nrun = (live && !bad) ? nseq : 0u;
-#ifdef MZD_SMALL_STAMPS
+#if defined(MZD_SMALL_STAMPS) && !defined(MZD_SS_NOACC)
             uint64_t tw_ = 0, tp_ = 0, t0_ = __builtin_readcyclecounter(), t1_ = 0;
 #define GSTAMP(acc) do { t1_ = __builtin_readcyclecounter(); acc += t1_ - t0_; t0_ = t1_; } while (0)
 #else
@@ -1225,7 +1236,7 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                 wsync();
                 GSTAMP(tp_);
             }
-#ifdef MZD_SMALL_STAMPS
+#if defined(MZD_SMALL_STAMPS) && !defined(MZD_SS_NOACC)
             if (a.stamps && w0 && wv == 0 && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[10] = tw_; a.stamps[11] = tp_; }
 #endif
             if (bad) { ok = false; live = false; nrun = 0; why = 6; }
@@ -1343,7 +1354,7 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                 A.chunk_l = bcast<LPF - 1, LPF>(il); A.chunk_t = bcast<LPF - 1, LPF>(it);
                 lpos += A.chunk_l; opos += A.chunk_t;
             };
-#ifdef MZD_SMALL_STAMPS
+#if defined(MZD_SMALL_STAMPS) && !defined(MZD_SS_NOACC)
             uint64_t xa_ = 0, xr_ = 0, xl_ = 0, xm_ = 0, xn_ = 0, xf_ = 0, xc_ = 0, xq_ = 0, xrare_ = 0, x0_ = __builtin_readcyclecounter(), x1_ = 0;
 #define XSTAMP(acc) do { x1_ = __builtin_readcyclecounter(); acc += x1_ - x0_; x0_ = x1_; } while (0)
 #else
@@ -1483,7 +1494,10 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                         const uint64_t pm = __ballot(pending);
                         if (!pm) break;
 #ifdef MZD_SMALL_STAMPS
-                        xn_++; wg_rounds_++;
+                        wg_rounds_++;
+#ifndef MZD_SS_NOACC
+                        xn_++;
+#endif
 #endif
                         if (wide && !first_round) wide = __ballot((uint32_t)__builtin_popcount(file_bits<LPF>(pm, f)) > kTogether) != 0; // (the counts only fall)
                         first_round = false;
@@ -1531,7 +1545,7 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                             const uint32_t fmp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)mp), foff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)off), fm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)fl4, (int)m);
                             if (seg) rare_match<LPF, DICT>(outo, fmp, foff, fm, sub, dict_end, dict_len);
                             pending = pending & !fc;
-#ifdef MZD_SMALL_STAMPS
+#if defined(MZD_SMALL_STAMPS) && !defined(MZD_SS_NOACC)
                             xrare_++;
 #endif
                         }
@@ -1544,7 +1558,7 @@ __global__ __launch_bounds__(64 * NW * ND, ((G == 4 || NW > 1) && !DICT) ? 3 : (
                 wsync();
                 cur = nxt;
             }
-#ifdef MZD_SMALL_STAMPS
+#if defined(MZD_SMALL_STAMPS) && !defined(MZD_SS_NOACC)
             if (a.stamps && w0 && wv == 0 && blockIdx.x == 0 && lane == 0 && first_group) { a.stamps[18] = xa_; a.stamps[19] = xr_; a.stamps[20] = xl_; a.stamps[21] = xm_; a.stamps[22] = xn_; a.stamps[23] = xf_; a.stamps[24] = xc_; a.stamps[25] = xq_; a.stamps[26] = xrare_; }
 #endif
             // the literals behind the last sequence
