@@ -453,11 +453,11 @@ struct DictInfo { // the dictionary whose image sits in LDS (wave-uniform)
 // tables: one image a CU instead of one a wavefront is what lets a fifth wavefront's slots fit (cfg5: 32 -> 40 files a CU).  Every
 // wavefront writes the image itself before it reads it (the same bytes from all of them).
 template <int G, bool DICT, int XG, int NW = 1, int ND = 1>
-#ifdef MZD_SS_NOACC // (the light stamps build must keep the product's residency: two wavefronts a SIMD at least)
-#define MZD_LDS_MINWAVES(G, DICT, NW, ND) (((G == 4 || NW > 1) && !DICT) ? 3 : 2)
-#else
-#define MZD_LDS_MINWAVES(G, DICT, NW, ND) (((G == 4 || NW > 1) && !DICT) ? 3 : (ND > 4 ? 2 : 1))
-#endif
+// Wavefronts a SIMD the kernels are built for -- what lds_waves_by_registers (below) tells the host: three for the plain G = 4 kernel
+// (168 registers), two for the other kernels without a dictionary image and for the dictionary kernels of five or more wavefronts a
+// workgroup (256), one for the other dictionary kernels (265).  Stated, not left to the compiler: the 8 / 4 kernel sits at exactly 256,
+// and one register more would halve a launch's residency without a word (a diagnostic build did: 257, a cfg4 launch in two rounds).
+#define MZD_LDS_MINWAVES(G, DICT, NW, ND) (((G == 4 || NW > 1) && !DICT) ? 3 : ((ND > 4 || !DICT) ? 2 : 1))
 __global__ __launch_bounds__(64 * NW * ND, MZD_LDS_MINWAVES(G, DICT, NW, ND)) void mzd_lds_kernel(LdsArgs a) {
     constexpr uint32_t LPF = 64 / G; // lanes per file in the entropy phases
     constexpr uint32_t XLPF = 64 / XG, NX = G / XG; // lanes per file = sequences per plan step in the execution; passes
