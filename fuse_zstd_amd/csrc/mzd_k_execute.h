@@ -182,10 +182,25 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint32_t first16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w.y >> 16));
         return first_full - ((first16 - (w.y >> 16)) & 0xFFFFu);
     };
-    auto issue_bits = [&](uint2 w2, uint32_t first_full, bool live, Win& o) {
+#if MZD_REC_NOPOS
+    // The records carry the three states only.  Where a sequence's fields lie follows from the states themselves: a sequence consumes
+    // extra + nbBits of each of its three entries (byte 1 of their high words; < 128 bits together), so a chunk's read heads are its
+    // first one minus an exclusive scan of those sums -- a DPP scan a chunk here instead of a select and a fourth lane's store per
+    // sequence on the walking wavefront, whose instruction slots are the block's critical path.  Returns the chunk's total.
+    auto issue_bits = [&](uint2 w2, uint32_t first_full, bool live, Win& o) -> uint32_t {
+        const uint32_t vL = w2.x & 0xFFFFu, vM = w2.x >> 16, vO = w2.y & 0xFFFFu;
+        o.hL = (uint32_t)(lds_entry(vL) >> 32); o.hM = (uint32_t)(lds_entry(vM) >> 32); o.hO = (uint32_t)(lds_entry(vO) >> 32); // (records hold state addresses)
+        const uint32_t tot_ = live ? ((o.hL + o.hM + o.hO) >> 8) & 0xFFu : 0u;
+        const uint32_t incl_ = wave_incl_scan(tot_, lane);
+        o.G = first_full - (incl_ - tot_) + 32; // (first_full: the chunk's first read head - 32)
+        const uint32_t chunk_bits = __builtin_amdgcn_readlane(incl_, 63);
+#else
+    auto issue_bits = [&](uint2 w2, uint32_t first_full, bool live, Win& o) -> uint32_t {
         const uint32_t vL = w2.x & 0xFFFFu, vM = w2.x >> 16, vO = w2.y & 0xFFFFu;
         o.G = unwrap(w2, first_full) + 32; // records carry the read head - 32
         o.hL = (uint32_t)(lds_entry(vL) >> 32); o.hM = (uint32_t)(lds_entry(vM) >> 32); o.hO = (uint32_t)(lds_entry(vO) >> 32); // (records hold state addresses)
+        const uint32_t chunk_bits = 0;
+#endif
         o.bO = 0; o.bM = 0; o.bL = 0;
         if (live) {
             const uint32_t xM = o.hM >> 24, xO = o.hO >> 24, xL = o.hL >> 24;
@@ -193,6 +208,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
             const gcptr gb = (gcptr)gbase;
             __builtin_memcpy(&o.bO, gb + (tO >> 3), 8); __builtin_memcpy(&o.bM, gb + (tM >> 3), 8); __builtin_memcpy(&o.bL, gb + (tL >> 3), 8);
         }
+        return chunk_bits;
     };
     if (!wait_walker(128)) return MZD_E_CORRUPT;
     uint2 recA = load_rec((uint32_t)lane), recB = load_rec(64 + (uint32_t)lane); // chunks 0 and 1
@@ -202,7 +218,8 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         return cur_full - ((a16 - b16) & 0xFFFFu);
     };
     Win win;
-    issue_bits(recA, gfirst, (uint32_t)lane < nseq, win);
+    uint32_t bits_cur = issue_bits(recA, gfirst, (uint32_t)lane < nseq, win); // (MZD_REC_NOPOS: bits the current chunk consumes)
+    (void)bits_cur;
     uint32_t chunk = 0;
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
@@ -216,8 +233,13 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         if (!wait_walker(base + 192)) return MZD_E_CORRUPT; // the walker failed (it posted the error) or never got there
         const uint2 recC = load_rec(base + 128 + (uint32_t)lane);
         Win next;
+#if MZD_REC_NOPOS
+        const uint32_t gnext = gfirst - bits_cur;
+        bits_cur = issue_bits(recB, gnext, base + 64 + (uint32_t)lane < nseq, next);
+#else
         const uint32_t gnext = base + 64 < nseq ? next_first(recA, recB, gfirst) : gfirst;
         issue_bits(recB, gnext, base + 64 + (uint32_t)lane < nseq, next);
+#endif
         // stage 2: fields of chunk k from the windows issued an iteration ago
         uint32_t ll = 0, ml = 0, ofv = 4;
         if (valid) {

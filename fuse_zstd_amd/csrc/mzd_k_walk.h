@@ -98,6 +98,16 @@ constexpr uint32_t kWalkLag = 32;
 constexpr uint32_t kWalkYield = MZD_WALK_YIELD;
 #define MZD_SDWA_B1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
 #define MZD_DPP_ALL " row_mask:0xf bank_mask:0xf\n"
+// the record: lane k of quad 0 stores 16 bits -- the three state addresses; the fourth lane's are the read head's (MZD_REC_NOPOS = 0)
+// or nothing anybody reads (1: the planner works the positions out of the states, plan_wave: a select less per step)
+#ifndef MZD_REC_NOPOS
+#define MZD_REC_NOPOS 1
+#endif
+#if MZD_REC_NOPOS
+#define MZD_WALK_REC(RECOFF) "global_store_short %[woff], v84, %[base] offset:" RECOFF "\n"
+#else
+#define MZD_WALK_REC(RECOFF) "v_cndmask_b32_e64 v70, v84, v87, %[l3]\n" "global_store_short %[woff], v70, %[base] offset:" RECOFF "\n"
+#endif
 #define MZD_WALK_STEP(SH, RECOFF, TAIL) \
     "s_waitcnt lgkmcnt(1)\n"                                             /* the entry is there (the window may still be on its way) */ \
     "v_add_u32_dpp v64, v49, v49 quad_perm:[1,0,3,2]" MZD_DPP_ALL        /* pair sums of the high words */ \
@@ -114,8 +124,7 @@ constexpr uint32_t kWalkYield = MZD_WALK_YIELD;
     "v_lshrrev_b32_e32 v71, 3, v87\n" \
     "v_and_b32_e32 v71, 0x1ffc, v71\n" \
     "ds_read2_b32 v[54:55], v71 offset1:1\n" \
-    "v_cndmask_b32_e64 v70, v84, v87, %[l3]\n" \
-    "global_store_short %[woff], v70, %[base] offset:" RECOFF "\n"       /* the NEXT step's record: the state as it is now, 16 bits a field */ \
+    MZD_WALK_REC(RECOFF)                                                 /* the NEXT step's record: the state as it is now, 16 bits a field */ \
     "v_and_or_b32 %[av], v87, 31, 32\n" \
     TAIL
 #define MZD_WALK_SLACK "v_min3_i32 %[slack], %[slack], %[sa], %[sb]\n"
@@ -140,8 +149,7 @@ __device__ __forceinline__ void walk_run_asm(uint32_t& A, uint32_t& Gm, uint32_t
         "ds_read_b64 v[48:49], v84\n"
         "v_and_b32_e32 v71, 0x1ffc, v71\n"
         "ds_read2_b32 v[54:55], v71 offset1:1\n"
-        "v_cndmask_b32_e64 v70, v84, v87, %[l3]\n"
-        "global_store_short %[woff], v70, %[base]\n" // the first step's record
+        MZD_WALK_REC("0") // the first step's record
         "v_and_or_b32 %[av], v87, 31, 32\n"
         "1:\n"
         "v_mov_b32_e32 %[s0], v84\n v_mov_b32_e32 %[s3], v87\n" // the group's starting state (the reads are in flight)
