@@ -21,19 +21,32 @@ constexpr int32_t kSegBitsHalf = 64 * 120; // ... 15 bytes per lane: a segment b
 #endif
 // BIG: a tree of depth 12 (L == 12), which libzstd accepts and no encoder emits: the table is indexed by the top 11 of the next 12
 // bits and two codes of length 12 share an entry (mzd_device.h: kHufEntries); four symbols per window instead of five (4 * 12 <= 57).
+//
+// `below` decides what becomes of a stream that is not consumed exactly (the rule of the reference's pin, libzstd 1.5.x -- restated in
+// oracle/zstd_oracle.c: huf_decode_stream, huf_fast_eligible):
+//   kHufStrict   libzstd's checked loops (one stream; a four-stream section that is not eligible for its fast loops): the stream needs its end
+//                mark and must be consumed exactly (RFC 8878 4.2.2);
+//   otherwise    libzstd's fast loops: they decode `nsym` symbols and never look at where the read point ends up -- what is left of the stream is
+//                ignored, a last byte of zero is eight data bits, and a stream that runs out reads on into the bytes in front of it, down to the
+//                section's first byte (the jump table's), `below` bytes under the stream; needing more than that is corrupt.
+constexpr uint32_t kHufStrict = 0xFFFFFFFFu;
 template <bool BIG>
-__device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int32_t seg_bits, int lane) {
+__device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int32_t seg_bits, int lane, uint32_t below) {
     if (sl == 0) return MZD_E_CORRUPT;
     uint32_t last = sp[sl - 1];
-    if (last == 0) return MZD_E_CORRUPT;
-    const int32_t nbits = (int32_t)((sl - 1) * 8 + (uint32_t)hibit(last));
+    const bool fast = !BIG && below != kHufStrict;
+    if (last == 0 && !fast) return MZD_E_CORRUPT;
+    const int32_t own_bits = last ? (int32_t)((sl - 1) * 8 + (uint32_t)hibit(last)) : (int32_t)(sl * 8); // the stream's own bits
+    if (fast) { sp -= below; sl += below; } // (what may be read: the section from its first byte)
+    const int32_t nbits = own_bits + (fast ? (int32_t)(below * 8) : 0);
     const uint32_t mask = (1u << L) - 1;
     const uint16_t* const tab = S.huf;
     const uint32_t lseg = lds_offset_of(seg); // (the staging segment is in LDS: DS instructions -- through the generic pointer every window load is a flat_load)
     int32_t pos = 0;        // bits consumed so far (wave-uniform, exact)
     uint32_t done = 0;      // symbols written so far
-    while (pos < nbits) {
-        const int32_t s0 = pos, s1 = pos + seg_bits < nbits ? pos + seg_bits : nbits;
+    while (pos < nbits && !(fast && done >= nsym)) {
+        const int32_t send = pos < own_bits ? own_bits : nbits; // (segments end at the stream's own first bit: a valid stream decodes nothing below it)
+        const int32_t s0 = pos, s1 = pos + seg_bits < send ? pos + seg_bits : send;
         // stage stream bytes [blo - 16, bhi): everything the segment can touch (16 bits of slack below it) behind a
         // 16-byte prefix, so that a window may start up to 8 bytes below the lowest byte needed; bytes below the
         // stream start read as zero (bits below bit 0 of a backward stream are zero)
@@ -54,10 +67,10 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
         if (lane == 63) q1 = s1;
         const int32_t lim = nbits - q1;
         // decode from stream position `from` until the lane's upper boundary; returns the exit position
-        auto walk = [&](int32_t from, uint32_t& cnt, uint8_t* dst) -> int32_t {
+        auto walk = [&](int32_t from, uint32_t& cnt, uint8_t* dst, uint32_t maxw) -> int32_t { // (maxw: symbols the lane may write, ~0u = all)
             int32_t rem = nbits - from; // bits below the read point
             uint32_t c = 0;
-            if (!BIG) {
+            if (!BIG && maxw == ~0u) {
                 // Whole windows of five symbols without the per-symbol boundary test, as long as the window STARTS above the lane's
                 // boundary: the last one may pass it -- it is then taken back and left to the checked loop below, which reads the same
                 // window.  (Four instruction slots per symbol instead of eleven; the decoder is bound by VALU issue on noisy data.)
@@ -98,7 +111,7 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
                     uint32_t l = e >> 8;
                     if (BIG && l == 12 && (v & 1)) e = reinterpret_cast<const uint8_t*>(&S.huf[2048])[v >> 1]; // the odd one of two codes of length 12
                     l = l ? l : 1u;
-                    if (dst && act) dst[c] = (uint8_t)e; // (one window per walk, but for a tree of depth 12)
+                    if (dst && act && c < maxw) dst[c] = (uint8_t)e; // (one window per walk, but for a tree of depth 12)
                     l = act ? l : 0u;
                     c += act ? 1u : 0u;
                     h -= (int32_t)l;
@@ -123,7 +136,7 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
         };
         int32_t start = q0;
         uint32_t cnt = 0;
-        int32_t exitp = walk(start, cnt, nullptr);
+        int32_t exitp = walk(start, cnt, nullptr, ~0u);
         if (cnt < 256 && (uint32_t)(exitp - q1) < 15) memo_put(0, (uint32_t)(exitp - q1 + 1) | (cnt << 4));
         for (int round = 0; round < 64; round++) {
             int32_t pe = __shfl_up(exitp, 1);
@@ -141,7 +154,7 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
             }
             if (__any(need)) {
                 if (need) {
-                    exitp = walk(start, cnt, nullptr);
+                    exitp = walk(start, cnt, nullptr, ~0u);
                     if (cnt < 256 && (uint32_t)(exitp - q1) < 15) memo_put(j, (uint32_t)(exitp - q1 + 1) | (cnt << 4));
                 }
 #if defined(MZD_STAMPS) && !defined(MZD_EXP_ROUNDS)
@@ -152,15 +165,20 @@ __device__ __noinline__ int huf_stream_wave_t(const uint8_t* sp, uint32_t sl, ui
         const uint32_t incl = wave_incl_scan(cnt, lane);
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
         const int32_t endp = __builtin_amdgcn_readlane(exitp, 63);
-        if (done + total > nsym || endp > nbits) return MZD_E_CORRUPT; // never write past this stream's share of the literals
         uint32_t dummy;
-        walk(start, dummy, out + done + (incl - cnt));
+        if (fast && done + total > nsym) { // the stream's symbols end inside this segment: what is left is ignored.  Never write past the stream's share
+            const uint32_t first = done + (incl - cnt); // of the literals: the lane that holds symbol nsym writes its first ones only (symbol by symbol)
+            if (first < nsym) walk(start, dummy, out + first, first + cnt <= nsym ? cnt : nsym - first);
+            return 0;
+        }
+        if (done + total > nsym || endp > nbits) return MZD_E_CORRUPT; // never write past this stream's share of the literals; a code that passes the lowest readable bit
+        walk(start, dummy, out + done + (incl - cnt), ~0u);
         done += total;
         pos = endp;
     }
-    if (done != nsym) return MZD_E_CORRUPT; // pos == nbits here: the stream was consumed exactly
+    if (done != nsym) return MZD_E_CORRUPT; // (checked loops: pos == nbits here, the stream was consumed exactly; fast loops: the section's bytes ran out)
     return 0;
 }
-__device__ __forceinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int32_t seg_bits, int lane) {
-    return L == 12 ? huf_stream_wave_t<true>(sp, sl, out, nsym, L, seg, seg_bits, lane) : huf_stream_wave_t<false>(sp, sl, out, nsym, L, seg, seg_bits, lane);
+__device__ __forceinline__ int huf_stream_wave(const uint8_t* sp, uint32_t sl, uint8_t* out, uint32_t nsym, uint32_t L, uint8_t* seg, int32_t seg_bits, int lane, uint32_t below) {
+    return L == 12 ? huf_stream_wave_t<true>(sp, sl, out, nsym, L, seg, seg_bits, lane, kHufStrict) : huf_stream_wave_t<false>(sp, sl, out, nsym, L, seg, seg_bits, lane, below);
 }

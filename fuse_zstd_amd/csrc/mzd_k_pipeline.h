@@ -53,6 +53,9 @@ template <bool TASKS> struct BlockRun {
         Ctl& c = S.c;
         const uint32_t hl = c.huf_log;
         uint8_t* const lbase = lit_in_place() ? place() : b.lit_buf;
+        // libzstd 1.5's fast loops take a four-stream section when its table is indexed by 11 bits, every stream has >= 8 bytes and the fourth
+        // stream's share starts inside the output; they do not insist on exact consumption (mzd_k_huffman.h: kHufStrict)
+        const bool fast_loops = streams == 4 && hl <= 11 && c.s_len[0] >= 8 && c.s_len[1] >= 8 && c.s_len[2] >= 8 && c.s_len[3] >= 8 && c.s_n[3] != 0;
         for (uint32_t took = 0; took < max_take; took++) {
             // every lane takes part (lanes != 0 add 0): no divergent region around the returning atomic
             uint32_t st = __atomic_fetch_add(&c.next_stream, lane == 0 ? 1u : 0u, __ATOMIC_RELAXED);
@@ -63,7 +66,8 @@ template <bool TASKS> struct BlockRun {
 #endif
             int r = 0;
             if (!__atomic_load_n(&c.err, __ATOMIC_RELAXED))
-                r = huf_stream_wave(b.blk + c.s_off[st], c.s_len[st], lbase + c.s_out[st], c.s_n[st], hl, hseg(), (wave == 2 && kSeg2Bytes < 2048) ? kSegBitsHalf : kSegBits, lane);
+                r = huf_stream_wave(b.blk + c.s_off[st], c.s_len[st], lbase + c.s_out[st], c.s_n[st], hl, hseg(), (wave == 2 && kSeg2Bytes < 2048) ? kSegBitsHalf : kSegBits, lane,
+                                    fast_loops ? c.s_off[st] - (c.s_off[0] - 6) : kHufStrict);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) { post_err(&c.err, r); __atomic_fetch_or(&c.streams_mask, 1u << st, __ATOMIC_RELAXED); __atomic_fetch_add(&c.streams_done, 1u, __ATOMIC_RELAXED); }
 #ifdef MZD_EXP_STREAMSTAMP

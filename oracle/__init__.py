@@ -68,6 +68,10 @@ def lib():
         L.ozs_last_verdict_unpinned.restype = C.c_int
         L.ozs_last_verdict_inexact.restype = C.c_int
         L.ozs_last_verdict_lit_inexact.restype = C.c_int
+        L.ozs_last_verdict_lit_lenient.restype = C.c_int
+        L.ozs_last_verdict_lit_over.restype = C.c_int
+        L.ozs_last_verdict_lit_through.restype = C.c_int
+        L.ozs_set_huf_rule.argtypes = [C.c_int]
         L.ozs_strerror.restype = C.c_char_p
         L.ozs_strerror.argtypes = [C.c_int]
         _lib = L
@@ -124,6 +128,28 @@ def last_verdict_lit_inexact():
     """True when the last decode() failed because a Huffman literal stream was not consumed exactly: corrupt by RFC 8878 and for
     libzstd 1.4; libzstd 1.5 decodes on and leaves it to the content checksum."""
     return bool(lib().ozs_last_verdict_lit_inexact())
+
+
+def last_verdict_lit_lenient():
+    """True when the last decode() ACCEPTED a literal stream that was not consumed exactly, as the reference's libzstd 1.5.x does in its
+    fast loops (libzstd 1.4.x refuses such input)."""
+    return bool(lib().ozs_last_verdict_lit_lenient())
+
+
+def last_verdict_lit_through():
+    """True when the last decode() ACCEPTED a literal stream that ran out and read on into the bytes in front of it (libzstd 1.5.x's fast
+    loops are bounded by the section's first byte, not the stream's)."""
+    return bool(lib().ozs_last_verdict_lit_through())
+
+
+def last_verdict_lit_over():
+    """True when the last decode() failed because a literal stream of a fast-loop section needed bits from below the section's first byte."""
+    return bool(lib().ozs_last_verdict_lit_over())
+
+
+def set_huf_rule(rule):
+    """1 (default): literal streams judged as the reference's libzstd 1.5.x does; 0: RFC 8878 / libzstd 1.4.x (always exact)."""
+    lib().ozs_set_huf_rule(int(rule))
 
 
 def content_size(src):

@@ -261,16 +261,60 @@ static int huf_read_table(huf_tab* t, const uint8_t* src, size_t n) {
 /* ------------------------------------------------------------------ K2: Huffman literals (A.4) */
 static int g_lit_inexact; /* the last verdict was "a Huffman literal stream was not consumed exactly" */
 int ozs_last_verdict_lit_inexact(void) { return g_lit_inexact; }
-static int huf_decode_stream(const huf_tab* t, const uint8_t* src, size_t n, uint8_t* out, size_t nout) {
-    bbr b; int rc = bbr_init(&b, src, n);
-    if (rc) return rc;
+/* Which rule decides about a literal stream that is not consumed exactly.
+ *   1 (default): the reference's pin, libzstd 1.5.x (Cargo.lock:2371-2396; >= 1.5.4).  Four-stream sections go through its "fast"
+ *      decoding loops whenever they are eligible (huf_fast_eligible below).  Those loops decode exactly `regen` symbols and never look
+ *      at where a stream's read point ends up:
+ *        - an UNDER-consumed stream is accepted, its leftover bits are ignored (g_lit_lenient);
+ *        - a last byte of zero -- no end mark -- is eight data bits (HUF_initFastDStream);
+ *        - a stream that RUNS OUT reads on into the bytes in front of it -- the previous stream's, then the jump table's: the loops'
+ *          lower bound is the section's first byte, not the stream's (g_lit_through).  libzstd refuses such a stream only if its read
+ *          pointer stands more than 8 bytes below the stream when the five-symbols-a-round loop ends (about the last ten symbols of
+ *          stream 1 are decoded behind that test), which depends on which of its two decoders (X1 / X2) the size heuristic picked;
+ *          here the stream is accepted whenever the section's bytes suffice.  tests/test_oracle.py counts both sides by name;
+ *        - a stream that needs bits from below the section's first byte is rejected (g_lit_over): libzstd decodes on from a bit
+ *          container it no longer refills.
+ *      One-stream sections, ineligible four-stream sections and trees of depth 12 take libzstd's checked loops: exact consumption or
+ *      corruption_detected, as RFC 8878 4.2.2 says.
+ *   0: RFC 8878 / libzstd 1.4.x: every stream must be consumed exactly. */
+static int g_huf_rule = 1;
+void ozs_set_huf_rule(int rule) { g_huf_rule = rule; }
+static int g_lit_lenient; /* the last decode ACCEPTED a literal stream that was not consumed exactly (rule 1) */
+int ozs_last_verdict_lit_lenient(void) { return g_lit_lenient; }
+static int g_lit_through; /* the last decode ACCEPTED a literal stream that ran out and read on into the bytes in front of it (rule 1) */
+int ozs_last_verdict_lit_through(void) { return g_lit_through; }
+static int g_lit_over;    /* the last verdict was "a stream of a fast-loop section needed bits from below the section's first byte" (rule 1) */
+int ozs_last_verdict_lit_over(void) { return g_lit_over; }
+static int huf_decode_stream(const huf_tab* t, const uint8_t* src, size_t n, uint8_t* out, size_t nout, int fast, size_t below) {
+    bbr b;
+    if (fast) { /* libzstd 1.5 HUF_initFastDStream: no end mark is no error, the byte is data */
+        if (n == 0) return OZS_E_CORRUPT;
+        b.p = src; b.n = n; b.pos = src[n - 1] ? (int64_t)(n - 1) * 8 + highbit(src[n - 1]) : (int64_t)n * 8;
+        b.p = src - below; b.n = n + below; b.pos += 8 * (int64_t)below; /* the loops' lower bound is the section's first byte */
+    } else {
+        int rc = bbr_init(&b, src, n);
+        if (rc) return rc;
+    }
     for (size_t i = 0; i < nout; i++) {
         uint32_t idx = bbr_peek(&b, t->log);
         out[i] = t->sym[idx];
         b.pos -= t->len[idx];
     }
-    if (b.pos != 0) { g_lit_inexact = 1; return OZS_E_CORRUPT; } /* must end exactly at bit 0 (RFC 8878 4.2.2; libzstd 1.5's fast loops do not look: ozs_last_verdict_lit_inexact) */
+    if (fast) {
+        if (b.pos < 0) { g_lit_inexact = 1; g_lit_over = 1; return OZS_E_CORRUPT; }
+        if (b.pos > 8 * (int64_t)below) g_lit_lenient = 1;
+        else if (b.pos < 8 * (int64_t)below) g_lit_through = 1;
+        return 0;
+    }
+    if (b.pos != 0) { g_lit_inexact = 1; return OZS_E_CORRUPT; } /* must end exactly at bit 0 (RFC 8878 4.2.2; libzstd's checked loops: BIT_endOfDStream) */
     return 0;
+}
+/* libzstd 1.5 HUF_DecompressFastArgs_init: the fast loops run when the table is indexed by 11 bits (every tree but one of depth 12: shallower
+ * trees are rescaled to 11), every stream has at least 8 bytes, and the fourth stream's share starts inside the output (3 * ceil(regen / 4) < regen:
+ * all sizes but 6 and 9).  (64-bit little-endian hosts with BMI2, i.e. any x86-64 machine of the last ten years: the reference's platform.) */
+static int huf_fast_eligible(const huf_tab* t, size_t l1, size_t l2, size_t l3, size_t l4, uint32_t regen) {
+    uint32_t seg = (regen + 3) / 4;
+    return g_huf_rule == 1 && t->log <= 11 && l1 >= 8 && l2 >= 8 && l3 >= 8 && l4 >= 8 && 3 * seg < regen;
 }
 
 /* ------------------------------------------------------------------ frame context */
@@ -318,7 +362,7 @@ static int decode_literals(dctx* d, scratch* sc, const uint8_t* src, size_t n, u
             CHECK(d->huf_valid, OZS_E_DICT);
         }
         if (streams == 1) {
-            int rc = huf_decode_stream(&d->huf, p, rem, sc->lit, regen);
+            int rc = huf_decode_stream(&d->huf, p, rem, sc->lit, regen, 0, 0);
             if (rc) return rc;
         } else {
             CHECK(rem >= 10, OZS_E_CORRUPT);
@@ -328,10 +372,11 @@ static int decode_literals(dctx* d, scratch* sc, const uint8_t* src, size_t n, u
             uint32_t seg = (regen + 3) / 4;
             CHECK(3 * seg <= regen, OZS_E_CORRUPT);
             const uint8_t* s = p + 6; int rc;
-            if ((rc = huf_decode_stream(&d->huf, s, l1, sc->lit, seg))) return rc;
-            if ((rc = huf_decode_stream(&d->huf, s + l1, l2, sc->lit + seg, seg))) return rc;
-            if ((rc = huf_decode_stream(&d->huf, s + l1 + l2, l3, sc->lit + 2 * seg, seg))) return rc;
-            if ((rc = huf_decode_stream(&d->huf, s + l1 + l2 + l3, l4, sc->lit + 3 * seg, regen - 3 * seg))) return rc;
+            const int fast = huf_fast_eligible(&d->huf, l1, l2, l3, l4, regen);
+            if ((rc = huf_decode_stream(&d->huf, s, l1, sc->lit, seg, fast, 6))) return rc;
+            if ((rc = huf_decode_stream(&d->huf, s + l1, l2, sc->lit + seg, seg, fast, 6 + l1))) return rc;
+            if ((rc = huf_decode_stream(&d->huf, s + l1 + l2, l3, sc->lit + 2 * seg, seg, fast, 6 + l1 + l2))) return rc;
+            if ((rc = huf_decode_stream(&d->huf, s + l1 + l2 + l3, l4, sc->lit + 3 * seg, regen - 3 * seg, fast, 6 + l1 + l2 + l3))) return rc;
         }
         *consumed = hs + comp;
     }
@@ -600,7 +645,7 @@ int ozs_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* o
     scratch sc; sc.lit = (uint8_t*)malloc(OZS_BLOCK_MAX + 32); sc.seq = (ozs_seq*)malloc(sizeof(ozs_seq) * (OZS_MAX_SEQ + 1));
     int rc = OZS_E_CORRUPT;
     size_t pos = 0, out = 0;
-    g_unpinned = 0; g_inexact = 0; g_lit_inexact = 0; /* (per call: a decode that fails before any sequence is executed must not inherit the previous call's flags) */
+    g_unpinned = 0; g_inexact = 0; g_lit_inexact = 0; g_lit_lenient = 0; g_lit_through = 0; g_lit_over = 0; /* (per call: a decode that fails before any sequence is executed must not inherit the previous call's flags) */
     if (trace) trace->n = 0;
     if (!ds || !sc.lit || !sc.seq) goto done;
     rc = load_dict(ds, dict, dict_len);

@@ -89,6 +89,17 @@ int ozs_last_verdict_inexact(void);
 /* 1 when the last ozs_decode() rejected its input because a Huffman literal stream was not consumed exactly (RFC 8878 4.2.2 calls
  * that corrupt, and so does libzstd 1.4; libzstd 1.5 decodes on and leaves the garbage to the content checksum, if there is one). */
 int ozs_last_verdict_lit_inexact(void);
+/* The rule for literal streams that are not consumed exactly: 1 (default) libzstd 1.5.x's, the reference's pin -- the fast loops of
+ * eligible four-stream sections decode their symbols and ignore what is left; 0: RFC 8878 / libzstd 1.4.x, always exact.  Test hook. */
+void ozs_set_huf_rule(int rule);
+/* 1 when the last ozs_decode() ACCEPTED a literal stream that was not consumed exactly (rule 1): libzstd 1.4.x refuses that input. */
+int ozs_last_verdict_lit_lenient(void);
+/* 1 when the last ozs_decode() ACCEPTED a literal stream that ran out and read on into the bytes in front of it (rule 1): libzstd 1.5.x
+ * does the same unless the overrun is deep when its loop ends (zstd_oracle.c). */
+int ozs_last_verdict_lit_through(void);
+/* 1 when the last ozs_decode() rejected its input because a stream of a fast-loop section needed bits from below the section's first
+ * byte (rule 1): libzstd 1.5.x decodes on from a bit container it no longer refills. */
+int ozs_last_verdict_lit_over(void);
 
 #ifdef __cplusplus
 }

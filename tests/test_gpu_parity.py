@@ -311,6 +311,35 @@ def test_multi_byte_mutations_match_oracle(driver, force_driver):
 
 
 @needs_zstd
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_literal_streams_not_consumed_exactly_follow_the_pinned_libzstd(driver, force_driver):
+    """Row A7b (foreign files, reference README.md:20-26): frames WITHOUT a checksum whose Huffman literal streams no longer end at their first
+    bit.  The reference's libzstd 1.5.x accepts most of them -- the fast loops of a four-stream section decode its symbols and never look at
+    the streams' ends: leftover bits are ignored, a stream that runs out reads on into the bytes in front of it -- and returns bytes;
+    RFC 8878 and libzstd 1.4 call them corrupt.  The oracle restates 1.5's rule and is pinned against 1.5's bytes on exactly these mutants
+    (tests/test_oracle.py::test_error_classes_against_libzstd_1_5_when_loadable, same generator and seed); here every mutant's status and bytes
+    on the device must be the oracle's, and the launch must contain accepted mutants of both kinds."""
+    from tests.mutants import NOCHK_FRAMES, nochk_mutants
+    force_driver(driver)
+    rng = np.random.RandomState(5)
+    cases = []
+    for kind, size, level, extra in NOCHK_FRAMES:
+        cases += nochk_mutants(kind, size, level, extra, 400 if kind == "xray" else 150, rng)
+    res = mzd.decode_batch([m for _, m, _ in cases], [cap for _, _, cap in cases])
+    bad = []
+    lenient = through = 0
+    for i, ((name, m, cap), (st, out)) in enumerate(zip(cases, res)):
+        rc, want = oracle.decode(m, cap=cap)
+        if rc == 0:
+            lenient += oracle.last_verdict_lit_lenient()
+            through += oracle.last_verdict_lit_through()
+        if st != rc or (st == 0 and out != want):
+            bad.append((i, name, st, rc))
+    assert not bad, (len(bad), bad[:10])
+    assert lenient > 100 and through > 100, (lenient, through)
+
+
+@needs_zstd
 def test_mutated_dictionary_frames_and_multi_frame_files_match_oracle():
     """Config-5-shaped records with mutated bytes, with the dictionary missing, truncated; files of frame + skippable frame +
     frame with mutated bytes (tools/fuzz_dict.py runs the same generator with more cases)."""
