@@ -181,6 +181,9 @@ uint32_t lds_spare_table_bytes(uint32_t comp_bytes, uint32_t out_bytes);
 
 
 void launch_decode(const KernelArgs& a, uint32_t grid, void* stream);
+// driver 1 with two files a workgroup (mzd_kernels.hip compiled with MZD_PAIRS = 1: mzd_decode_kernel_pairs); grid counts GROUPS of four wavefronts
+void launch_decode_pairs(const KernelArgs& a, uint32_t grid, void* stream);
+int pairs_prepare_device();
 int kernel_lds_bytes();
 
 } // namespace mzd

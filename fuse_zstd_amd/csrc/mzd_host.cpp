@@ -31,6 +31,10 @@ void launch_dict_kernel(const uint8_t* dict, uint32_t n, DevDict* out, int32_t* 
 #ifdef MZD_EXP_DEVSITE
 void devsite_take(uint32_t* out3);
 #endif
+#ifdef MZD_EXP_PLANDIAG
+void plandiag_take(uint32_t* out16);
+void plandiag_take_pairs(uint32_t* out16);
+#endif
 void* decode_kernel_ptr(int tasks);
 }
 
@@ -50,7 +54,7 @@ constexpr uint32_t kMaxDicts = 64;
 constexpr size_t kMaxChunks = 16;               // ... and at most this many chunks per call
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
-std::atomic<int> g_small_g{0}, g_small_xg{0}, g_small_nw{0}, g_trace_t2{0}, g_keep_behind{0}, g_resolve{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
+std::atomic<int> g_small_g{0}, g_small_xg{0}, g_small_nw{0}, g_trace_t2{0}, g_keep_behind{0}, g_resolve{0}, g_pairs{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
 std::atomic<unsigned> g_small_grid{0};               // mzd_debug_host_path 6: its grid (0: as many wavefronts as the device holds)
 constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 1280u; // (a workgroup's LDS is allocated in steps of 320 dwords: tools/micro/lds_granule_micro.hip -- five workgroups of 32 000 bytes share a CU, five of 32 640 do not, and the occupancy API says they do)
 std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic with the
@@ -165,6 +169,7 @@ int init_device(Device& d, int hip_id, int index, const InitCfg& cfg) {
     HIPCHK(hipSetDevice(hip_id));
     int cus = 0, per_cu = 0, per_cu2 = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_id));
+    { int prc = pairs_prepare_device(); if (prc) return prc; } // (two LDS images are more dynamic LDS than a kernel may ask for by default)
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_kernel_ptr(0), kWG, 0));
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, (const void*)decode_kernel_ptr(1), kWG, 0));
     { int lrc = lds_prepare_device(); if (lrc) return lrc; } // (the small-file kernels' dynamic-LDS limit: per device)
@@ -528,9 +533,22 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         if (p.lpt) { ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig; } // (largest first; nothing is appended: counter word 4 stays 0)
     }
     grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, l.nwg));
+    // Driver 1 with TWO files a workgroup (mzd_kernels.hip compiled with MZD_PAIRS, mzd_k_walk.h: one wavefront runs both files' sequence
+    // chains, the other walking wavefront sleeps): built in round 6 on the premise that the block pipeline is bound by VALU issue, and it
+    // is not -- the shared walk takes 11 % of a launch's VALU instructions away (SQ_INSTS_VALU 310 K -> 276 K a 128 KiB JSON file) and the
+    // launch is 15-30 % SLOWER (4 000 files: 2.63 -> 3.41 ms): a joint step costs 160 cycles against 151, every ring refill and void group of
+    // one file stalls the other's chain, and wavefronts wait on memory and LDS half of their time, on issue an eighth
+    // (profiles/r06_pairs_walkstat.txt, r06_pairs_pmc.txt).  Never chosen by the library; mzd_debug_host_path 11 = 2 runs it (the parity
+    // suite does, as driver "1p").
+    int groups = 1;
+    if (!use_tasks && g_pairs.load(std::memory_order_relaxed) == 2) {
+        groups = 2;
+        grid = std::max<uint32_t>(2u, std::min<uint32_t>((grid + 1u) & ~1u, l.nwg & ~1u)); // (whole workgroups: the odd group would lie outside the lane's scratch slots)
+    }
     // (the launch behind the small-file kernel takes what that kernel handed on, and its last workgroup zeroes the counter block of
     //  the lane's next launch)
-    launch_decode(ka, grid, s);
+    if (groups == 2) { launch_decode_pairs(ka, grid, s); if (&l == &d.whole) d.set_kernels("mzd_decode_kernel_pairs"); }
+    else launch_decode(ka, grid, s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev1, s));
     return MZD_OK;
@@ -1066,6 +1084,7 @@ int mzd_debug_host_path(int device, int what, int value) {
     if (what == 7) { g_trace_t2.store(value); return MZD_OK; }
     if (what == 8) { g_keep_behind.store(value); return MZD_OK; }
     if (what == 9) { g_small_nw.store(value); return MZD_OK; }
+    if (what == 11) { g_pairs.store(value); return MZD_OK; } // driver 1's workgroups: 0 the library's choice, 1 one file each, 2 two files each (one walking wavefront for both)
     if (what == 10) { g_resolve.store(value); return MZD_OK; } // (the small-file kernel's wavefronts per workgroup: 0 the library's choice, 1 never a helper wavefront, 2 with the 8 / 4 shape always) // (the general driver's launch behind a launch of small files alone stays: A/B)
     return MZD_E_PARAM;
 }
@@ -1336,6 +1355,9 @@ int mzd_debug_counters(int device, uint32_t* out8) {
     else HIPCHK(hipMemcpy(out8, d->job0_counter, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
 #ifdef MZD_EXP_DEVSITE
     mzd::devsite_take(out8 + 5); // (words 5, 6, 7: first, max, count)
+#endif
+#ifdef MZD_EXP_PLANDIAG
+    for (int tu_ = 0; tu_ < 2; tu_++) { uint32_t pd[16]; if (tu_) mzd::plandiag_take_pairs(pd); else mzd::plandiag_take(pd); if (pd[10]) { fprintf(stderr, "WALKSTAT tu %d: walks %u joint runs %u (steps %u) solo-after-wait %u solo runs %u (steps %u) slave alone %u slave served %u releases %u (void %u low %u) master wait Kcyc %u slave wait Kcyc %u; asm cycles/step joint %.1f solo %.1f\n", tu_, pd[10], pd[1], pd[7], pd[2], pd[3], pd[8], pd[4], pd[11], pd[9], pd[12], pd[13], pd[5], pd[6], pd[7] ? 64.0 * pd[14] / pd[7] : 0.0, pd[8] ? 64.0 * pd[15] / pd[8] : 0.0); } }
 #endif
     return MZD_OK;
 }

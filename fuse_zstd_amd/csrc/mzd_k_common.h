@@ -84,6 +84,14 @@ constexpr uint32_t kStage = MZD_WGS_PER_CU >= 5 ? 1536 : 2048;
 static_assert(true, ""); // K5: bytes of a staged run (mzd_k_execute.h)
 constexpr uint32_t kSeg2Bytes = MZD_WGS_PER_CU >= 5 ? 1024 : 2048; // Huffman stream segment of wavefront 2 (the others' are 2 KiB: mzd_k_huffman.h)
 constexpr uint32_t kResSymMax = 30;
+// Two groups in a workgroup: the walking wavefronts meet before every run of their hot loop; group 1's posts what its run starts from and
+// sleeps, group 0's runs both chains in one loop -- a quad of lanes each -- and writes back where group 1's ended (mzd_k_walk.h: walk_run).
+struct WalkShare {
+    uint32_t active;   // this group's walking wavefront is inside a walk (it will come to the meeting point again)
+    uint32_t state;    // the request: 0 none, 1 posted, 3 taken by the partner, 2 results are in
+    uint32_t A[3], Gm, woff, n, thresh, pv, prog_lds, yield;               // request: state addresses (LL, ML, OF), read head - 32, record offset, steps, lower bound, progress
+    uint32_t rA[3], rGm, done, voided, sA[3], sG;                   // results: the same after the run, steps done, the last group void, the state at its start
+};
 struct __attribute__((aligned(16))) Shared {
     uint8_t ring[kRingBytes + 16]; // first: at LDS offset 0 the walker's window address needs no base add
     // FSE decode entries, 8 bytes: low dword = LDS address (offset into S) of the next state's entry before the
@@ -122,6 +130,9 @@ struct __attribute__((aligned(16))) Shared {
     uint32_t res_prog[3];        // ... steps the three gathering wavefronts have completed (resolve_gather3)
     uint32_t res_nsym, res_sym[kResSymMax]; // ... chunks left out by the build that follows the planner: they hold offsets still symbolic
     uint32_t took_first;         // this workgroup has used its first ticket (take_ticket)
+    uint32_t and_word;           // mzd_k_resolve.h: a workgroup-wide AND
+    uint32_t bar;                // grp_sync: arrivals at the group's barriers (workgroups of two groups: s_barrier would join both)
+    WalkShare wk;                // the walking wavefronts' rendezvous (mzd_k_walk.h)
     uint32_t pre_job, pre_valid; // the job taken ahead (kNoJob: none) and whether c2 holds its parsed first block
     // driver 1: the small fields of the dictionary the workgroup used last (config 5: every file names the same one --
     // reading them from HBM again for each file costs a round trip per dependent load)
@@ -132,17 +143,54 @@ struct __attribute__((aligned(16))) Shared {
 #endif
 };
 
-// The workgroup's LDS image.  File scope, so that every device function addresses it with DS
-// instructions and immediate offsets (a `Shared&` parameter would be a flat pointer).
+// A GROUP is four wavefronts with an LDS image of their own: what decodes one file (driver 1) or one block (driver 2).  A hardware workgroup
+// holds ONE group (256 threads: the block-task driver, single-round launches of driver 1) or TWO (512 threads, round 6: the two groups' walking
+// wavefronts run their hot loop in ONE wavefront, a quad of lanes each -- mzd_k_walk.h: the chain's instructions are issued once for both files).
+// The groups of a workgroup share nothing else: each has its queue tickets, its scratch slot, its barriers (grp_sync).
+//
+// The image lives in the dynamic LDS segment (the kernels have no static LDS object, so it starts at LDS address 0): group g's image is
+// lds_img[g].  `S` is the calling wavefront's image; with two groups its address is not a compile-time constant (a base register per
+// function: measured at 1.3-2 % of a launch, profiles/r06_rtbase_ab.txt).
 #ifndef MZD_EXP_PADLDS
-static_assert(sizeof(Shared) <= (128 / MZD_WGS_PER_CU) * 1280, "MZD_WGS_PER_CU workgroups per CU");
+static_assert(sizeof(Shared) <= (128 / MZD_WGS_PER_CU) * 1280, "MZD_WGS_PER_CU groups per CU");
+static_assert(sizeof(Shared) % 16 == 0, "images are 16-byte aligned");
 static_assert(sizeof(((Shared*)nullptr)->stage) >= 2064 + 2048 + 64, "the copying wavefront's Huffman segment");
 #endif
-__shared__ Shared S;
+// The source is compiled TWICE (Makefile): MZD_PAIRS = 0, the kernels of one group a workgroup -- the image is a file-scope object at LDS address
+// 0, every place in it a compile-time constant, nothing of the above costs anything --, and MZD_PAIRS = 1, driver 1 alone as
+// mzd_decode_kernel_pairs with two groups a workgroup, the images in the dynamic LDS segment.
+#ifndef MZD_PAIRS
+#define MZD_PAIRS 0
+#endif
+#if MZD_PAIRS
+extern __shared__ __attribute__((aligned(16))) uint8_t lds_img[];
+constexpr uint32_t kGroupsMax = 2;
+__device__ __forceinline__ uint32_t grp_index() { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)); }
+__device__ __forceinline__ uint32_t grp_count() { return kGroupsMax; }
+__device__ __forceinline__ Shared& S_of(uint32_t g) { return *reinterpret_cast<Shared*>(lds_img + g * (uint32_t)sizeof(Shared)); }
+#define S (S_of(grp_index()))
+#else
+__shared__ Shared S_one;
+constexpr uint32_t kGroupsMax = 1;
+__device__ __forceinline__ uint32_t grp_index() { return 0u; }
+__device__ __forceinline__ uint32_t grp_count() { return 1u; }
+__device__ __forceinline__ Shared& S_of(uint32_t) { return S_one; }
+#define S S_one
+#endif
+__device__ __forceinline__ uint32_t vblock() { return blockIdx.x * grp_count() + grp_index(); } // the group's index in the launch: its first ticket, its scratch slot
+__device__ __forceinline__ uint32_t vgrid() { return gridDim.x * grp_count(); }
+// places inside an image (add the image's LDS address: lds_base())
 constexpr uint32_t kLdsLL = (uint32_t)offsetof(Shared, ll), kLdsML = (uint32_t)offsetof(Shared, ml), kLdsOF = (uint32_t)offsetof(Shared, of);
 constexpr uint32_t kLdsWalkDummy = (uint32_t)offsetof(Shared, walk_dummy);
 static_assert(kLdsLL == kBlkLdsLL && kLdsML == kBlkLdsML && kLdsOF == kBlkLdsOF, "mzd_device.h names the tables' places (dictionary images in HBM carry them)");
-__device__ __forceinline__ uint64_t lds_entry(uint32_t state_addr) { uint64_t v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(&S) + state_addr, 8); return v; }
+static_assert(kGroupsMax * sizeof(Shared) - sizeof(Shared) + kLdsOF + 2048 <= 65536, "walk records hold 16-bit state addresses");
+typedef __attribute__((address_space(3))) uint8_t lds_byte;
+__device__ __forceinline__ uint32_t lds_base() { return grp_index() * (uint32_t)sizeof(Shared); } // LDS address of the calling wavefront's image
+// A pointer parameter that always names a place in LDS: says so, so that the function's accesses are DS instructions, not flat ones (with the
+// image at a compile-time address the compiler saw that by itself -- every call passed the same constant)
+#define MZD_IN_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)(p)))
+// an FSE entry by its ABSOLUTE LDS address (what entries, walk records and the walker's registers hold)
+__device__ __forceinline__ uint64_t lds_entry(uint32_t state_addr) { uint64_t v; __builtin_memcpy(&v, (const lds_byte*)(uintptr_t)state_addr, 8); return v; }
 
 // The launch's arguments are read where the runtime put them (the kernel-argument segment: constant memory), never through the
 // by-value parameter: the roles take them by reference, and a reference to the parameter makes the compiler keep a copy of it per
@@ -184,6 +232,9 @@ __device__ __noinline__ uint32_t bits_at(const uint8_t* p, uint32_t nbytes, int3
     return (uint32_t)(v & ((1ull << n) - 1));
 }
 
+#ifdef MZD_EXP_PLANDIAG // (experiment: the first live plan lane whose position left the stream)
+static __device__ uint32_t g_plandiag[16];
+#endif
 // Intra-workgroup flags in LDS (the block pipeline): relaxed atomics + workgroup fences.  Every spin
 // also ends when an error is posted, and is bounded.
 __device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
@@ -193,7 +244,6 @@ __device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __atom
 __device__ __forceinline__ uint32_t flag_load_u(const uint32_t* p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__atomic_load_n(p, __ATOMIC_RELAXED)); }
 // LDS by offset: an address-space-qualified access is a DS instruction (a generic pointer into LDS makes FLAT ones, which
 // take the vector memory path as well)
-typedef __attribute__((address_space(3))) uint8_t lds_byte;
 __device__ __forceinline__ uint32_t lds_offset_of(const void* p) { return (uint32_t)(uintptr_t)(const lds_byte*)p; }
 __device__ __forceinline__ uint64_t lds_load_u64(uint32_t off) { uint64_t v; __builtin_memcpy(&v, (const lds_byte*)(uintptr_t)off, 8); return v; } // any alignment
 __device__ __forceinline__ void lds_store_u128(uint32_t off, const uint4& v) { __builtin_memcpy((lds_byte*)__builtin_assume_aligned((lds_byte*)(uintptr_t)off, 16), &v, 16); } // 16-byte aligned
@@ -221,6 +271,30 @@ __device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want, int32_
     return false;
 }
 
+
+// The group's barrier.  One group in the workgroup: the hardware's.  Two: s_barrier would join all eight wavefronts, whose groups work on
+// different files -- the four wavefronts of a group count their arrivals in their image instead (arrival k of barrier b is 4 b + k; everybody
+// leaves when 4 b + 4 are in).  Same memory semantics as __syncthreads: the wavefront's stores are complete before, its loads start after.
+__device__ __noinline__ void grp_sync_counted() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t* const bar = &S.bar;
+    uint32_t old = __atomic_fetch_add(bar, (threadIdx.x & 63) == 0 ? 1u : 0u, __ATOMIC_RELAXED); // (every lane takes part: no divergent region around the atomic)
+    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+    const uint32_t target = (old | 3u) + 1u;
+    if (old + 1u != target) {
+        uint32_t it = 0;
+        for (; it < (1u << 22) && (int32_t)(flag_load_u(bar) - target) < 0; it++) __builtin_amdgcn_s_sleep(4); // (a waiting wavefront must not eat issue slots: the hardware's barrier costs none)
+#ifdef MZD_EXP_PLANDIAG
+        if (it == (1u << 22) && (threadIdx.x & 63) == 0 && atomicCAS(&g_plandiag[0], 0u, 4u) == 0u) { g_plandiag[1] = S.c.job; g_plandiag[2] = old; g_plandiag[3] = flag_load(bar); g_plandiag[4] = threadIdx.x; g_plandiag[6] = blockIdx.x; g_plandiag[7] = vgrid(); }
+#endif
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#if MZD_PAIRS
+__device__ __forceinline__ void grp_sync() { grp_sync_counted(); }
+#else
+__device__ __forceinline__ void grp_sync() { __syncthreads(); }
+#endif
 
 // wave-wide inclusive scans, hand-written on the DPP path (no LDS traffic, no ds_bpermute latency): Hillis-Steele inside a row
 // of 16 lanes (row_shr 1, 2, 4, 8: a lane whose source lies outside its row keeps the identity), then a row's total into the row

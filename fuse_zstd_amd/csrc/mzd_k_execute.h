@@ -123,6 +123,7 @@ struct PlanCtx { // what the planning wavefront needs
     uint32_t rep[3];
     uint4* chunk_base;       // [k] = {output, literals} of the block before chunk k (for mzd_k_resolve.h): the walk records' array, whose
                              // entry k the planner has consumed by the time it plans chunk k
+    uint32_t seq_len;        // bytes of the sequence bitstream: no field is fetched from outside it
 };
 
 // Offsets in the plan: a plain value, or -- when the block starts before its predecessor has finished, so that
@@ -161,6 +162,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
     uint4* const chunk_base = (uint4*)(uintptr_t)u64_((uint64_t)(uintptr_t)cx.chunk_base);
     const uint32_t bias = 16 + (uint32_t)((uintptr_t)seq_sp & 15);
     const uint8_t* const gbase = seq_sp - bias;
+    const uint32_t g_hi = (bias + u32_(cx.seq_len)) * 8; // positions (bits from gbase) lie in [bias * 8, g_hi]: whatever the records say, nothing outside is fetched
     auto wait_walker = [&](uint32_t need) -> bool { // true when sequences [0, need) are recorded
         if (need > nseq) need = nseq;
         uint32_t pg = 0, it = 0;
@@ -202,7 +204,16 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint32_t chunk_bits = 0;
 #endif
         o.bO = 0; o.bM = 0; o.bL = 0;
-        if (live) {
+#ifdef MZD_EXP_PLANDIAG
+        if (live && !(o.G <= g_hi && o.G >= bias * 8) && atomicCAS(&g_plandiag[0], 0u, 1u) == 0u) {
+            g_plandiag[1] = S.c.job; g_plandiag[2] = (uint32_t)lane; g_plandiag[3] = o.G; g_plandiag[4] = g_hi; g_plandiag[5] = bias * 8; g_plandiag[6] = first_full;
+            g_plandiag[7] = nseq; g_plandiag[8] = w2.x; g_plandiag[9] = w2.y; g_plandiag[10] = grp_index(); g_plandiag[11] = vgrid(); g_plandiag[12] = flag_load(&S.c.walk_prog); g_plandiag[13] = flag_load(&S.c.walk_g0);
+            g_plandiag[14] = o.hL; g_plandiag[15] = o.hO;
+        }
+#endif
+        // (the walker stops at the first group that over-reads a corrupt stream and never publishes it; this bound is the second line: a position
+        //  that left the stream would be a wild HBM read here -- the fields then read as zero and the block fails in the copier's or the walker's verdict)
+        if (live && o.G <= g_hi && o.G >= bias * 8) { // (a field reaches at most 48 bits below its top: the 8 bytes in front of the stream are the block's own)
             const uint32_t xM = o.hM >> 24, xO = o.hO >> 24, xL = o.hL >> 24;
             const uint32_t tO = o.G - xO, tM = tO - xM, tL = tM - xL; // bottoms of the three fields
             const gcptr gb = (gcptr)gbase;

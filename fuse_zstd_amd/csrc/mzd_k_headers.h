@@ -3,6 +3,7 @@
 #pragma once
 // ------------------------------------------------------------------------------------ K0 + block driver
 __device__ __noinline__ void parse_frame_or_skip(Ctl& c, const uint8_t* src, uint64_t n, const DevDict* dicts, uint32_t ndicts, uint32_t job_dict) {
+    MZD_IN_LDS(&c);
     uint64_t pos = c.pos;
     if (pos >= n) { c.action = 2; return; }
     if (n - pos < 4) { c.err = MZD_E_TRUNCATED; return; }
@@ -52,6 +53,7 @@ __device__ __noinline__ void parse_frame_or_skip(Ctl& c, const uint8_t* src, uin
 }
 
 __device__ __noinline__ void parse_block_header(Ctl& c, const uint8_t* src, uint64_t n) {
+    MZD_IN_LDS(&c);
     if (n - c.pos < 3) { c.err = MZD_E_TRUNCATED; return; }
     uint32_t bh = ld24(src + c.pos);
     c.pos += 3;
@@ -64,6 +66,7 @@ __device__ __noinline__ void parse_block_header(Ctl& c, const uint8_t* src, uint
 
 // literals section header (+ Huffman weights).  Lane 0.
 __device__ __noinline__ void parse_literals(Ctl& c, const uint8_t* b, uint32_t n) {
+    MZD_IN_LDS(&c); MZD_IN_LDS(b);
     uint32_t type = b[0] & 3, sf = (b[0] >> 2) & 3;
     uint32_t regen, comp = 0, hs, streams = 0;
     c.lit_type = type;
@@ -122,6 +125,7 @@ __device__ __noinline__ void parse_literals(Ctl& c, const uint8_t* b, uint32_t n
 // wavefronts already work on the literals (errors are posted first-wins).
 // `stage_off`: where `b` lies inside S.stage (the normalized-count reader addresses the staging area by offset)
 __device__ __noinline__ void parse_seq_header(Ctl& c, const uint8_t* b, uint32_t n, uint32_t stage_off) {
+    MZD_IN_LDS(&c);
     if (n < 1) { post_err(&c.err, MZD_E_CORRUPT); return; }
     const uint8_t* p = b;
     const uint8_t* end = b + n;
@@ -181,7 +185,7 @@ __device__ __noinline__ void build_tables_wave(int lane) {
 // decision the workgroup takes on them is read through WG_SNAPSHOT: barrier, every lane copies
 // the words it needs into registers, barrier -- so no lane can still be reading a word when the
 // next step rewrites it, and all 256 lanes always take the same branch.
-#define WG_SNAPSHOT(...) do { __syncthreads(); __VA_ARGS__; __syncthreads(); } while (0)
+#define WG_SNAPSHOT(...) do { grp_sync(); __VA_ARGS__; grp_sync(); } while (0)
 
 
 // The launch's queue: tickets are job indices, or -- behind the small-file kernel -- indices into the launch's job list
@@ -189,10 +193,10 @@ __device__ __noinline__ void build_tables_wave(int lane) {
 __device__ __forceinline__ uint32_t queue_len(const KernelArgs& a) { return a.job_list ? a.nlist_fixed + __atomic_load_n(&a.counter[4], __ATOMIC_RELAXED) : a.njobs; }
 __device__ __forceinline__ uint32_t queue_job(const KernelArgs& a, uint32_t ticket) { return a.job_list ? a.job_list[ticket] : ticket; }
 // Tickets: a workgroup's FIRST ticket is its own index -- a thousand workgroups starting at once would otherwise queue up on one
-// atomic counter (~30 K cycles at the median) -- and the later ones come from the counter, which therefore counts from gridDim.x.
+// atomic counter (~30 K cycles at the median) -- and the later ones come from the counter, which therefore counts from the number of groups.
 __device__ __forceinline__ uint32_t take_ticket(const KernelArgs& a) { // thread 0
-    if (!S.took_first) { S.took_first = 1; return blockIdx.x; }
-    return gridDim.x + atomicAdd(&a.counter[0], 1u);
+    if (!S.took_first) { S.took_first = 1; return vblock(); }
+    return vgrid() + atomicAdd(&a.counter[0], 1u);
 }
 __device__ __forceinline__ uint32_t take_job(const KernelArgs& a) { // thread 0
     const uint32_t t = take_ticket(a);

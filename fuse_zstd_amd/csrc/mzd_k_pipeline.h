@@ -98,6 +98,7 @@ template <bool TASKS> struct BlockRun {
 // ---- wave 0: K0 sequence header, K3 tables, K4a serial state walk
 template <bool TASKS>
 __device__ __noinline__ void role_walk(BlockRun<TASKS> r) {
+    MZD_IN_LDS(&r.b);
     Ctl& c = S.c;
     const BlockArgs& b = r.b;
     const int lane = r.lane;
@@ -159,6 +160,7 @@ __device__ __noinline__ void role_walk(BlockRun<TASKS> r) {
 // ---- wave 3: (a task: publishes the tables for its successor,) K4b plan: fields, repeat offsets, positions
 template <bool TASKS>
 __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
+    MZD_IN_LDS(&r.b);
     Ctl& c = S.c;
     const BlockArgs& b = r.b;
     const int lane = r.lane;
@@ -199,7 +201,7 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
         int rc = MZD_E_CORRUPT;
         if (spin_ge(&c.tables_ready, 1, &c.err)) {
             // (a task plans before its predecessor has finished: the repeat offsets at its start are unknown unless it opens the frame)
-            PlanCtx px{b.walk, b.src + r.seq_off, &c.walk_prog, r.nlit, (!TASKS || b.frame_first) ? 1u : 0u, {c.rep[0], c.rep[1], c.rep[2]}, b.walk};
+            PlanCtx px{b.walk, b.src + r.seq_off, &c.walk_prog, r.nlit, (!TASKS || b.frame_first) ? 1u : 0u, {c.rep[0], c.rep[1], c.rep[2]}, b.walk, r.seq_len};
             MZD_SETPRIO(MZD_PRIO_PLAN);
             rc = plan_wave(b.seqs, r.nseq, px, lane);
             MZD_SETPRIO(0);
@@ -224,6 +226,7 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
 // phase: 3 both halves; 1 the literals only (a resolving task: mzd_k_resolve.h executes the block); 2 copy / hash only (its fallback)
 template <bool TASKS>
 __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored, int phase) {
+    MZD_IN_LDS(&r.b);
     Ctl& c = S.c;
     const BlockArgs& b = r.b;
     const KernelArgs& a = *r.b.args;
@@ -289,7 +292,7 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
     if (wave == 1) TFIN(4);
     }
     if (phase == 1) { // a resolving task: these two wavefronts build the block's byte map behind the planner (mzd_k_resolve.h)
-        if (r.get_seq() && r.nseq) resolve_build_follow(a.resolve_map + (size_t)(a.wg0 + blockIdx.x) * kResMapStride, b.seqs, b.walk, r.nseq, (uint32_t)(wave - 1), lane);
+        if (r.get_seq() && r.nseq) resolve_build_follow(a.resolve_map + (size_t)(a.wg0 + vblock()) * kResMapStride, b.seqs, b.walk, r.nseq, (uint32_t)(wave - 1), lane);
         return;
     }
     if (!(phase & 2)) return;
@@ -323,9 +326,9 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
             c.out = opos; c.pos = b.pos0 + b.bsize;
             flag_store(&c.exec_done, 1);
             if (a.debug) {
-                DebugSlot& ds = a.debug[a.wg0 + blockIdx.x];
+                DebugSlot& ds = a.debug[a.wg0 + vblock()];
                 ds.n_lit = nlit; ds.n_seq = r.nseq; ds.lit_is_raw = lit_type == 0 || r.lit_in_place(); ds.lit_raw_ptr = (uint64_t)(uintptr_t)(r.lit_in_place() ? r.place() : r.lit);
-                if (TASKS && b.job == 0) atomicMax(&a.counter[1], (t << 12) | (a.wg0 + blockIdx.x)); // the slot that ran the last compressed block of job 0
+                if (TASKS && b.job == 0) atomicMax(&a.counter[1], (t << 12) | (a.wg0 + vblock())); // the slot that ran the last compressed block of job 0
             }
         }
         TFIN(1);
@@ -383,7 +386,7 @@ __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const Bloc
     TSTART();
     if (!b.block_pre) {
         for (uint32_t k = tid; k < b.bsize && k < 256; k += kWG) S.stage[k] = b.blk[k];
-        __syncthreads();
+        grp_sync();
     }
     if (tid == 0) {
         c.huf_ready = 0; c.huf_fill = 0; c.lit_done = 0; c.walk_prog = 0; c.walk_inexact = 0; c.exec_done = 0; c.exec_pos = TASKS ? 0 : b.out0;
@@ -402,13 +405,13 @@ __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const Bloc
             // A block that continues a frame parses its headers before it knows what the frame has inherited (Ctl::huf_valid is
             // provisional): treeless literals without a tree are libzstd's first finding in the section, before its sizes
             if (tid == 0 && g_wait_ge(&b.fs->tables_ver, b.t) && !g_ld(&b.fs->huf_valid)) c.err = MZD_E_DICT;
-            __syncthreads();
+            grp_sync();
         }
         return false;
     }
     if (!b.block_pre) {
         for (uint32_t k = tid; k < seq_len && k < 256; k += kWG) S.stage[256 + k] = b.src[seq_off + k];
-        __syncthreads();
+        grp_sync();
     }
     // The sequence header (three normalized-count descriptions: a serial bit parse) is read by lane 0 of the walking
     // wavefront INSIDE the pipeline, so the literal side (Huffman tree, streams) starts at once.

@@ -202,7 +202,15 @@ __device__ __noinline__ bool resolve_jump_tiled(uint32_t* map, uint32_t B, int t
     // `good` is a wavefront's own finding (its entries' chains): the caller branches on the answer around workgroup barriers, so it
     // must be the same in all four.  (A consistent map always settles; one that does not has been written to from outside.)
     if (!good && (tid & 63) == 0) DEVSITE(15);
-    return __syncthreads_and(good ? 1 : 0) != 0;
+    // (an AND over the workgroup through a word of the image: __syncthreads_and keeps a static LDS object of its own, and the image must
+    //  be the kernel's only one -- it starts at LDS address 0)
+    if (tid == 0) S.and_word = 1u;
+    __syncthreads();
+    if (!good && (tid & 63) == 0) __atomic_store_n(&S.and_word, 0u, __ATOMIC_RELAXED);
+    __syncthreads();
+    const bool all_good = flag_load_u(&S.and_word) != 0;
+    __syncthreads();
+    return all_good;
 }
 
 // Step 2, all 256 threads (workgroup barriers inside).  true: no entry refers to the block any more.

@@ -73,7 +73,7 @@ __device__ __noinline__ int read_ncount_staged(uint32_t stage_off, uint32_t n, i
 // number of extra bits of a code: kind 0 LL, 1 OF, 2 ML
 __device__ __forceinline__ uint32_t code_extra(uint32_t s, int kind) { return kind == 0 ? LL_BITS[s] : (kind == 1 ? s : ML_BITS[s]); }
 // the table's place in S: an entry's low word is the ADDRESS of the next state's base entry (the walker reads with it as it stands)
-__device__ __forceinline__ uint32_t table_lds(int kind) { return kind == 0 ? kLdsLL : (kind == 1 ? kLdsOF : kLdsML); }
+__device__ __forceinline__ uint32_t table_lds(int kind) { return lds_base() + (kind == 0 ? kLdsLL : (kind == 1 ? kLdsOF : kLdsML)); }
 __device__ __forceinline__ uint64_t pack_entry(uint32_t nbase, uint32_t nb, uint32_t s, int kind) {
     uint32_t extra = code_extra(s, kind);
     uint32_t hi = nb | ((extra + nb) << 8) | (s << 16) | (extra << 24);

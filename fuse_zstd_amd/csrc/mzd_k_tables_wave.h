@@ -14,6 +14,7 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, int lane) {
 //   D (lane = symbol)  state numbering in table order: every symbol walks the table once
 // tmp: 2 KiB of LDS scratch (tabsym[512], mark[512], per-symbol masks / counters / extra-bit counts).
 __device__ __noinline__ void build_seq_table_wave(uint64_t* tab, const int16_t* norm, uint32_t nsym, uint32_t log, int kind, uint8_t* tmp, int lane) {
+    MZD_IN_LDS(tab); MZD_IN_LDS(norm); MZD_IN_LDS(tmp);
     uint8_t* const tabsym = tmp;
     uint8_t* const mark = tmp + 512;
     const uint32_t size = 1u << log, mask = size - 1;

@@ -77,12 +77,12 @@ namespace mzd {
 #endif
 #define TCOUNT(k, v) do { if (lane == 0) atomicAdd((unsigned long long*)&S.tfin[k], (unsigned long long)(v)); } while (0)
 #ifdef MZD_EXP_STREAMSTAMP
-#define TFIN_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 12; k_++) a.debug[a.wg0 + blockIdx.x].tfin[k_] = S.tfin[k_]; \
-    for (int k_ = 0; k_ < 4; k_++) a.debug[a.wg0 + blockIdx.x].tfin[k_] = S.sst[k_]; \
-    a.debug[a.wg0 + blockIdx.x].tfin[4] = (S.swv[0] << 32) | (S.swv[1] & 0xFFFFFFFFull); a.debug[a.wg0 + blockIdx.x].tfin[5] = (S.swv[2] << 32) | (S.swv[3] & 0xFFFFFFFFull); \
-    a.debug[a.wg0 + blockIdx.x].tfin[6] = (S.swv[12] << 32) | (S.swv[13] & 0xFFFFFFFFull); a.debug[a.wg0 + blockIdx.x].tfin[7] = (S.swv[14] << 32) | (S.swv[15] & 0xFFFFFFFFull); } } while (0)
+#define TFIN_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 12; k_++) a.debug[a.wg0 + vblock()].tfin[k_] = S.tfin[k_]; \
+    for (int k_ = 0; k_ < 4; k_++) a.debug[a.wg0 + vblock()].tfin[k_] = S.sst[k_]; \
+    a.debug[a.wg0 + vblock()].tfin[4] = (S.swv[0] << 32) | (S.swv[1] & 0xFFFFFFFFull); a.debug[a.wg0 + vblock()].tfin[5] = (S.swv[2] << 32) | (S.swv[3] & 0xFFFFFFFFull); \
+    a.debug[a.wg0 + vblock()].tfin[6] = (S.swv[12] << 32) | (S.swv[13] & 0xFFFFFFFFull); a.debug[a.wg0 + vblock()].tfin[7] = (S.swv[14] << 32) | (S.swv[15] & 0xFFFFFFFFull); } } while (0)
 #else
-#define TFIN_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 12; k_++) a.debug[a.wg0 + blockIdx.x].tfin[k_] = S.tfin[k_]; } } while (0)
+#define TFIN_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 12; k_++) a.debug[a.wg0 + vblock()].tfin[k_] = S.tfin[k_]; } } while (0)
 #endif
 #else
 #define TFIN(k)
@@ -97,7 +97,7 @@ namespace mzd {
 #ifdef MZD_STAMPS
 #define STAMP_DECL uint64_t st_prev = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(k) do { uint64_t t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
-#define STAMP_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 8; k_++) { a.debug[a.wg0 + blockIdx.x].stamp[k_] = st_acc[k_]; a.debug[a.wg0 + blockIdx.x].cstamp[k_] = S.cdiag[k_]; } a.debug[a.wg0 + blockIdx.x].stamp[2] = S.c.diag_slow; } } while (0)
+#define STAMP_FLUSH() do { if (tid == 0 && a.debug) { for (int k_ = 0; k_ < 8; k_++) { a.debug[a.wg0 + vblock()].stamp[k_] = st_acc[k_]; a.debug[a.wg0 + vblock()].cstamp[k_] = S.cdiag[k_]; } a.debug[a.wg0 + vblock()].stamp[2] = S.c.diag_slow; } } while (0)
 #define CSTAMP_DECL uint64_t cs_prev = __builtin_readcyclecounter()
 #ifdef MZD_EXP_WALKSTAT // (the copier's slots show the walker's statistics instead: tools/stamps.py prints them raw)
 #define CSTAMP(k) do { } while (0)
@@ -218,32 +218,48 @@ __device__ __noinline__ bool rep_hop(FileState* fs, uint32_t t, bool frame_first
 #include "mzd_k_pipeline.h"
 
 // The launch's last workgroup to finish zeroes the counter block of the lane's NEXT launch (KernelArgs::counter_next): no
-// memset between launches.  counter[6] counts the workgroups that are done.
+// memset between launches.  counter[6] counts the groups that are done.
 __device__ __forceinline__ void clean_next_counters(const KernelArgs& a, int tid) {
-    if (tid == 0 && a.counter_next && atomicAdd(&a.counter[6], 1u) == gridDim.x - 1)
+    if (tid == 0 && a.counter_next && atomicAdd(&a.counter[6], 1u) == vgrid() - 1)
         for (uint32_t k = 0; k < kCounterWords; k++) a.counter_next[k] = 0;
 }
 
 // ---- driver 1: one workgroup decodes a whole file, block after block.  Used when no file of the launch can have more
 // than one block (every output capacity <= 128 KiB): nothing is forked, nothing is published, the file's state
 // stays in registers and LDS.
-__global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_files(KernelArgs) {
+#if MZD_PAIRS
+#define MZD_FILES_KERNEL mzd_decode_kernel_pairs
+#else
+#define MZD_FILES_KERNEL mzd_decode_kernel_files
+#endif
+__global__ __launch_bounds__(kWG * kGroupsMax, MZD_LB_WAVES) void MZD_FILES_KERNEL(KernelArgs) {
     const KernelArgs& a = launch_args();
-    // A workgroup's first ticket is its own index: one past the queue's end has nothing to do -- the launch behind the small-file
+    // Inside the group (mzd_k_common.h).  `wave` is the wavefront's ROLE.  The hardware puts a workgroup's wavefronts on the four SIMDs in
+    // rotation: with one group a workgroup every SIMD holds one wavefront of each role; with two groups wavefronts w and w + 4 share a SIMD, and
+    // the same role in both would put a CU's four copying wavefronts on ONE SIMD (measured: -22 %).  So a group's roles are rotated by its index,
+    // and by two more in every other workgroup: the four groups of a CU then bring each SIMD one wavefront of each role.
+#ifndef MZD_ROT_BIT
+#define MZD_ROT_BIT 8
+#endif
+    const int rot_ = grp_count() > 1 ? (int)(grp_index() + 2u * ((blockIdx.x >> MZD_ROT_BIT) & 1u)) : 0;
+    const int lane = threadIdx.x & 63, wave = (int)(((threadIdx.x >> 6) + rot_) & 3), tid = wave * 64 + lane;
+    // what the groups of a workgroup share must be in place before either of them moves: the barrier counters and the walkers' rendezvous
+    if (tid == 0) { S.bar = 0; S.wk.active = 0; S.wk.state = 0; }
+    __syncthreads(); // (the workgroup's only hardware barrier: every wavefront of both groups is still here)
+    // A group's first ticket is its own index: one past the queue's end has nothing to do -- the launch behind the small-file
     // kernel when that kernel handed nothing on.  Leaving at once keeps most of the kernel's private-segment stores out of HBM (1 200
     // bytes per lane: the roles' register spills, and a copy per lane of the launch's arguments, whose address the roles take): an idle
     // launch of 256 workgroups wrote 22.5 MB (profiles/r02_cfg4_pmc.json), now 10 (the per-lane argument copy, made on entry).  A body
     // in a function of its own, called behind this test, brings that to 7 MB but costs the headline 3 % (measured): not taken.
-    if (blockIdx.x >= queue_len(a)) { clean_next_counters(a, threadIdx.x); return; }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t slot = a.wg0 + blockIdx.x; // this workgroup's place in the scratch arrays
+    if (vblock() >= queue_len(a)) { clean_next_counters(a, tid); return; }
+    const uint32_t slot = a.wg0 + vblock(); // this group's place in the scratch arrays
     uint8_t* const lit_buf = a.lit_scratch + (size_t)slot * kLitStride;
     uint4* const seqs = a.seq_scratch + (size_t)slot * kSeqStride;
     uint4* const walk = a.walk_scratch + (size_t)slot * kSeqStride;
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
-    if (tid == 0) S.walk_dummy = kLdsWalkDummy; // {own address, no bits}: what the walker's fourth lane follows
+    if (tid == 0) S.walk_dummy = lds_base() + kLdsWalkDummy; // {own address, no bits}: what the walker's fourth lane follows
     if (tid == 0) { c.lds_dict_fse = 0; c.lds_dict_huf = 0; S.pre_job = kNoJob; S.pre_valid = 0; S.dcache.id = 0; S.took_first = 0; }
 
     for (;;) {
@@ -267,7 +283,7 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_files(Ker
         if (pre) { // the prepared control block replaces the current one: by all threads, a dword each (what must survive was read above)
             static_assert(sizeof(Ctl) % 4 == 0, "copied by dwords");
             for (uint32_t k = (uint32_t)tid; k < sizeof(Ctl) / 4; k += kWG) reinterpret_cast<uint32_t*>(&c)[k] = reinterpret_cast<const uint32_t*>(&S.c2)[k];
-            __syncthreads();
+            grp_sync();
         }
         if (tid == 0) {
             if (pre) { c.lds_dict_fse = lf; c.lds_dict_huf = lh; c.job = j; }
@@ -276,7 +292,7 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_files(Ker
 #ifdef MZD_STAMPS
             for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = 0;
 #endif
-            if (j == 0) a.counter[1] = a.wg0 + blockIdx.x;
+            if (j == 0) a.counter[1] = a.wg0 + vblock();
             if (job_dict > a.ndicts) c.err = MZD_E_DICT;
         }
         int err = 0;
@@ -300,16 +316,17 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_files(Ker
                     for (int t_ = 0; t_ < 3; t_++) { S.dcache.al[t_] = dd->al[t_]; S.dcache.rep[t_] = dd->rep[t_]; }
                     S.dcache.id = job_dict;
                 }
-                __syncthreads();
+                grp_sync();
                 if (S.dcache.formatted) {
                     // Config 5 (many small frames, one dictionary): a workgroup keeps the dictionary's tables resident in LDS
                     // from file to file -- such frames use them as they are (repeat-mode tables, treeless literals), so the
                     // 14 KB copy happens once per workgroup, not once per file.  Any block that rebuilds a table clears the mark.
                     const bool have_fse = c.lds_dict_fse == job_dict, have_huf = c.lds_dict_huf == job_dict;
-                    __syncthreads();
-                    if (!have_fse) {
-                        for (int i = tid; i < 512; i += kWG) { S.ll[i] = dd->ll[i]; S.ml[i] = dd->ml[i]; }
-                        for (int i = tid; i < 256; i += kWG) S.of[i] = dd->of[i];
+                    grp_sync();
+                    if (!have_fse) { // (an entry's low word is an LDS address in the image of a workgroup's first group: mzd_device.h)
+                        const uint64_t rb = lds_base();
+                        for (int i = tid; i < 512; i += kWG) { S.ll[i] = dd->ll[i] + rb; S.ml[i] = dd->ml[i] + rb; }
+                        for (int i = tid; i < 256; i += kWG) S.of[i] = dd->of[i] + rb;
                     }
                     if (!have_huf) for (int i = tid; i < (int)kHufEntries; i += kWG) S.huf[i] = dd->huf[i];
                     if (tid == 0) {
@@ -347,11 +364,11 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_files(Ker
                 } else {
                     // (the block's arguments live in LDS: the roles take them by reference, and on the stack they would be a copy per lane)
                     if (tid == 0) { S.ba = BlockArgs{src, n, dst, cap, dst2, src + pos0, bsize, pos0, out0, lit_buf, seqs, walk, last, hashing, block_pre, 0u, false, true, nullptr, nullptr, j, &a}; }
-                    __syncthreads();
+                    grp_sync();
                     if (!compressed_block<false>(a, S.ba, xv, xstripes, mirrored, tid, lane, wave)) { WG_SNAPSHOT(err = c.err); break; } // (an error of the block's headers: the class it posted stands)
                 }
                 if (btype == 2) { // the block's repeat-offset transform (the planner leaves it symbolic) -> the offsets after it
-                    __syncthreads();
+                    grp_sync();
                     if (tid == 0) {
                         RepOp Rf; Rf.s = c.rep_op[0]; Rf.v0 = (int32_t)c.rep_op[1]; Rf.v1 = (int32_t)c.rep_op[2]; Rf.v2 = (int32_t)c.rep_op[3];
                         const uint32_t a0 = c.rep[0], a1 = c.rep[1], a2 = c.rep[2];
@@ -399,11 +416,12 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_files(Ker
         STAMP_FLUSH();
         TTASK_END();
         TFIN_FLUSH();
-        __syncthreads();
+        grp_sync();
     }
     clean_next_counters(a, tid);
 }
 
+#if !MZD_PAIRS
 // ---- driver 2: block tasks (the hand-over helpers are above, in front of the shared block pipeline)
 #ifdef MZD_EXP_DEVSITE // (experiment: the first segment of a task that took more than 50 ms, with its job and task)
 #define DEVSLOW_DECL uint64_t ds_t0_ = wall_clock64()
@@ -415,15 +433,15 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_files(Ker
 __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_tasks(KernelArgs) {
     const KernelArgs& a = launch_args();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t slot = a.wg0 + blockIdx.x; // this workgroup's place in the scratch arrays
+    const uint32_t slot = a.wg0 + vblock(); // this workgroup's place in the scratch arrays
     uint8_t* const lit_buf = a.lit_scratch + (size_t)slot * kLitStride;
     uint4* const seqs = a.seq_scratch + (size_t)slot * kSeqStride;
     uint4* const walk = a.walk_scratch + (size_t)slot * kSeqStride;
     Ctl& c = S.c;
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
-    if (tid == 0) S.walk_dummy = kLdsWalkDummy; // {own address, no bits}: what the walker's fourth lane follows
-    if (tid == 0) S.took_first = 0;
+    if (tid == 0) S.walk_dummy = lds_base() + kLdsWalkDummy; // {own address, no bits}: what the walker's fourth lane follows
+    if (tid == 0) { S.took_first = 0; S.bar = 0; S.wk.active = 0; S.wk.state = 0; }
 
     for (;;) {
         // ---------------- take a task: tickets below njobs are the first blocks of the files, the others the pushed
@@ -705,7 +723,7 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_tasks(Ker
                         __syncthreads();
                         if (tid == 0) { c.out = out0 + B; c.pos = pos0 + bsize; }
                         if (a.debug && tid == 0) {
-                            DebugSlot& ds = a.debug[a.wg0 + blockIdx.x];
+                            DebugSlot& ds = a.debug[a.wg0 + vblock()];
                             ds.n_lit = nlit; ds.n_seq = nseq; ds.lit_is_raw = lit_type == 0; ds.lit_raw_ptr = (uint64_t)(uintptr_t)(lit_type == 0 ? src + lit_off : lit_buf);
                             if (j == 0) atomicMax(&a.counter[1], (t << 12) | (a.wg0 + blockIdx.x));
                         }
@@ -831,7 +849,7 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_tasks(Ker
 __global__ __launch_bounds__(kWG) void mzd_dict_kernel(const uint8_t* dict, uint32_t n, DevDict* out, int32_t* status) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Ctl& c = S.c;
-    __shared__ uint32_t pos_after_huf, pos_after_tables;
+    uint32_t& pos_after_huf = S.res[0]; uint32_t& pos_after_tables = S.res[1]; // (no static LDS object: the image starts at LDS address 0, and the entries built here name its addresses)
     if (tid == 0) {
         c.err = 0; c.action = 0;
         if (n < 8 || ld32(dict) != 0xEC30A437u) c.action = 1; // raw content
@@ -900,12 +918,33 @@ void* decode_kernel_ptr(int tasks) { return tasks ? (void*)mzd_decode_kernel_tas
 #ifdef MZD_EXP_DEVSITE
 void devsite_take(uint32_t* out3) { uint32_t z[4] = {0, 0, 0, 0}; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_devsite), 12); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_devsite), z, 16); }
 #endif
+// grid: GROUPS (mzd_k_common.h); groups_per_wg: 1, or 2 for driver 1 (two files a workgroup, one walking wavefront for both)
+#endif // !MZD_PAIRS
+
+#ifdef MZD_EXP_PLANDIAG
+#if MZD_PAIRS
+#define MZD_PLANDIAG_TAKE plandiag_take_pairs
+#else
+#define MZD_PLANDIAG_TAKE plandiag_take
+#endif
+void MZD_PLANDIAG_TAKE(uint32_t* out16) { uint32_t z[16] = {0}; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_plandiag), 64); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_plandiag), z, 64); }
+#endif
+#if MZD_PAIRS
+// grid: GROUPS of four wavefronts (an even number: the host rounds); two a workgroup
+void launch_decode_pairs(const KernelArgs& a, uint32_t grid, void* stream) {
+    hipLaunchKernelGGL(mzd_decode_kernel_pairs, dim3((grid + 1) / 2), dim3(2 * kWG), 2 * sizeof(Shared), (hipStream_t)stream, a);
+}
+// once per device: two images are more dynamic LDS than a kernel may ask for by default
+int pairs_prepare_device() {
+    return hipFuncSetAttribute((const void*)mzd_decode_kernel_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGroupsMax * sizeof(Shared))) == hipSuccess ? 0 : MZD_E_DEVICE;
+}
+#else
 void launch_decode(const KernelArgs& a, uint32_t grid, void* stream) {
     if (a.use_tasks) hipLaunchKernelGGL(mzd_decode_kernel_tasks, dim3(grid), dim3(kWG), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(mzd_decode_kernel_files, dim3(grid), dim3(kWG), 0, (hipStream_t)stream, a);
 }
-
 int kernel_lds_bytes() { return (int)sizeof(Shared); }
+#endif
 
 } // namespace mzd
 

@@ -171,7 +171,10 @@ int mzd_debug_counters(int device, uint32_t* out8);
  * memory (default 4).  what 3: `value` host threads for the staging copies of pageable buffers (default 8).  what 4 / 5: the small-file
  * kernel's files per wavefront / files executed at a time (0: the library's choice).  what 6: its grid.  what 7: a timing trace of
  * mzd_decode_batch on stderr.  what 8: a launch of small files alone keeps the general driver's launch behind it (A/B).  what 9: the small-file kernel's wavefronts
- * per workgroup (0: the library's choice, 1: never a helper wavefront, 2: with the 8 / 4 shape always). */
+ * per workgroup (0: the library's choice, 1: never a helper wavefront, 2: with the 8 / 4 shape always).  what 10: how block tasks execute a
+ * file's blocks (0: the library's choice, 1 in order, 2 every task resolved ahead, 3 only behind a running predecessor, 4 every other task).
+ * what 11: driver 1's workgroups (0 / 1: one file each; 2: two files each, their sequence chains walked by ONE wavefront --
+ * mzd_decode_kernel_pairs, built and measured in round 6, never chosen by the library: it is slower). */
 int mzd_debug_host_path(int device, int what, int value);
 /* Diagnostic builds only (make diag / tfin): per-phase cycle sums of the workgroup that ran job 0; role finish times of
  * every workgroup slot.  In the product build they return zeros. */

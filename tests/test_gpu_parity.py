@@ -22,8 +22,9 @@ def gpu():
     mzd.shutdown()
 
 
-DRIVERS = ["auto", "1", "4", "5"]  # auto (mode 3): small files take the small-file kernel however few they are, the rest (and what it hands on) a general driver;
-                                    # 4 / 5: block tasks with / without blocks resolved ahead of their predecessors (mzd_k_resolve.h)
+DRIVERS = ["auto", "1", "1p", "4", "5"]  # auto (mode 3): small files take the small-file kernel however few they are, the rest (and what it hands on) a general driver;
+                                          # 1p: a workgroup per file with TWO files a workgroup -- one walking wavefront for both (mzd_debug_host_path 11 = 2);
+                                          # 4 / 5: block tasks with / without blocks resolved ahead of their predecessors (mzd_k_resolve.h)
 
 
 @pytest.fixture
@@ -32,6 +33,9 @@ def force_driver():
     kernel's shape (G files per wavefront through the entropy phases, XG of them executed at a time: mzd_debug_host_path 4 / 5)."""
     def set_(driver):
         parts = driver.split(":")
+        if parts[0] == "1p":
+            parts[0] = "1"
+            mzd.lib().mzd_debug_host_path(0, 11, 2)
         mzd.set_driver(3 if parts[0] == "auto" else int(parts[0]))
         if len(parts) >= 3:
             mzd.lib().mzd_debug_host_path(0, 4, int(parts[1]))
@@ -40,6 +44,7 @@ def force_driver():
             mzd.lib().mzd_debug_host_path(0, 9, int(parts[3]))
     yield set_
     mzd.set_driver(0)
+    mzd.lib().mzd_debug_host_path(0, 11, 0)
     mzd.lib().mzd_debug_host_path(0, 4, 0)
     mzd.lib().mzd_debug_host_path(0, 5, 0)
     mzd.lib().mzd_debug_host_path(0, 9, 0)
