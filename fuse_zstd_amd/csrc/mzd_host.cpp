@@ -54,7 +54,7 @@ constexpr uint32_t kMaxDicts = 64;
 constexpr size_t kMaxChunks = 16;               // ... and at most this many chunks per call
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
-std::atomic<int> g_small_g{0}, g_small_xg{0}, g_small_nw{0}, g_trace_t2{0}, g_keep_behind{0}, g_resolve{0}, g_pairs{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
+std::atomic<int> g_small_g{0}, g_small_xg{0}, g_small_nw{0}, g_trace_t2{0}, g_keep_behind{0}, g_resolve{0}, g_pairs{0}, g_small_nd{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
 std::atomic<unsigned> g_small_grid{0};               // mzd_debug_host_path 6: its grid (0: as many wavefronts as the device holds)
 constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 1280u; // (a workgroup's LDS is allocated in steps of 320 dwords: tools/micro/lds_granule_micro.hip -- five workgroups of 32 000 bytes share a CU, five of 32 640 do not, and the occupancy API says they do)
 std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic with the
@@ -413,6 +413,7 @@ Plan make_plan(const DevJob* jobs, size_t njobs, uint32_t* lists, uint32_t max_w
                 };
                 uint32_t best = files_per_cu(1);
                 for (int nd : {5, 8}) { const uint32_t fc = files_per_cu(nd); if (fc > best) { best = fc; p.lds_nd = nd; } }
+                if (const int fnd = g_small_nd.load(std::memory_order_relaxed); (fnd == 1 || fnd == 5 || fnd == 8) && (fnd == 1 || files_per_cu(fnd))) { p.lds_nd = fnd; p.lds_g = 8; p.lds_xg = 8; } // (mzd_debug_host_path 12: the tests' way to these shapes)
             }
             const int dbg_g = g_small_g.load(std::memory_order_relaxed), dbg_xg = g_small_xg.load(std::memory_order_relaxed); // (mzd_debug_host_path 4 / 5)
             if (dbg_g == 4 || dbg_g == 8 || dbg_g == 16) {
@@ -1084,6 +1085,7 @@ int mzd_debug_host_path(int device, int what, int value) {
     if (what == 7) { g_trace_t2.store(value); return MZD_OK; }
     if (what == 8) { g_keep_behind.store(value); return MZD_OK; }
     if (what == 9) { g_small_nw.store(value); return MZD_OK; }
+    if (what == 12) { g_small_nd.store(value); return MZD_OK; } // the dictionary kernels' decoding wavefronts around one table image (launches that name ONE dictionary): 0 the library's choice, 1 / 5 / 8
     if (what == 11) { g_pairs.store(value); return MZD_OK; } // driver 1's workgroups: 0 the library's choice, 1 one file each, 2 two files each (one walking wavefront for both)
     if (what == 10) { g_resolve.store(value); return MZD_OK; } // (the small-file kernel's wavefronts per workgroup: 0 the library's choice, 1 never a helper wavefront, 2 with the 8 / 4 shape always) // (the general driver's launch behind a launch of small files alone stays: A/B)
     return MZD_E_PARAM;
@@ -1214,7 +1216,8 @@ int mzd_batch_prepare(int device, const mzd_job* jobs, size_t njobs, mzd_batch**
     for (size_t i = 0; i < njobs; i++) fill_devjob(b->h_jobs[i], jobs[i].src, jobs[i].src_len, jobs[i].dst, jobs[i].dst_cap, jobs[i].dict_id, *d);
     b->plan = make_plan(b->h_jobs, njobs, lists.data(), d->max_wg, d->cus);
     if (hipMemcpy(b->d_jobs, b->h_jobs, njobs * sizeof(DevJob), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(b->d_lists, lists.data(), njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(b->d_lists, lists.data(), njobs * 2 * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(b->d_lists + njobs * 2, 0, 4 * sizeof(uint32_t)) != hipSuccess) { // (the word a launch of small files alone leaves its hand-on count in: never read uninitialised)
         hipFree(b->d_jobs); hipFree(b->d_lists); hipHostFree(b->h_jobs); delete b; return MZD_E_DEVICE;
     }
     *out = b;
@@ -1229,10 +1232,11 @@ int mzd_batch_launch_ex(mzd_batch* b, void* stream, unsigned flags) {
     HIPCHK(hipSetDevice(d.hip_id));
     WholeGuard g(d); // (launches of one batch follow each other on `stream`; host-path launches wait for their end event)
     d.whole_used.store(true, std::memory_order_relaxed);
-    b->solo = b->plan.nsmall && b->plan.nbig == 0 && !g_keep_behind.load(std::memory_order_relaxed);
+    const bool solo = b->plan.nsmall && b->plan.nbig == 0 && !g_keep_behind.load(std::memory_order_relaxed);
     // (untimed: the start event is left out -- one packet less between two launches of a measurement loop; the end event stays, it is
     //  what host-path launches wait for when a device-path launch may still be running on a caller's stream)
-    const int rc = enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists, (flags & MZD_LAUNCH_UNTIMED) ? nullptr : d.whole.ev0, d.whole.ev1, b->solo ? b->d_lists + 2 * b->njobs : nullptr);
+    const int rc = enqueue(d, d.whole, stream ? (hipStream_t)stream : d.whole.stream, b->d_jobs, b->plan, b->d_lists, (flags & MZD_LAUNCH_UNTIMED) ? nullptr : d.whole.ev0, d.whole.ev1, solo ? b->d_lists + 2 * b->njobs : nullptr);
+    b->solo = solo && rc == MZD_OK; // (a launch that failed left no count behind: collect must not go looking for one)
     b->timed = (flags & MZD_LAUNCH_UNTIMED) == 0;
     d.job0_counter = d.whole.counter; d.job0_snap_valid = false;
     return rc;
@@ -1256,10 +1260,15 @@ int mzd_batch_collect(mzd_batch* b, mzd_job* jobs, void* stream) {
     if (b->solo && handed) { // (the launch ended with the small-file kernel: the files it handed on take the general driver now)
         if (handed > b->njobs) return MZD_E_DEVICE;
         WholeGuard g(d);
+        HIPCHK(hipEventRecord(d.whole.ev0, s));
         const int rc = redo_handed_on(d, d.whole, s, b->d_jobs, (uint32_t)b->njobs, b->d_lists, handed);
         if (rc) { hipStreamSynchronize(s); return rc; }
+        HIPCHK(hipEventRecord(d.whole.ev1, s));
         HIPCHK(hipMemcpyAsync(b->h_jobs, b->d_jobs, b->njobs * sizeof(DevJob), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        float redo_ms = 0; // (what was handed on is part of the batch's decode: its launch counts, as in run_device_jobs)
+        HIPCHK(hipEventElapsedTime(&redo_ms, d.whole.ev0, d.whole.ev1));
+        d.last_ms += redo_ms;
     }
     if (jobs)
         for (size_t i = 0; i < b->njobs; i++) { jobs[i].out_len = (size_t)b->h_jobs[i].out_len; jobs[i].status = b->h_jobs[i].status; jobs[i].device = d.index; }

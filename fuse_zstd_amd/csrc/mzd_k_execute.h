@@ -176,15 +176,9 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         return (pg & ~kWalkFin) >= need;
     };
     struct Win { uint32_t hL, hM, hO, G; uint64_t bO, bM, bL; }; // entry words + raw 8-byte windows of one sequence
-    // records are 8 bytes (walk_record): three 16-bit state addresses and the low 16 bits of (read head - 32).  A chunk's positions are
-    // unwrapped against its first record's, and that one against the chunk before (64 sequences consume < 2^16 bits)
+    // records are 8 bytes (walk_record): three 16-bit state addresses (absolute in LDS) and 16 bits nobody reads
     const uint2* const recs = reinterpret_cast<const uint2*>((uintptr_t)u64_((uint64_t)(uintptr_t)cx.walk));
     auto load_rec = [&](uint32_t idx) -> uint2 { uint2 r = make_uint2(0, 0); if (idx < nseq) __builtin_memcpy(&r, (gcptr)(recs + idx), 8); return r; };
-    auto unwrap = [&](uint2 w, uint32_t first_full) -> uint32_t { // full (read head - 32) of a record of the chunk whose first record is at first_full
-        const uint32_t first16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w.y >> 16));
-        return first_full - ((first16 - (w.y >> 16)) & 0xFFFFu);
-    };
-#if MZD_REC_NOPOS
     // The records carry the three states only.  Where a sequence's fields lie follows from the states themselves: a sequence consumes
     // extra + nbBits of each of its three entries (byte 1 of their high words; < 128 bits together), so a chunk's read heads are its
     // first one minus an exclusive scan of those sums -- a DPP scan a chunk here instead of a select and a fourth lane's store per
@@ -196,13 +190,6 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint32_t incl_ = wave_incl_scan(tot_, lane);
         o.G = first_full - (incl_ - tot_) + 32; // (first_full: the chunk's first read head - 32)
         const uint32_t chunk_bits = __builtin_amdgcn_readlane(incl_, 63);
-#else
-    auto issue_bits = [&](uint2 w2, uint32_t first_full, bool live, Win& o) -> uint32_t {
-        const uint32_t vL = w2.x & 0xFFFFu, vM = w2.x >> 16, vO = w2.y & 0xFFFFu;
-        o.G = unwrap(w2, first_full) + 32; // records carry the read head - 32
-        o.hL = (uint32_t)(lds_entry(vL) >> 32); o.hM = (uint32_t)(lds_entry(vM) >> 32); o.hO = (uint32_t)(lds_entry(vO) >> 32); // (records hold state addresses)
-        const uint32_t chunk_bits = 0;
-#endif
         o.bO = 0; o.bM = 0; o.bL = 0;
 #ifdef MZD_EXP_PLANDIAG
         if (live && !(o.G <= g_hi && o.G >= bias * 8) && atomicCAS(&g_plandiag[0], 0u, 1u) == 0u) {
@@ -224,13 +211,8 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
     if (!wait_walker(128)) return MZD_E_CORRUPT;
     uint2 recA = load_rec((uint32_t)lane), recB = load_rec(64 + (uint32_t)lane); // chunks 0 and 1
     uint32_t gfirst = flag_load_u(&S.c.walk_g0); // full position of the current chunk's first record ...
-    auto next_first = [&](uint2 cur, uint2 nxt, uint32_t cur_full) -> uint32_t { // ... and of the next chunk's (lane 0 of each)
-        const uint32_t a16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur.y >> 16)), b16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nxt.y >> 16));
-        return cur_full - ((a16 - b16) & 0xFFFFu);
-    };
     Win win;
-    uint32_t bits_cur = issue_bits(recA, gfirst, (uint32_t)lane < nseq, win); // (MZD_REC_NOPOS: bits the current chunk consumes)
-    (void)bits_cur;
+    uint32_t bits_cur = issue_bits(recA, gfirst, (uint32_t)lane < nseq, win); // (bits the current chunk consumes)
     uint32_t chunk = 0;
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
@@ -244,13 +226,8 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         if (!wait_walker(base + 192)) return MZD_E_CORRUPT; // the walker failed (it posted the error) or never got there
         const uint2 recC = load_rec(base + 128 + (uint32_t)lane);
         Win next;
-#if MZD_REC_NOPOS
         const uint32_t gnext = gfirst - bits_cur;
         bits_cur = issue_bits(recB, gnext, base + 64 + (uint32_t)lane < nseq, next);
-#else
-        const uint32_t gnext = base + 64 < nseq ? next_first(recA, recB, gfirst) : gfirst;
-        issue_bits(recB, gnext, base + 64 + (uint32_t)lane < nseq, next);
-#endif
         // stage 2: fields of chunk k from the windows issued an iteration ago
         uint32_t ll = 0, ml = 0, ofv = 4;
         if (valid) {

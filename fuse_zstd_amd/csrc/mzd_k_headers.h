@@ -199,8 +199,12 @@ __device__ __forceinline__ uint32_t take_ticket(const KernelArgs& a) { // thread
     return vgrid() + atomicAdd(&a.counter[0], 1u);
 }
 __device__ __forceinline__ uint32_t take_job(const KernelArgs& a) { // thread 0
-    const uint32_t t = take_ticket(a);
-    return t < queue_len(a) ? queue_job(a, t) : kDoneJob;
+    for (;;) {
+        const uint32_t t = take_ticket(a);
+        if (t >= queue_len(a)) return kDoneJob;
+        const uint32_t j = queue_job(a, t);
+        if (j < a.njobs) return j; // (a list entry that names no job of the launch is skipped, never decoded: the list is the host's or the small-file kernel's)
+    }
 }
 
 // Driver 1, by the walking wavefront once its own work on a file's last block is done: take the next file and parse

@@ -93,14 +93,13 @@ constexpr uint32_t kInRing = 0x80000000u;   // parse_seq_header: the staged head
 // 64-bit shift, the field, the address = 8 VALU slots (the one-lane form: 12 + three reads).  Everything the chain does not need --
 // the read head, the next window's address and read, the record store, publishing progress -- sits behind the read, in the shadow
 // of its latency; the window is waited for separately, right before the shift (it was issued last and is needed later).
-// Same arithmetic as the careful C++ step.  The record of a step is the state as it stands: lane k of quad 0 stores dword k
-// {LL, ML, OF state address, read head - 32}.  Progress (records visible to the planner: all but the newest kWalkLag stores have
+// Same arithmetic as the careful C++ step.  The record of a step is the state as it stands: lane k of the quad stores 16 bits, its state's
+// address (LL, ML, OF; the fourth lane's are nothing anybody reads).  Progress (records visible to the planner: all but the newest kWalkLag stores have
 // landed) is published once per group.  Registers: v[48:49] the lane's entry, v[54:55] the window, v[64:71] temporaries, v84 the
-// lane's state address, v87 the read head - 32.  Entries hold ABSOLUTE LDS addresses (pack_entry) and the ring's address is an
-// immediate: S must start at LDS address 0 (checked by the caller, which otherwise keeps the C++ form).
+// lane's state address, v87 the read head - 32.  Entries hold ABSOLUTE LDS addresses (pack_entry); the ring's address is a per-lane operand.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// walk record, 8 bytes: LL, ML, OF state addresses (LDS: < 2^16) and the low 16 bits of (read head - 32) -- a sequence consumes < 128 bits, so the
-// planner, which knows where the walk started (Ctl::walk_g0), unwraps the positions chunk by chunk (plan_wave)
+// walk record, 8 bytes: LL, ML, OF state addresses (LDS: < 2^16) and 16 spare bits -- the planner, which knows where the walk started
+// (Ctl::walk_g0), works a chunk's positions out of the states themselves (plan_wave)
 __device__ __forceinline__ uint64_t walk_record(uint32_t vL, uint32_t vM, uint32_t vO, uint32_t gm) { return (uint64_t)(vL | (vM << 16)) | ((uint64_t)(vO | (gm << 16)) << 32); }
 constexpr uint32_t kWalkGroup = 8;
 #ifndef MZD_WALK_RUN
@@ -116,7 +115,6 @@ constexpr uint32_t kWalkYield = MZD_WALK_YIELD;
 #define MZD_DPP_ALL " row_mask:0xf bank_mask:0xf\n"
 // the record: lane k of a quad stores 16 bits -- the three state addresses (the fourth lane's are nothing anybody reads: the planner works the
 // positions out of the states, plan_wave)
-#define MZD_REC_NOPOS 1
 #define MZD_WALK_REC(RECOFF) "global_store_short %[woff], v84, %[base] offset:" RECOFF "\n"
 #define MZD_WALK_STEP(SH, RECOFF, TAIL) \
     "s_waitcnt lgkmcnt(1)\n"                                             /* the entry is there (the window may still be on its way) */ \

@@ -450,7 +450,8 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_tasks(Ker
             c.t_valid = 0;
             const uint32_t ticket = take_ticket(a);
             const uint32_t nq = queue_len(a);
-            if (ticket < nq) { c.job = queue_job(a, ticket); c.task = 0; c.pos = 0; c.in_frame = 0; c.with_dict = 0; c.t_valid = 1; }
+            if (ticket < nq && queue_job(a, ticket) >= a.njobs) atomicAdd(&a.counter[3], 1u); // (a list entry that names no job of the launch: counted as finished, never decoded)
+            else if (ticket < nq) { c.job = queue_job(a, ticket); c.task = 0; c.pos = 0; c.in_frame = 0; c.with_dict = 0; c.t_valid = 1; }
             else {
                 const uint32_t m = ticket - nq;
                 const ContRecord* r = &a.ring[m % a.ring_cap];

@@ -174,7 +174,8 @@ int mzd_debug_counters(int device, uint32_t* out8);
  * per workgroup (0: the library's choice, 1: never a helper wavefront, 2: with the 8 / 4 shape always).  what 10: how block tasks execute a
  * file's blocks (0: the library's choice, 1 in order, 2 every task resolved ahead, 3 only behind a running predecessor, 4 every other task).
  * what 11: driver 1's workgroups (0 / 1: one file each; 2: two files each, their sequence chains walked by ONE wavefront --
- * mzd_decode_kernel_pairs, built and measured in round 6, never chosen by the library: it is slower). */
+ * mzd_decode_kernel_pairs, built and measured in round 6, never chosen by the library: it is slower).  what 12: decoding wavefronts around ONE
+ * dictionary table image in the small-file kernel, for launches whose files all name the same dictionary (0: the library's choice, 1 / 5 / 8). */
 int mzd_debug_host_path(int device, int what, int value);
 /* Diagnostic builds only (make diag / tfin): per-phase cycle sums of the workgroup that ran job 0; role finish times of
  * every workgroup slot.  In the product build they return zeros. */

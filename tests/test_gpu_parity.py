@@ -384,6 +384,63 @@ def test_mutated_dictionary_frames_and_multi_frame_files_match_oracle():
 
 
 @needs_zstd
+@pytest.mark.parametrize("nd", [1, 5, 8])
+def test_mutated_records_of_one_dictionary_under_every_shape_of_the_dictionary_kernels(nd):
+    """Config 5's kernels keep one dictionary table image for ND decoding wavefronts of a workgroup (ND = 5 or 8; the library picks them only
+    for launches whose files ALL name the same dictionary, so the mixed batch above runs ND = 1).  Here every job names the dictionary: valid
+    records, records with one to three mutated bytes, truncated ones -- what is corrupt is handed on to the general driver from inside a
+    workgroup whose other wavefronts go on decoding around the same image -- under each forced ND (mzd_debug_host_path 12), status and bytes
+    against the oracle."""
+    rng = np.random.RandomState(17)
+    sizes = [int(x) for x in np.random.RandomState(56).randint(300, 3001, size=400)]
+    d = corpus.train_dict("json", 6, sizes[:200], cap=40000)
+    h = mzd.load_dict(d)
+    cp = corpus.build_corpus("json", 6, sizes, dictionary=d)
+    cases = []
+    for i in range(400):
+        good = cp.comp_file(i).tobytes()
+        cases.append((good, sizes[i]))
+        for _ in range(3):
+            b = bytearray(good)
+            for _ in range(int(rng.randint(1, 4))):
+                b[int(rng.randint(0, len(b)))] ^= int(rng.randint(1, 256))
+            cases.append((bytes(b), sizes[i]))
+        cases.append((good[:int(rng.randint(0, len(good)))], sizes[i]))
+        cases.append((good, max(0, sizes[i] - int(rng.randint(1, 40)))))  # (a destination that is too small)
+    # device-resident (one launch on the whole device: the kernel's name is the library's record of what it ran)
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    offs = np.zeros(len(cases) + 1, dtype=np.int64); ooffs = np.zeros(len(cases) + 1, dtype=np.int64)
+    for i, (c, cap) in enumerate(cases):
+        offs[i + 1] = offs[i] + ((len(c) + 64 + 15) & ~15); ooffs[i + 1] = ooffs[i] + ((cap + 64 + 15) & ~15)
+    img = np.zeros(int(offs[-1]) + 64, dtype=np.uint8)
+    for i, (c, _) in enumerate(cases):
+        img[int(offs[i]):int(offs[i]) + len(c)] = np.frombuffer(c, dtype=np.uint8)
+    comp = torch.from_numpy(img).to(dev)
+    out = torch.zeros(int(ooffs[-1]) + 64, dtype=torch.uint8, device=dev)
+    jobs = mzd.api.make_jobs([comp.data_ptr() + int(o) for o in offs[:-1]], [len(c) for c, _ in cases], [out.data_ptr() + int(o) for o in ooffs[:-1]], [cap for _, cap in cases], [h] * len(cases))
+    torch.cuda.synchronize()
+    mzd.set_driver(3)
+    mzd.lib().mzd_debug_host_path(0, 12, nd)
+    try:
+        res = mzd.decode_batch_device(0, jobs)
+        name = mzd.last_kernel_name(0)
+    finally:
+        mzd.lib().mzd_debug_host_path(0, 12, 0)
+        mzd.set_driver(0)
+        mzd.unload_dict(h)
+    if nd > 1:
+        assert ",%d>" % nd in name.replace(" ", ""), name  # (mzd_lds_kernel<8,true,8,1,ND>)
+    host = out.cpu().numpy()
+    bad = []
+    for i, ((c, cap), (st, n)) in enumerate(zip(cases, res)):
+        rc, want = oracle.decode(c, cap=cap, dictionary=d)
+        if st != rc or (st == 0 and host[int(ooffs[i]):int(ooffs[i]) + n].tobytes() != want):
+            bad.append((i, st, rc))
+    assert not bad, (nd, len(bad), bad[:10])
+
+
+@needs_zstd
 def test_random_mutations_of_128k_frames_match_oracle():
     """Single-block frames of the config-2 size (thousands of sequences: the state walk runs through many ring refills,
     the planner and the copier follow it through HBM queues), 400 random single-byte mutations each.  A corrupt
