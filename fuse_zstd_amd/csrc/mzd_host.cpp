@@ -54,7 +54,7 @@ constexpr uint32_t kMaxDicts = 64;
 constexpr size_t kMaxChunks = 16;               // ... and at most this many chunks per call
 constexpr size_t kChunkBytes = 24u << 20;       // host path: input + output bytes per pipeline chunk
 
-std::atomic<int> g_small_g{0}, g_small_xg{0}, g_small_nw{0}, g_trace_t2{0}, g_keep_behind{0}, g_resolve{0}, g_pairs{0}, g_small_nd{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
+std::atomic<int> g_small_g{0}, g_small_xg{0}, g_small_nw{0}, g_trace_t2{0}, g_keep_behind{0}, g_resolve{0}, g_pairs{0}, g_small_nd{0}, g_t2_mode{0}; // mzd_debug_host_path 4 / 5 / 7: the small-file kernel's files per wavefront / executed at a time; the host path's timing trace
 std::atomic<unsigned> g_small_grid{0};               // mzd_debug_host_path 6: its grid (0: as many wavefronts as the device holds)
 constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 1280u; // (a workgroup's LDS is allocated in steps of 320 dwords: tools/micro/lds_granule_micro.hip -- five workgroups of 32 000 bytes share a CU, five of 32 640 do not, and the occupancy API says they do)
 std::atomic<int> g_force_driver{0}; // mzd_debug_set_driver: 0 automatic, 1 / 2 that general driver only (no small-file kernel), 3 automatic with the
@@ -123,6 +123,7 @@ struct Device {
     uint32_t job0_snap[kCounterWords] = {}; // ... as it stood when a launch of small files alone was collected (the launch of what it handed on
     bool job0_snap_valid = false;          //     cleans that block): what mzd_debug_counters reports then
     std::atomic<bool> whole_used{false};   // a whole-device launch may still be running on a caller's stream: lanes wait for its end event
+    std::mutex t2_submit_mu; // (mzd_debug_host_path 13)
     // resources: lanes and stagings are handed out under `mu`
     std::mutex mu;
     std::condition_variable cv;
@@ -897,6 +898,9 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         if (e == hipSuccess && any_small) e = hipMemcpyAsync(st->d_lists, st->h_lists, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, d.copy_in);
         if (e != hipSuccess) result = MZD_E_DEVICE;
     }
+    const int t2_mode = g_t2_mode.load(std::memory_order_relaxed);
+    std::unique_lock<std::mutex> submit_all(d.t2_submit_mu, std::defer_lock);
+    if (t2_mode & 1) submit_all.lock();
     for (size_t c = 0; c < nchunks && result == MZD_OK; c++) {
         const size_t c0 = cut[c], c1 = cut[c + 1];
         Chunk& k = ch[c];
@@ -960,12 +964,17 @@ int run_host_jobs(Device& d, mzd_job* jobs, const std::vector<size_t>& idx) {
         for (size_t c = 0; c < submitted; c++) hipStreamSynchronize(ch[c].lane == kWholeLane ? d.whole.stream : d.lane[ch[c].lane].stream);
         hipStreamSynchronize(d.copy_out);
     }
+    if (submit_all.owns_lock()) submit_all.unlock();
     mark("all chunks submitted");
     float ms_sum = 0.f;
     for (size_t c = 0; c < nchunks; c++) { // retire in order: wait, hand bytes and results to the caller
         Chunk& k = ch[c];
         if (c < submitted && result == MZD_OK) {
-            if (hipEventSynchronize(k.done) != hipSuccess) result = MZD_E_DEVICE;
+            if (t2_mode & 2) {
+                hipError_t q;
+                while ((q = hipEventQuery(k.done)) == hipErrorNotReady) std::this_thread::yield();
+                if (q != hipSuccess) result = MZD_E_DEVICE;
+            } else if (hipEventSynchronize(k.done) != hipSuccess) result = MZD_E_DEVICE;
             float ms = 0.f;
             if (result == MZD_OK && hipEventElapsedTime(&ms, k.k0, k.k1) == hipSuccess) ms_sum += ms;
         }
@@ -1085,6 +1094,7 @@ int mzd_debug_host_path(int device, int what, int value) {
     if (what == 7) { g_trace_t2.store(value); return MZD_OK; }
     if (what == 8) { g_keep_behind.store(value); return MZD_OK; }
     if (what == 9) { g_small_nw.store(value); return MZD_OK; }
+    if (what == 13) { g_t2_mode.store(value); return MZD_OK; } // host path experiments: bit 0 one call at a time inside the submission loop, bit 1 retire by polling hipEventQuery
     if (what == 12) { g_small_nd.store(value); return MZD_OK; } // the dictionary kernels' decoding wavefronts around one table image (launches that name ONE dictionary): 0 the library's choice, 1 / 5 / 8
     if (what == 11) { g_pairs.store(value); return MZD_OK; } // driver 1's workgroups: 0 the library's choice, 1 one file each, 2 two files each (one walking wavefront for both)
     if (what == 10) { g_resolve.store(value); return MZD_OK; } // (the small-file kernel's wavefronts per workgroup: 0 the library's choice, 1 never a helper wavefront, 2 with the 8 / 4 shape always) // (the general driver's launch behind a launch of small files alone stays: A/B)

@@ -17,6 +17,7 @@ end = int(cp.raw_offs[-1] + cp.raw_sizes[-1])
 hin = mzd.HostBuffer(len(cp.comp)); hin.a[:] = cp.comp
 outs = [mzd.HostBuffer(end + 64) for _ in range(nth)]
 L = api.lib()
+if os.environ.get("MZD_T2_MODE"): L.mzd_debug_host_path(0, 13, int(os.environ["MZD_T2_MODE"]))
 jobs = [api.make_jobs([hin.a.ctypes.data + int(o) for o in cp.comp_offs], cp.comp_sizes, [o.a.ctypes.data + int(x) for x in cp.raw_offs], cp.raw_sizes) for o in outs]
 L.mzd_decode_batch(jobs[0], n)
 times = [[] for _ in range(nth)]
