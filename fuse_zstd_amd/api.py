@@ -49,7 +49,7 @@ def build(force=False):
             fcntl.flock(lk, fcntl.LOCK_EX)
             try:
                 if stale():
-                    subprocess.check_call(["make", "-C", src_dir, "-s", "-j4"])
+                    subprocess.check_call(["make", "-C", src_dir, "-s", "-j5"])
             finally:
                 fcntl.flock(lk, fcntl.LOCK_UN)
     return _SO

@@ -5,7 +5,11 @@
 
 namespace mzd {
 
+#if defined(MZD_W3) && MZD_W3
+constexpr int kWG = 192;                     // the MZD_W3 build of driver 1: workgroups of three wavefronts (mzd_k_common.h)
+#else
 constexpr int kWG = 256;                     // threads per workgroup = 4 wavefronts of 64
+#endif
 constexpr uint32_t kBlockMax = 128u * 1024u; // Block_Maximum_Size upper bound (RFC 8878 3.1.1.2.4)
 constexpr uint32_t kMaxSeq = 43691u;         // a block regenerates <= 128 KiB and every match is >= 3 bytes
 constexpr uint32_t kLitStride = kBlockMax + 64;
@@ -184,6 +188,9 @@ void launch_decode(const KernelArgs& a, uint32_t grid, void* stream);
 // driver 1 with two files a workgroup (mzd_kernels.hip compiled with MZD_PAIRS = 1: mzd_decode_kernel_pairs); grid counts GROUPS of four wavefronts
 void launch_decode_pairs(const KernelArgs& a, uint32_t grid, void* stream);
 int pairs_prepare_device();
+// driver 1 with workgroups of three wavefronts, five to a CU (mzd_kernels.hip compiled with MZD_W3 = 1: mzd_decode_kernel_files3)
+void launch_decode_w3(const KernelArgs& a, uint32_t grid, void* stream);
+int w3_workgroups_per_cu();
 int kernel_lds_bytes();
 
 } // namespace mzd

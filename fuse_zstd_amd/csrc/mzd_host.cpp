@@ -70,6 +70,7 @@ struct Lane {
     uint32_t* cnt[2] = {nullptr, nullptr}; // the lane's two blocks alternate: a launch's last workgroup cleans the other one (mzd_kernels.hip)
     unsigned flip = 0;
     uint32_t wg0 = 0, nwg = 0;
+    uint32_t wg0_3 = 0, nwg3 = 0;   // ... its share when driver 1 runs workgroups of three wavefronts, five to a CU (mzd_decode_kernel_files3)
     uint8_t* small_lit = nullptr;
     size_t small_lit_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -95,6 +96,7 @@ struct Device {
     int hip_id = 0;
     int index = 0;
     uint32_t max_wg = 0, cus = 0;
+    uint32_t max_wg3 = 0;           // workgroup slots of the three-wavefront build of driver 1 (>= max_wg: the scratch arrays are sized for it)
     uint8_t* lit_scratch = nullptr;
     uint4* seq_scratch = nullptr;
     uint4* walk_scratch = nullptr;
@@ -181,12 +183,14 @@ int init_device(Device& d, int hip_id, int index, const InitCfg& cfg) {
     d.max_wg = (uint32_t)(cus * per_cu);
     if (cfg.max_workgroups) d.max_wg = std::max<uint32_t>(4u * kSlots, std::min<uint32_t>(d.max_wg, cfg.max_workgroups)) / kSlots * kSlots;
     d.small_lit_total = std::max<size_t>(16u << 20, cfg.small_scratch_bytes ? cfg.small_scratch_bytes : kSmallLitBytes) / (kSlots * kAlign) * (kSlots * kAlign);
-    HIPCHK(hipMalloc(&d.lit_scratch, (size_t)d.max_wg * kLitStride));
-    HIPCHK(hipMalloc(&d.seq_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
-    HIPCHK(hipMalloc(&d.walk_scratch, (size_t)d.max_wg * kSeqStride * sizeof(uint4)));
+    d.max_wg3 = std::max<uint32_t>(d.max_wg, (uint32_t)(cus * std::max(1, w3_workgroups_per_cu())) / kSlots * kSlots);
+    if (cfg.max_workgroups) d.max_wg3 = d.max_wg; // (a caller that bounds the device memory gets no extra slots)
+    HIPCHK(hipMalloc(&d.lit_scratch, (size_t)d.max_wg3 * kLitStride));
+    HIPCHK(hipMalloc(&d.seq_scratch, (size_t)d.max_wg3 * kSeqStride * sizeof(uint4)));
+    HIPCHK(hipMalloc(&d.walk_scratch, (size_t)d.max_wg3 * kSeqStride * sizeof(uint4)));
     HIPCHK(hipMalloc(&d.small_lit, d.small_lit_total));
     if (cfg.resolve_ahead) HIPCHK(hipMalloc(&d.resolve_map, (size_t)d.max_wg * kResMapStride * sizeof(uint32_t)));
-    const size_t debug_bytes = std::max<size_t>((size_t)d.max_wg * sizeof(DebugSlot), (2048 + 16 * 3072) * sizeof(uint64_t)); // (diagnostic builds of the small-file kernel keep 1 032 stamps there: mzd_debug_small_stamps)
+    const size_t debug_bytes = std::max<size_t>((size_t)d.max_wg3 * sizeof(DebugSlot), (2048 + 16 * 3072) * sizeof(uint64_t)); // (diagnostic builds of the small-file kernel keep 1 032 stamps there: mzd_debug_small_stamps)
     HIPCHK(hipMalloc(&d.debug, debug_bytes));
     HIPCHK(hipMemset(d.debug, 0, debug_bytes));
     HIPCHK(hipMalloc(&d.counters, 2 * (kSlots + 1) * kCounterWords * sizeof(uint32_t)));
@@ -199,6 +203,7 @@ int init_device(Device& d, int hip_id, int index, const InitCfg& cfg) {
         HIPCHK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         l.cnt[0] = d.counters + (size_t)(2 * k) * kCounterWords; l.cnt[1] = l.cnt[0] + kCounterWords; l.counter = l.cnt[0];
         l.wg0 = (uint32_t)k * share; l.nwg = share;
+        l.nwg3 = d.max_wg3 / kSlots; l.wg0_3 = (uint32_t)k * l.nwg3;
         l.small_lit = d.small_lit + (size_t)k * (d.small_lit_total / kSlots); l.small_lit_bytes = d.small_lit_total / kSlots;
         HIPCHK(hipEventCreate(&l.ev0));
         HIPCHK(hipEventCreate(&l.ev1));
@@ -208,7 +213,7 @@ int init_device(Device& d, int hip_id, int index, const InitCfg& cfg) {
     Lane& w = d.whole;
     w.stream = d.lane[0].stream;
     w.cnt[0] = d.counters + (size_t)(2 * kSlots) * kCounterWords; w.cnt[1] = w.cnt[0] + kCounterWords; w.counter = w.cnt[0];
-    w.wg0 = 0; w.nwg = d.max_wg; w.small_lit = d.small_lit; w.small_lit_bytes = d.small_lit_total;
+    w.wg0 = 0; w.nwg = d.max_wg; w.wg0_3 = 0; w.nwg3 = d.max_wg3; w.small_lit = d.small_lit; w.small_lit_bytes = d.small_lit_total;
     HIPCHK(hipEventCreate(&w.ev0));
     HIPCHK(hipEventCreate(&w.ev1));
     return MZD_OK;
@@ -492,6 +497,16 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     // (profiles/r05_big_resolve.txt).
     ka.resolve = !use_tasks || force == 5 || !d.resolve_map ? 0u : ((force == 4 || p.blocks <= 2ull * l.nwg || p.nmulti <= l.nwg / 4) ? 1u : (p.nmulti >= l.nwg * 15 / 32 ? 0u : (p.nmulti >= l.nwg * 5 / 16 ? 3u : 2u)));
     if (const int fr = g_resolve.load(std::memory_order_relaxed); fr && use_tasks && d.resolve_map) ka.resolve = (uint32_t)(fr - 1); // (mzd_debug_host_path 10: 1 in order, 2 every task ahead, 3 only behind a running predecessor, 4 every other task)
+    // Driver 1 with workgroups of THREE wavefronts, five to a CU (mzd_decode_kernel_files3, the MZD_W3 build: the walking, the copying and a
+    // wavefront that plans and, in the planner's waits, hashes): five chains of sequences a CU where four ran, at the copier's 128 registers.
+    // Built and measured in round 6 (tools/pairs_probe.py, profiles/r06_w3_probe.txt): byte-exact, and no faster -- a file takes 35 % longer
+    // beside four others than beside three (4 000 x 128 KiB JSON: 2.85 against 2.64 ms; 8 000: 5.10 against 5.14), so a CU's throughput is
+    // what it was: with four files a CU the SIMDs' VALU pipes are 79 % busy (profiles/r05_pmc_cfg2x8_util.txt) and a fifth file finds no
+    // room there.  Never chosen by the library; mzd_debug_host_path 11 = 3 runs it (the parity suite does, as driver "1w").
+    const int fp = g_pairs.load(std::memory_order_relaxed); // (mzd_debug_host_path 11: 1 four wavefronts a file, 2 two files a workgroup, 3 three wavefronts a file)
+    const uint32_t queued = p.nsmall ? p.nbig + std::min<uint32_t>(p.nsmall, 256u) : njobs;
+    const bool w3 = !use_tasks && fp == 3 && l.nwg3 > l.nwg;
+    const char* const files_kernel = w3 ? "mzd_decode_kernel_files3" : "mzd_decode_kernel_files";
     if (ev0) HIPCHK(hipEventRecord(ev0, s)); // (null: an untimed launch -- mzd_batch_launch_ex)
     uint32_t grid;
     if (p.nsmall) {
@@ -520,7 +535,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
             char small[48];
             if (p.lds_nw > 1 || p.lds_nd > 1) snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d,%d,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg, p.lds_nw, p.lds_nd);
             else snprintf(small, sizeof small, "mzd_lds_kernel<%d,%s,%d>", p.lds_g, p.with_dict ? "true" : "false", p.lds_xg);
-            const char* big = use_tasks ? "mzd_decode_kernel_tasks" : "mzd_decode_kernel_files";
+            const char* big = use_tasks ? "mzd_decode_kernel_tasks" : files_kernel;
             if (solo) d.set_kernels(small);
             else if (p.nbig > p.nsmall) d.set_kernels(big, small);
             else d.set_kernels(small, big); // (the general driver's launch behind it takes what was handed on: usually nothing)
@@ -531,7 +546,7 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
         grid = std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(p.nbig + std::min<uint32_t>(p.nsmall, 256u), l.nwg));
     } else {
         grid = use_tasks ? std::max<uint32_t>(p.big_tasks, std::min<uint32_t>(njobs, l.nwg)) : njobs;
-        if (&l == &d.whole) d.set_kernels(use_tasks ? "mzd_decode_kernel_tasks" : "mzd_decode_kernel_files");
+        if (&l == &d.whole) d.set_kernels(use_tasks ? "mzd_decode_kernel_tasks" : files_kernel);
         if (p.lpt) { ka.job_list = d_lists + njobs; ka.nlist_fixed = p.nbig; } // (largest first; nothing is appended: counter word 4 stays 0)
     }
     grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, l.nwg));
@@ -543,13 +558,13 @@ int enqueue(Device& d, Lane& l, hipStream_t s, DevJob* d_jobs, const Plan& p, co
     // (profiles/r06_pairs_walkstat.txt, r06_pairs_pmc.txt).  Never chosen by the library; mzd_debug_host_path 11 = 2 runs it (the parity
     // suite does, as driver "1p").
     int groups = 1;
-    if (!use_tasks && g_pairs.load(std::memory_order_relaxed) == 2) {
+    if (!use_tasks && fp == 2) {
         groups = 2;
         grid = std::max<uint32_t>(2u, std::min<uint32_t>((grid + 1u) & ~1u, l.nwg & ~1u)); // (whole workgroups: the odd group would lie outside the lane's scratch slots)
     }
-    // (the launch behind the small-file kernel takes what that kernel handed on, and its last workgroup zeroes the counter block of
-    //  the lane's next launch)
+    if (w3) { ka.wg0 = l.wg0_3; grid = std::max<uint32_t>(1u, std::min<uint32_t>(queued, l.nwg3)); }
     if (groups == 2) { launch_decode_pairs(ka, grid, s); if (&l == &d.whole) d.set_kernels("mzd_decode_kernel_pairs"); }
+    else if (w3) launch_decode_w3(ka, grid, s);
     else launch_decode(ka, grid, s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev1, s));
@@ -1096,7 +1111,7 @@ int mzd_debug_host_path(int device, int what, int value) {
     if (what == 9) { g_small_nw.store(value); return MZD_OK; }
     if (what == 13) { g_t2_mode.store(value); return MZD_OK; } // host path experiments: bit 0 one call at a time inside the submission loop, bit 1 retire by polling hipEventQuery
     if (what == 12) { g_small_nd.store(value); return MZD_OK; } // the dictionary kernels' decoding wavefronts around one table image (launches that name ONE dictionary): 0 the library's choice, 1 / 5 / 8
-    if (what == 11) { g_pairs.store(value); return MZD_OK; } // driver 1's workgroups: 0 the library's choice, 1 one file each, 2 two files each (one walking wavefront for both)
+    if (what == 11) { g_pairs.store(value); return MZD_OK; } // driver 1's workgroups: 0 the library's choice, 1 four wavefronts a file, 2 two files a workgroup (one walking wavefront for both), 3 three wavefronts a file, five workgroups a CU
     if (what == 10) { g_resolve.store(value); return MZD_OK; } // (the small-file kernel's wavefronts per workgroup: 0 the library's choice, 1 never a helper wavefront, 2 with the 8 / 4 shape always) // (the general driver's launch behind a launch of small files alone stays: A/B)
     return MZD_E_PARAM;
 }
@@ -1391,7 +1406,7 @@ int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit
     if (!d->job0_counter) return MZD_E_PARAM;
     HIPCHK(hipMemcpy(&slot, d->job0_counter + 1, 4, hipMemcpyDeviceToHost));
     slot &= 0xFFFu; // task << 12 | slot
-    if (slot >= d->max_wg) return MZD_E_PARAM;
+    if (slot >= d->max_wg3) return MZD_E_PARAM;
     DebugSlot ds;
     HIPCHK(hipMemcpy(&ds, d->debug + slot, sizeof(ds), hipMemcpyDeviceToHost));
     if (n_lit) *n_lit = ds.n_lit;
@@ -1416,7 +1431,7 @@ int mzd_debug_stamps(int device, uint64_t* out8) {
     if (!d->job0_counter) return MZD_E_PARAM;
     HIPCHK(hipMemcpy(&slot, d->job0_counter + 1, 4, hipMemcpyDeviceToHost));
     slot &= 0xFFFu; // task << 12 | slot
-    if (slot >= d->max_wg) return MZD_E_PARAM;
+    if (slot >= d->max_wg3) return MZD_E_PARAM;
     DebugSlot ds;
     HIPCHK(hipMemcpy(&ds, d->debug + slot, sizeof(ds), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out8[i] = ds.stamp[i];
@@ -1474,7 +1489,7 @@ int mzd_debug_tfin_all(int device, uint64_t* out, int max_slots) {
     Device* d = dp.get();
     WholeGuard g(*d);
     HIPCHK(hipSetDevice(d->hip_id));
-    int n = std::min<int>((int)d->max_wg, max_slots);
+    int n = std::min<int>((int)d->max_wg3, max_slots);
     std::vector<DebugSlot> all((size_t)n);
     HIPCHK(hipMemcpy(all.data(), d->debug, sizeof(DebugSlot) * (size_t)n, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) for (int k = 0; k < 12; k++) out[(size_t)i * 12 + k] = all[(size_t)i].tfin[k];

@@ -71,6 +71,19 @@ struct BlockArgs {
     const KernelArgs* args;               // the launch's arguments (the roles reach them through the block: launch_args)
 };
 
+#ifndef MZD_PAIRS
+#define MZD_PAIRS 0
+#endif
+// MZD_W3 (round 6, the third compile of this source): driver 1 with workgroups of THREE wavefronts, five to a CU -- the walking, the copying
+// and a FOLLOWING wavefront that plans behind the walker and hashes in the planner's waits (mzd_k_pipeline.h) -- where the launch fills
+// the machine more than once: 15 wavefronts a CU keep the 128 registers the copier needs (20 would leave 96: profiles/r05_wg5_ab.txt), and
+// the image goes on the diet below.
+#ifndef MZD_W3
+#define MZD_W3 0
+#endif
+#if MZD_W3 && !defined(MZD_WGS_PER_CU)
+#define MZD_WGS_PER_CU 5
+#endif
 // Residency: MZD_WGS_PER_CU workgroups share a CU -- 512 / that many registers a lane, and an LDS image of at most 160 KiB / that
 // many, in the 1 280-byte steps LDS is allocated in (tools/micro/lds_granule_micro.hip).  Five: 96 registers, 32 000 bytes.
 #ifndef MZD_WGS_PER_CU
@@ -131,8 +144,10 @@ struct __attribute__((aligned(16))) Shared {
     uint32_t res_nsym, res_sym[kResSymMax]; // ... chunks left out by the build that follows the planner: they hold offsets still symbolic
     uint32_t took_first;         // this workgroup has used its first ticket (take_ticket)
     uint32_t and_word;           // mzd_k_resolve.h: a workgroup-wide AND
+#if MZD_PAIRS
     uint32_t bar;                // grp_sync: arrivals at the group's barriers (workgroups of two groups: s_barrier would join both)
     WalkShare wk;                // the walking wavefronts' rendezvous (mzd_k_walk.h)
+#endif
     uint32_t pre_job, pre_valid; // the job taken ahead (kNoJob: none) and whether c2 holds its parsed first block
     // driver 1: the small fields of the dictionary the workgroup used last (config 5: every file names the same one --
     // reading them from HBM again for each file costs a round trip per dependent load)
@@ -159,9 +174,6 @@ static_assert(sizeof(((Shared*)nullptr)->stage) >= 2064 + 2048 + 64, "the copyin
 // The source is compiled TWICE (Makefile): MZD_PAIRS = 0, the kernels of one group a workgroup -- the image is a file-scope object at LDS address
 // 0, every place in it a compile-time constant, nothing of the above costs anything --, and MZD_PAIRS = 1, driver 1 alone as
 // mzd_decode_kernel_pairs with two groups a workgroup, the images in the dynamic LDS segment.
-#ifndef MZD_PAIRS
-#define MZD_PAIRS 0
-#endif
 #if MZD_PAIRS
 extern __shared__ __attribute__((aligned(16))) uint8_t lds_img[];
 constexpr uint32_t kGroupsMax = 2;
@@ -275,6 +287,7 @@ __device__ __forceinline__ bool spin_ge(const uint32_t* p, uint32_t want, int32_
 // The group's barrier.  One group in the workgroup: the hardware's.  Two: s_barrier would join all eight wavefronts, whose groups work on
 // different files -- the four wavefronts of a group count their arrivals in their image instead (arrival k of barrier b is 4 b + k; everybody
 // leaves when 4 b + 4 are in).  Same memory semantics as __syncthreads: the wavefront's stores are complete before, its loads start after.
+#if MZD_PAIRS
 __device__ __noinline__ void grp_sync_counted() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     uint32_t* const bar = &S.bar;
@@ -290,7 +303,6 @@ __device__ __noinline__ void grp_sync_counted() {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-#if MZD_PAIRS
 __device__ __forceinline__ void grp_sync() { grp_sync_counted(); }
 #else
 __device__ __forceinline__ void grp_sync() { __syncthreads(); }

@@ -114,6 +114,10 @@ __device__ __forceinline__ void copy_short(uint32_t n, LD ld, ST st) { // n <= 6
 constexpr uint32_t kPlanFin = 0x80000000u;
 constexpr int kPlanBlockTooLong = -64; // plan_wave: the block's output passes 128 KiB (internal: becomes Ctl::plan_too_long)
 
+// MZD_W3: the planning wavefront is also the hashing one -- in its waits for the walker it takes the checksum (and the host mirror) as far as
+// the copier's published position allows (mzd_k_pipeline.h: follow_step)
+struct FollowHook { uint64_t* xv; uint64_t* xstripes; uint64_t* mirrored; const uint8_t* frame; uint64_t fstart; uint8_t* dst; uint8_t* dst2; bool hashing; };
+__device__ __noinline__ bool follow_step(const FollowHook& h, int lane);
 struct PlanCtx { // what the planning wavefront needs
     const uint4* walk;       // state-walk records of the block (HBM scratch)
     const uint8_t* seq_sp;   // the block's sequence bitstream
@@ -124,6 +128,7 @@ struct PlanCtx { // what the planning wavefront needs
     uint4* chunk_base;       // [k] = {output, literals} of the block before chunk k (for mzd_k_resolve.h): the walk records' array, whose
                              // entry k the planner has consumed by the time it plans chunk k
     uint32_t seq_len;        // bytes of the sequence bitstream: no field is fetched from outside it
+    struct FollowHook* hook; // MZD_W3: what this wavefront does while it waits for the walker (the checksum, the host mirror), or null
 };
 
 // Offsets in the plan: a plain value, or -- when the block starts before its predecessor has finished, so that
@@ -169,7 +174,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         for (; it < (1u << 24); it++) {
             pg = flag_load_u(&S.c.walk_prog); // (= cx.prog, spelled as the LDS word it is: through the generic pointer it was a flat load)
             if ((pg & ~kWalkFin) >= need || (pg & kWalkFin)) break;
-            __builtin_amdgcn_s_sleep(4);
+            if (!(cx.hook && follow_step(*cx.hook, lane))) __builtin_amdgcn_s_sleep(4);
         }
         if (it == (1u << 24)) { DEVSITE(2); post_err(&S.c.err, MZD_E_DEVICE); } // (a wait that ran out: see spin_ge)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -159,7 +159,7 @@ __device__ __noinline__ void role_walk(BlockRun<TASKS> r) {
 
 // ---- wave 3: (a task: publishes the tables for its successor,) K4b plan: fields, repeat offsets, positions
 template <bool TASKS>
-__device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
+__device__ __noinline__ void role_plan(BlockRun<TASKS> r, FollowHook* hook = nullptr) {
     MZD_IN_LDS(&r.b);
     Ctl& c = S.c;
     const BlockArgs& b = r.b;
@@ -201,7 +201,7 @@ __device__ __noinline__ void role_plan(BlockRun<TASKS> r) {
         int rc = MZD_E_CORRUPT;
         if (spin_ge(&c.tables_ready, 1, &c.err)) {
             // (a task plans before its predecessor has finished: the repeat offsets at its start are unknown unless it opens the frame)
-            PlanCtx px{b.walk, b.src + r.seq_off, &c.walk_prog, r.nlit, (!TASKS || b.frame_first) ? 1u : 0u, {c.rep[0], c.rep[1], c.rep[2]}, b.walk, r.seq_len};
+            PlanCtx px{b.walk, b.src + r.seq_off, &c.walk_prog, r.nlit, (!TASKS || b.frame_first) ? 1u : 0u, {c.rep[0], c.rep[1], c.rep[2]}, b.walk, r.seq_len, hook};
             MZD_SETPRIO(MZD_PRIO_PLAN);
             rc = plan_wave(b.seqs, r.nseq, px, lane);
             MZD_SETPRIO(0);
@@ -281,7 +281,8 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
         for (uint32_t k = (uint32_t)(tid - 64) * 16; k < nlit; k += 128 * 16)
             *reinterpret_cast<uint4*>(b.lit_buf + k) = make_uint4(w, w, w, w); // lit_buf has slack past nlit
     } else if (lit_type >= 2 && !failed && r.get_seq()) { // K2: the copying wavefront decodes one stream and then
-        r.huf_streams(wave == 1 && !r.lit_in_place() && (phase & 2) ? 1u : 4u); // copies behind the literals; wavefront 2 (and idle ones) drain the queue
+        // (MZD_W3: the other literal wavefront plans behind its streams, so the copying one takes two of the four)
+        r.huf_streams(wave == 1 && !r.lit_in_place() && (phase & 2) ? (MZD_W3 ? 2u : 1u) : 4u); // copies behind the literals; wavefront 2 (and idle ones) drain the queue
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) {
@@ -291,10 +292,12 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
     MZD_SETPRIO(0);
     if (wave == 1) TFIN(4);
     }
+#if !MZD_W3
     if (phase == 1) { // a resolving task: these two wavefronts build the block's byte map behind the planner (mzd_k_resolve.h)
         if (r.get_seq() && r.nseq) resolve_build_follow(a.resolve_map + (size_t)(a.wg0 + vblock()) * kResMapStride, b.seqs, b.walk, r.nseq, (uint32_t)(wave - 1), lane);
         return;
     }
+#endif
     if (!(phase & 2)) return;
     if (wave == 1) { // the copying half of K5
         uint64_t opos = b.out0;
@@ -374,6 +377,28 @@ __device__ __noinline__ void role_literals_then_copy_or_hash(BlockRun<TASKS> r, 
     }
 }
 
+// MZD_W3: a piece of the following wavefront's second job, done in the planner's waits: the checksum up to the copier's published position,
+// at most 64 stripes (2 KiB) a call, and the host mirror.  true: something was done.
+__device__ __noinline__ bool follow_step(const FollowHook& h, int lane) {
+    Ctl& c = S.c;
+    if (flag_load_u(&c.exec_done)) return false; // (the rest is the hashing loop's, behind the plan)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint64_t pos = __atomic_load_n(&c.exec_pos, __ATOMIC_RELAXED);
+    bool did = false;
+    if (h.hashing) {
+        uint64_t upto = pos > h.fstart ? (pos - h.fstart) / 32 : 0;
+        const uint64_t xs = *h.xstripes;
+        upto = upto >= xs + 64 ? xs + 64 : xs; // whole groups of 8 stripes, 2 KiB at a time: the walker's next records are looked at in between
+        if (upto > xs) { xxh_advance(*h.xv, *h.xstripes, upto, h.frame, lane); did = true; }
+    }
+    if (h.dst2) {
+        const uint64_t m = *h.mirrored;
+        const uint64_t to = pos >= m + MZD_MIRROR_MIN ? m + ((pos - m) & ~1023ull) : m;
+        if (to > m) { mirror_wave(h.dst, h.dst2, m, to < m + 4096 ? to : m + 4096, lane); *h.mirrored = to < m + 4096 ? to : m + 4096; did = true; }
+    }
+    return did;
+}
+
 // One compressed block.  Returns false when its headers already failed (c.err is set): nothing was started.
 template <bool TASKS>
 __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const BlockArgs& b, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored, int tid, int lane, int wave,
@@ -420,12 +445,26 @@ __device__ __forceinline__ bool compressed_block(const KernelArgs& a, const Bloc
     BlockRun<TASKS> r{b, lane, wave, lit_type, nlit, streams, 0u, seq_len, lit_off, seq_off,
                       lit_type == 0 ? b.src + lit_off : b.lit_buf};
     static_assert(sizeof(BlockRun<TASKS>) <= 64, "passed in registers");
+#if MZD_W3
+    // three wavefronts: the walking one, the copying one, and one that decodes its share of the literals, PLANS behind the walker -- hashing
+    // and mirroring in the planner's waits (follow_step) -- and finishes the checksum behind the copier
+    if (wave == 0) role_walk<TASKS>(r);
+    else if (wave == 1) role_literals_then_copy_or_hash<TASKS>(r, xv, xstripes, mirrored, 3);
+    else {
+        role_literals_then_copy_or_hash<TASKS>(r, xv, xstripes, mirrored, 1);
+        FollowHook hk{&xv, &xstripes, &mirrored, b.dst + c.frame_out0, c.frame_out0, b.dst, b.dst2, b.hashing};
+        role_plan<TASKS>(r, (b.hashing || b.dst2) ? &hk : nullptr);
+        role_literals_then_copy_or_hash<TASKS>(r, xv, xstripes, mirrored, 2);
+    }
+#else
     if (wave == 0) role_walk<TASKS>(r);
     else if (wave == 3) role_plan<TASKS>(r);
     else role_literals_then_copy_or_hash<TASKS>(r, xv, xstripes, mirrored, defer_copy ? 1 : 3);
+#endif
     return true;
 }
 
+#if !MZD_W3
 // The deferred second half (a task that could not be resolved after all): wavefront 1 copies, wavefront 2 hashes / mirrors.
 __device__ __forceinline__ void compressed_block_copy(const KernelArgs& a, const BlockArgs& b, uint64_t& xv, uint64_t& xstripes, uint64_t& mirrored, int tid, int lane, int wave) {
     Ctl& c = S.c;
@@ -434,3 +473,4 @@ __device__ __forceinline__ void compressed_block_copy(const KernelArgs& a, const
                      c.lit_type == 0 ? b.src + c.lit_off : b.lit_buf};
     role_literals_then_copy_or_hash<true>(r, xv, xstripes, mirrored, 2);
 }
+#endif

@@ -448,7 +448,9 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
 #define WSTAT(k, cnt)
 #endif
     WSTATP(10, 1);
+#if MZD_PAIRS
     if (lane == 0) flag_store(&S.wk.active, 1u); // (two groups in a workgroup: this wavefront will come to the meeting point -- walk_run)
+#endif
     int rc_walk = 0;
     while (i < nupd) {
         WSTAT(6, 0);
@@ -501,8 +503,8 @@ __device__ __noinline__ int walk_sequences_wave(const uint8_t* sp, uint32_t sl, 
     }
 #if MZD_PAIRS
     walk_release_partner(lane);
-#endif
     if (lane == 0) flag_store(&S.wk.active, 0u);
+#endif
     if (rc_walk) return rc_walk;
 #if defined(MZD_STAMPS) && defined(MZD_EXP_WALKSTAT)
     if (lane == 0) for (int k_ = 0; k_ < 8; k_++) S.cdiag[k_] = ws_[k_];

@@ -49,7 +49,11 @@
 #define MZD_PRIO_PLAN 1
 #endif
 #ifndef MZD_LB_WAVES
+#if MZD_W3
+#define MZD_LB_WAVES 4 // five workgroups of three wavefronts a CU: 15 wavefronts, at most four a SIMD -- 128 registers
+#else
 #define MZD_LB_WAVES MZD_WGS_PER_CU
+#endif
 #endif
 #ifdef MZD_EXP_NOPRIO // (experiment: no s_setprio instruction at all)
 #define MZD_SETPRIO(x) ((void)0)
@@ -214,7 +218,9 @@ __device__ __noinline__ bool rep_hop(FileState* fs, uint32_t t, bool frame_first
 }
 
 
+#if !MZD_W3
 #include "mzd_k_resolve.h"
+#endif
 #include "mzd_k_pipeline.h"
 
 // The launch's last workgroup to finish zeroes the counter block of the lane's NEXT launch (KernelArgs::counter_next): no
@@ -229,6 +235,8 @@ __device__ __forceinline__ void clean_next_counters(const KernelArgs& a, int tid
 // stays in registers and LDS.
 #if MZD_PAIRS
 #define MZD_FILES_KERNEL mzd_decode_kernel_pairs
+#elif MZD_W3
+#define MZD_FILES_KERNEL mzd_decode_kernel_files3
 #else
 #define MZD_FILES_KERNEL mzd_decode_kernel_files
 #endif
@@ -244,8 +252,10 @@ __global__ __launch_bounds__(kWG * kGroupsMax, MZD_LB_WAVES) void MZD_FILES_KERN
     const int rot_ = grp_count() > 1 ? (int)(grp_index() + 2u * ((blockIdx.x >> MZD_ROT_BIT) & 1u)) : 0;
     const int lane = threadIdx.x & 63, wave = (int)(((threadIdx.x >> 6) + rot_) & 3), tid = wave * 64 + lane;
     // what the groups of a workgroup share must be in place before either of them moves: the barrier counters and the walkers' rendezvous
+#if MZD_PAIRS
     if (tid == 0) { S.bar = 0; S.wk.active = 0; S.wk.state = 0; }
     __syncthreads(); // (the workgroup's only hardware barrier: every wavefront of both groups is still here)
+#endif
     // A group's first ticket is its own index: one past the queue's end has nothing to do -- the launch behind the small-file
     // kernel when that kernel handed nothing on.  Leaving at once keeps most of the kernel's private-segment stores out of HBM (1 200
     // bytes per lane: the roles' register spills, and a copy per lane of the launch's arguments, whose address the roles take): an idle
@@ -421,7 +431,7 @@ __global__ __launch_bounds__(kWG * kGroupsMax, MZD_LB_WAVES) void MZD_FILES_KERN
     clean_next_counters(a, tid);
 }
 
-#if !MZD_PAIRS
+#if !MZD_PAIRS && !MZD_W3
 // ---- driver 2: block tasks (the hand-over helpers are above, in front of the shared block pipeline)
 #ifdef MZD_EXP_DEVSITE // (experiment: the first segment of a task that took more than 50 ms, with its job and task)
 #define DEVSLOW_DECL uint64_t ds_t0_ = wall_clock64()
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(kWG, MZD_LB_WAVES) void mzd_decode_kernel_tasks(Ker
     if (tid < 36) S.ll_base[tid] = LL_BASE[tid];
     if (tid < 53) S.ml_base[tid] = ML_BASE[tid];
     if (tid == 0) S.walk_dummy = lds_base() + kLdsWalkDummy; // {own address, no bits}: what the walker's fourth lane follows
-    if (tid == 0) { S.took_first = 0; S.bar = 0; S.wk.active = 0; S.wk.state = 0; }
+    if (tid == 0) S.took_first = 0;
 
     for (;;) {
         // ---------------- take a task: tickets below njobs are the first blocks of the files, the others the pushed
@@ -920,17 +930,28 @@ void* decode_kernel_ptr(int tasks) { return tasks ? (void*)mzd_decode_kernel_tas
 void devsite_take(uint32_t* out3) { uint32_t z[4] = {0, 0, 0, 0}; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_devsite), 12); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_devsite), z, 16); }
 #endif
 // grid: GROUPS (mzd_k_common.h); groups_per_wg: 1, or 2 for driver 1 (two files a workgroup, one walking wavefront for both)
-#endif // !MZD_PAIRS
+#endif // !MZD_PAIRS && !MZD_W3
 
 #ifdef MZD_EXP_PLANDIAG
 #if MZD_PAIRS
 #define MZD_PLANDIAG_TAKE plandiag_take_pairs
+#elif MZD_W3
+#define MZD_PLANDIAG_TAKE plandiag_take_w3
 #else
 #define MZD_PLANDIAG_TAKE plandiag_take
 #endif
 void MZD_PLANDIAG_TAKE(uint32_t* out16) { uint32_t z[16] = {0}; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_plandiag), 64); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_plandiag), z, 64); }
 #endif
-#if MZD_PAIRS
+#if MZD_W3
+void launch_decode_w3(const KernelArgs& a, uint32_t grid, void* stream) {
+    hipLaunchKernelGGL(mzd_decode_kernel_files3, dim3(grid), dim3(kWG), 0, (hipStream_t)stream, a);
+}
+int w3_workgroups_per_cu() {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)mzd_decode_kernel_files3, kWG, 0) != hipSuccess) return 0;
+    return per_cu > 5 ? 5 : per_cu; // (LDS is allocated in 1 280-byte steps: five images of 32 000 bytes fit a CU, whatever the API says of six)
+}
+#elif MZD_PAIRS
 // grid: GROUPS of four wavefronts (an even number: the host rounds); two a workgroup
 void launch_decode_pairs(const KernelArgs& a, uint32_t grid, void* stream) {
     hipLaunchKernelGGL(mzd_decode_kernel_pairs, dim3((grid + 1) / 2), dim3(2 * kWG), 2 * sizeof(Shared), (hipStream_t)stream, a);

@@ -15,7 +15,7 @@ for n in [int(x) for x in sys.argv[2:]] or [256, 512, 1000, 2000, 4000, 8000]:
     dout = torch.zeros(end + 64, dtype=torch.uint8, device="cuda")
     jobs = mzd.api.make_jobs([dcomp.data_ptr() + int(o) for o in cp.comp_offs], cp.comp_sizes, [dout.data_ptr() + int(o) for o in cp.raw_offs], cp.raw_sizes)
     row = []
-    for way in (1, 2, 1, 2):
+    for way in [int(x) for x in os.environ.get("MZD_WAYS", "1,2,1,2").split(",")]:
         if os.environ.get("MZD_DIAG_EACH") and row: mzd.debug_counters(0)
         mzd.lib().mzd_debug_host_path(0, 11, way)
         best = 1e9
@@ -24,7 +24,7 @@ for n in [int(x) for x in sys.argv[2:]] or [256, 512, 1000, 2000, 4000, 8000]:
             res = mzd.api.decode_batch_device(0, jobs)
             best = min(best, mzd.last_kernel_ms(0))
         ok = all(st == 0 for st, _ in res) and bytes(dout.cpu().numpy()[:end]) == cp.raw[:end].tobytes()
-        row.append("%s %.3f%s" % ("one" if way == 1 else "two", best, "" if ok else " WRONG"))
+        row.append("%s %.3f%s" % ({1: "four-wave", 2: "pairs", 3: "three-wave"}[way], best, "" if ok else " WRONG"))
     mzd.lib().mzd_debug_host_path(0, 11, 0)
     print(kind, n, "files:", "  ".join(row), flush=True)
     mzd.debug_counters(0)  # (experiment builds print what they noted)
