@@ -207,7 +207,7 @@ def test_hand_overs_between_block_tasks_hold_under_repetition_on_a_machine_filli
 @pytest.mark.parametrize("mode", [0, 3, 2, 4, 5, "odd"])
 def test_a_batch_of_corrupted_multi_block_files_holds_under_repetition(mode):
     """Round 4's one real defect as a test: the 512 mutated, truncated and too-small multi-block files of
-    tests/test_gpu_parity.py::test_corrupted_multi_block_files_report_the_oracles_error, decoded 40 times under each
+    tests/test_gpu_parity.py::test_corrupted_multi_block_files_report_the_oracles_error, decoded 100 times under each
     block-task driver.  A walk that ends inexactly leaves a plan made of garbage; the byte map a resolving task builds
     from it reached past the workgroup's map slot into its neighbour's (mzd_k_resolve.h: resolve_build_chunk) -- whose
     chains then did not settle, in ONE of its four wavefronts, which took the other side of a branch around workgroup
@@ -234,7 +234,7 @@ def test_a_batch_of_corrupted_multi_block_files_holds_under_repetition(mode):
         mzd.api.lib().mzd_debug_host_path(0, 10, 4)
     try:
         mzd.decode_batch(comps, caps)  # (buffers, lanes)
-        for rep in range(40):
+        for rep in range(100):
             t0 = time.perf_counter()
             res = mzd.decode_batch(comps, caps)
             wall = time.perf_counter() - t0
