@@ -244,8 +244,9 @@ __global__ __launch_bounds__(kWG * kGroupsMax, MZD_LB_WAVES) void MZD_FILES_KERN
     const KernelArgs& a = launch_args();
     // Inside the group (mzd_k_common.h).  `wave` is the wavefront's ROLE.  The hardware puts a workgroup's wavefronts on the four SIMDs in
     // rotation: with one group a workgroup every SIMD holds one wavefront of each role; with two groups wavefronts w and w + 4 share a SIMD, and
-    // the same role in both would put a CU's four copying wavefronts on ONE SIMD (measured: -22 %).  So a group's roles are rotated by its index,
-    // and by two more in every other workgroup: the four groups of a CU then bring each SIMD one wavefront of each role.
+    // the same role in both would put a CU's four copying wavefronts on ONE SIMD.  So a group's roles are rotated by its index, and by two more in
+    // every other workgroup: the four groups of a CU then bring each SIMD one wavefront of each role.  (Measured with and without: no difference
+    // in this kernel -- its loss is elsewhere, mzd_host.cpp: enqueue -- the rotation is kept as the placement that is right by construction.)
 #ifndef MZD_ROT_BIT
 #define MZD_ROT_BIT 8
 #endif
