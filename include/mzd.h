@@ -175,7 +175,9 @@ int mzd_debug_counters(int device, uint32_t* out8);
  * file's blocks (0: the library's choice, 1 in order, 2 every task resolved ahead, 3 only behind a running predecessor, 4 every other task).
  * what 11: driver 1's workgroups (0 / 1: one file each; 2: two files each, their sequence chains walked by ONE wavefront --
  * mzd_decode_kernel_pairs, built and measured in round 6, never chosen by the library: it is slower).  what 12: decoding wavefronts around ONE
- * dictionary table image in the small-file kernel, for launches whose files all name the same dictionary (0: the library's choice, 1 / 5 / 8). */
+ * dictionary table image in the small-file kernel, for launches whose files all name the same dictionary (0: the library's choice, 1 / 5 / 8).
+ * what 11 = 3: driver 1 with workgroups of three wavefronts, five to a CU (mzd_decode_kernel_files3; measured, never chosen).  what 13: host-path
+ * experiments of profiles/r06_t2_pairs.txt (bit 0: one call at a time inside the submission loop; bit 1: chunks retired by polling hipEventQuery). */
 int mzd_debug_host_path(int device, int what, int value);
 /* Diagnostic builds only (make diag / tfin): per-phase cycle sums of the workgroup that ran job 0; role finish times of
  * every workgroup slot.  In the product build they return zeros. */
