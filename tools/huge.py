@@ -3,6 +3,8 @@ with blocks resolved ahead, 0 the library's own choice).  Kernel time only (PCIe
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fuse_zstd_amd as mzd, corpus
+from fuse_zstd_amd import api as _api
+if os.environ.get('MZD_AB_SO'): _api._SO = os.path.join(os.path.dirname(_api._SO), os.environ['MZD_AB_SO'])  # (another build of the library)
 mzd.init()
 for kind, size, n in (("json", 64 << 20, 1), ("text", 16 << 20, 4), ("xray", 32 << 20, 2)):
     cp = corpus.build_corpus(kind, 31, [size] * n)
