@@ -1415,8 +1415,18 @@ int mzd_debug_last_block(int device, uint8_t* lit, size_t lit_cap, size_t* n_lit
         const void* srcp = ds.lit_is_raw ? (const void*)(uintptr_t)ds.lit_raw_ptr : (const void*)(d->lit_scratch + (size_t)slot * kLitStride);
         HIPCHK(hipMemcpy(lit, srcp, std::min<size_t>(lit_cap, ds.n_lit), hipMemcpyDeviceToHost));
     }
-    if (seq4 && ds.n_seq)
-        HIPCHK(hipMemcpy(seq4, d->seq_scratch + (size_t)slot * kSeqStride, std::min<size_t>(seq_cap, ds.n_seq) * 16, hipMemcpyDeviceToHost));
+    if (seq4 && ds.n_seq) { // the plan: {ll | ml << 16, off} a sequence; a length of 0xFFFF or more in full in the array's second half (mzd_k_execute.h: plan_store)
+        const size_t ns = std::min<size_t>(seq_cap, std::min<size_t>(ds.n_seq, kSeqStride));
+        std::vector<uint32_t> nar(2 * ns), wide(2 * ns);
+        const uint8_t* const base = reinterpret_cast<const uint8_t*>(d->seq_scratch + (size_t)slot * kSeqStride);
+        HIPCHK(hipMemcpy(nar.data(), base, ns * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(wide.data(), base + (size_t)kSeqStride * 8, ns * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ns; i++) {
+            uint32_t ll = nar[2 * i] & 0xFFFFu, ml = nar[2 * i] >> 16;
+            if (ll == 0xFFFFu || ml == 0xFFFFu) { ll = wide[2 * i]; ml = wide[2 * i + 1]; }
+            seq4[4 * i] = ll; seq4[4 * i + 1] = ml; seq4[4 * i + 2] = nar[2 * i + 1]; seq4[4 * i + 3] = 0;
+        }
+    }
     return MZD_OK;
 }
 

@@ -138,10 +138,32 @@ constexpr uint32_t kOffTag = 0x80000000u;
 constexpr int32_t kOffBias = 1 << 28;
 __device__ __forceinline__ uint32_t off_symbolic(uint32_t slot, int32_t delta) { return kOffTag | (slot << 29) | ((uint32_t)(delta + kOffBias) & 0x1FFFFFFFu); }
 
+// The plan in HBM, 8 bytes a sequence (round 6; 16 before: the plan was 150 KB of a 128 KiB JSON block's traffic, written and read):
+// {ll | ml << 16, offset}.  A length of 0xFFFF or more is spelled 0xFFFF and stands in full at the same index of the array's second half
+// ({ll, ml}; one block in thousands holds such a sequence).  A sequence's output offset inside its chunk of 64 is not stored: its readers scan.
+typedef uint2 PlanEnt;
+__device__ __forceinline__ PlanEnt* plan_of(uint4* seqs) { return reinterpret_cast<PlanEnt*>(seqs); }             // (the workgroup's kSeqStride x 16 bytes)
+__device__ __forceinline__ const PlanEnt* plan_of(const uint4* seqs) { return reinterpret_cast<const PlanEnt*>(seqs); }
+__device__ __forceinline__ void plan_store(PlanEnt* plan, uint32_t i, uint32_t ll, uint32_t ml, uint32_t off) {
+    typedef __attribute__((address_space(1))) uint8_t* gptr_;
+    const PlanEnt e = make_uint2((ll < 0xFFFFu ? ll : 0xFFFFu) | (ml < 0xFFFFu ? ml : 0xFFFFu) << 16, off);
+    __builtin_memcpy((gptr_)(uintptr_t)(plan + i), &e, 8);
+    if (ll >= 0xFFFFu || ml >= 0xFFFFu) { const uint2 w = make_uint2(ll, ml); __builtin_memcpy((gptr_)(uintptr_t)(plan + kSeqStride + i), &w, 8); }
+}
+// e: entry i as loaded (zero for a lane without a sequence)
+__device__ __forceinline__ void plan_expand(const PlanEnt* plan, uint32_t i, PlanEnt e, uint32_t& ll, uint32_t& ml, uint32_t& off) {
+    typedef const __attribute__((address_space(1))) uint8_t* gcptr_;
+    ll = e.x & 0xFFFFu; ml = e.x >> 16; off = e.y;
+    const bool big = ll == 0xFFFFu || ml == 0xFFFFu;
+    if (__any(big)) { // (wave-uniform, rare)
+        if (big) { uint2 w; __builtin_memcpy(&w, (gcptr_)(uintptr_t)(plan + kSeqStride + i), 8); ll = w.x; ml = w.y; }
+    }
+}
+
 // K4(b) + the bookkeeping half of K5, by one wavefront, 64 sequences per step (lane = sequence):
 // field conversion from the walk records, repeat offsets, positions, what can be validated without knowing
 // where the block's output starts (the copier checks capacity and offsets).  The result goes to the plan array in
-// HBM: per sequence {ll, ml, off, output offset inside the chunk}.  The block's total repeat-offset transform
+// HBM (plan_store).  The block's total repeat-offset transform
 // (start slots -> end slots) is left in S.c.rep_op.  Returns 0 or an error.
 __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanCtx& cx, int lane) {
     const uint32_t nseq = __builtin_amdgcn_readfirstlane(nseq_in);
@@ -335,10 +357,9 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
         const uint32_t tot = ll + ml;
         const uint32_t incl_t = wave_incl_scan(tot, lane), incl_l = wave_incl_scan(ll, lane);
         const uint32_t chunk_tot = __builtin_amdgcn_readlane(incl_t, 63), chunk_lit = __builtin_amdgcn_readlane(incl_l, 63);
-        const uint32_t ex_t = incl_t - tot; // this sequence's output offset inside the 64-chunk
-        // the plan of this sequence: {ll, ml, offset, output offset inside the chunk} -> HBM (unbounded, so the
-        // planner never waits for the copier, which may still be decoding literals); also what mzd_debug_last_block shows
-        if (valid) { const uint4 pe_ = make_uint4(ll, ml, off, ex_t); __builtin_memcpy((gptr)(uintptr_t)(seqs + i), &pe_, 16); }
+        // the plan of this sequence -> HBM (unbounded, so the planner never waits for the copier, which may still be decoding
+        // literals); also what mzd_debug_last_block shows
+        if (valid) plan_store(plan_of(seqs), i, ll, ml, off);
         if (chunk_lit > cx_nlit - lpos || opos + chunk_tot > kBlockMax) {
             // the literals run out, or the block's output passes 128 KiB, inside this chunk: it is still published -- the copier
             // finds the first offending sequence in stream order -- and it is the plan's last (the mark is set first)
@@ -362,7 +383,7 @@ __device__ __noinline__ int plan_wave(uint4* seqs, uint32_t nseq_in, const PlanC
 }
 
 struct CopyCtx {
-    const uint4* plan;       // the block's plan (HBM): {ll, ml, off, output offset inside the chunk} per sequence
+    const uint4* plan;       // the block's plan (HBM; plan_of, plan_expand)
     uint8_t* dst;            // the file's output buffer
     uint64_t frame_start;    // offset of the current frame's first byte in dst
     const uint8_t* dict;     // dictionary content (logically just before frame_start) or null
@@ -451,13 +472,14 @@ __device__ __noinline__ int exec_verdict(int rc, uint32_t nseq, uint32_t lit_str
 // ... and inside the chunk that cannot be executed (sequences base .. base+63 of the plan, read again here) the earliest
 // offending sequence decides.  room / blk_room: bytes left in the destination / under the block limit at the chunk's
 // start; hist: output of the frame + dictionary bytes before the chunk; rep: the block's starting repeat offsets.
-__device__ __noinline__ int chunk_verdict(const uint4* plan, uint32_t base, int lane, uint64_t room, uint32_t blk_room, uint64_t hist, uint32_t lit_room,
+__device__ __noinline__ int chunk_verdict(const PlanEnt* plan, uint32_t base, int lane, uint64_t room, uint32_t blk_room, uint64_t hist, uint32_t lit_room,
                                           uint32_t rep0, uint32_t rep1, uint32_t rep2, uint32_t nseq, uint32_t lit_streams) {
     const bool valid = base + (uint32_t)lane < nseq;
-    const uint4 pe = valid ? plan[base + (uint32_t)lane] : make_uint4(0, 0, 0, 0);
-    uint32_t off = pe.z;
+    const PlanEnt pe = valid ? plan[base + (uint32_t)lane] : make_uint2(0, 0);
+    uint32_t ll, ml, off;
+    plan_expand(plan, base + (uint32_t)lane, pe, ll, ml, off);
     if (off & kOffTag) off = (uint32_t)sel3((off >> 29) & 3, (int32_t)rep0, (int32_t)rep1, (int32_t)rep2) + (off & 0x1FFFFFFFu) - (uint32_t)kOffBias; // (as in copy_wave)
-    const uint32_t ll = pe.x, ml = pe.y, ex_t = pe.w, incl_t = ex_t + ll + ml;
+    const uint32_t incl_t = wave_incl_scan(ll + ml, lane), ex_t = incl_t - ll - ml;
     // per sequence the reference checks (ZSTD_execSequenceEnd): the destination's end, literals left (lit_room: literals not yet used at
     // the chunk's start), then -- ours -- the block limit, then the offset: "destination too small" when the earliest offending sequence
     // has that wrong, whatever else is wrong with it
@@ -479,7 +501,7 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
     const uint8_t* const lit = (const uint8_t*)(uintptr_t)u64((uint64_t)(uintptr_t)cx.lit);
     const uint64_t cap = u64(cx.cap), frame_start = u64(cx.frame_start);
     const uint32_t dict_len = u32(cx.dict_len), nlit_all = u32(cx.nlit), lit_streams = u32(cx.lit_streams);
-    const uint4* const plan = (const uint4*)(uintptr_t)u64((uint64_t)(uintptr_t)cx.plan);
+    const PlanEnt* const plan = plan_of((const uint4*)(uintptr_t)u64((uint64_t)(uintptr_t)cx.plan));
     const uint8_t* const dict_end = (const uint8_t*)(uintptr_t)u64((uint64_t)(uintptr_t)cx.dict + cx.dict_len); // one past the dictionary content (or null)
     // where an old match's bytes are: in the output, or -- before the frame start -- in the dictionary
     auto match_src = [&](int32_t rel_src, uint64_t run_pos) -> const uint8_t* {
@@ -607,17 +629,17 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
         CSTAMP(7);
     };
 
-    uint4 pe_next = make_uint4(0, 0, 0, 0);
+    PlanEnt pe_next = make_uint2(0, 0);
     if (nseq) {
         if (!wait_plan(1)) return MZD_E_CORRUPT; // the planner failed and posted the error
-        if ((uint32_t)lane < nseq) __builtin_memcpy(&pe_next, (gcptr)(uintptr_t)(plan + lane), 16); // (global, not flat: see plan_wave)
+        if ((uint32_t)lane < nseq) __builtin_memcpy(&pe_next, (gcptr)(uintptr_t)(plan + lane), 8); // (global, not flat: see plan_wave)
     }
     uint32_t chunk = 0;
     uint32_t blk_room = kBlockMax; // bytes left under the block limit
     uint32_t tbase = 0xFFFFFFFFu; // the chunk that cannot be executed (see chunk_verdict)
     for (uint32_t base = 0; base < nseq; base += 64, chunk++) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
-        const uint4 pe = pe_next; // loaded an iteration ago
+        const PlanEnt pe = pe_next; // loaded an iteration ago
         if (lane == 0) flag_store(&S.c.copy_prog, chunk); // (how far this wavefront is: the walker yields when it is far ahead, mzd_k_walk.h)
         CSTAMP(1);
         bool cut = false; // the plan ends with this chunk (the block's output passes 128 KiB in it)
@@ -625,20 +647,25 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             if (wait_plan(chunk + 2)) {
                 CSTAMP(0);
                 const uint32_t j = base + 64 + (uint32_t)lane;
-                pe_next = make_uint4(0, 0, 0, 0);
-                if (j < nseq) __builtin_memcpy(&pe_next, (gcptr)(uintptr_t)(plan + j), 16);
+                pe_next = make_uint2(0, 0);
+                if (j < nseq) __builtin_memcpy(&pe_next, (gcptr)(uintptr_t)(plan + j), 8);
             } else if (flag_load_u(&S.c.plan_too_long) == 1) cut = true;
             else return MZD_E_CORRUPT;
         }
         const bool valid = (uint32_t)lane < cnt;
-        const uint32_t ll = valid ? pe.x : 0, ml = valid ? pe.y : 0, ex_t = pe.w;
-        uint32_t off = pe.z;
+        uint32_t ll, ml, off; // (a lane without a sequence: the entry is zero)
+        plan_expand(plan, base + (uint32_t)lane, pe, ll, ml, off);
         if (off & kOffTag) { // an offset left symbolic by the planner: start slot + delta
             const uint32_t slot = (off >> 29) & 3;
             off = (uint32_t)sel3(slot, (int32_t)cx.rep[0], (int32_t)cx.rep[1], (int32_t)cx.rep[2]) + (off & 0x1FFFFFFFu) - (uint32_t)kOffBias;
-            if (cx.plan_wb && valid) cx.plan_wb[base + (uint32_t)lane].z = off;
+            if (cx.plan_wb && valid) plan_of(cx.plan_wb)[base + (uint32_t)lane].y = off;
         }
-        const uint32_t incl_t = ex_t + ll + ml;
+        // the sequence's output offset inside the chunk, and its literals' place among the chunk's: ONE scan over both sums where every
+        // length of the chunk is short (64 x 127 < 2^16: the lower sum never carries into the upper), else two
+        uint32_t incl_t, incl_l;
+        if (!__any((ll | ml) > 127u)) { const uint32_t P = wave_incl_scan(ll | (ll + ml) << 16, lane); incl_l = P & 0xFFFFu; incl_t = P >> 16; }
+        else { incl_t = wave_incl_scan(ll + ml, lane); incl_l = wave_incl_scan(ll, lane); }
+        const uint32_t ex_t = incl_t - ll - ml;
         const uint32_t chunk_tot = __builtin_amdgcn_readlane(incl_t, cnt - 1);
         if (chunk_tot > cap - opos || chunk_tot > blk_room || cut ||
             __any(valid && (off == 0 || off > (opos + ex_t + ll - frame_start) + dict_len))) { // (beyond the window's history)
@@ -646,7 +673,6 @@ __device__ __noinline__ int copy_wave(uint32_t nseq_in, const CopyCtx& cx, uint6
             break;
         }
         blk_room -= chunk_tot;
-        const uint32_t incl_l = wave_incl_scan(ll, lane);
         const uint32_t my_lit = lpos + (incl_l - ll);
         lpos += __builtin_amdgcn_readlane(incl_l, 63);
         if (__builtin_expect(!wait_lits(lpos), 0)) {

@@ -30,17 +30,18 @@ __device__ __forceinline__ bool resolve_build_chunk(uint32_t* map, const uint4* 
                                                     uint32_t rep0, uint32_t rep1, uint32_t rep2, uint4* plan_wb, int lane, uint32_t& bad, uint32_t& maxprev) {
     const uint32_t i = chunk * 64 + (uint32_t)lane;
     bool valid = i < nseq;
-    const uint4 pe = valid ? plan[i] : make_uint4(0, 0, 1, 0);
-    uint32_t off = pe.z;
+    const PlanEnt pe = valid ? plan_of(plan)[i] : make_uint2(0, 1);
+    uint32_t ll, ml, off;
+    plan_expand(plan_of(plan), i, pe, ll, ml, off);
     if (__any(valid && (off & kOffTag) != 0)) { // start slot + delta (plan_wave)
         if (!rep_known) return false;
         if (off & kOffTag) {
             off = (uint32_t)sel3((off >> 29) & 3, (int32_t)rep0, (int32_t)rep1, (int32_t)rep2) + (off & 0x1FFFFFFFu) - (uint32_t)kOffBias;
-            if (plan_wb && valid) plan_wb[i].z = off;
+            if (plan_wb && valid) plan_of(plan_wb)[i].y = off;
         }
     }
     const uint4 cb = cbase[chunk];
-    const uint32_t ll = pe.x, ml = pe.y, ex_t = pe.w;
+    const uint32_t ex_t = wave_incl_scan(ll + ml, lane) - ll - ml; // (the sequence's output offset inside the chunk)
     const uint32_t p_l = cb.x + ex_t, p_m = p_l + ll;
     const uint32_t li = cb.y + (wave_incl_scan(ll, lane) - ll);
     // A plan made of garbage passes 128 KiB in the chunk the planner marks (Ctl::plan_too_long) -- which is public all the same, and
