@@ -77,11 +77,12 @@ def test_golden_negative(v):
 
 
 @pytest.mark.parametrize("name", ["json_4k", "json_128k", "proxy_text_128k", "proxy_dna_300k", "hand_rle_lits_rle_tables",
-                                  "hand_long_nbseq", "hand_direct_weights_4s", "json_1m"])
+                                  "hand_long_nbseq", "hand_direct_weights_4s", "json_1m", "zeros_128k", "rle_500k"])
 def test_phase_intermediates_match_cpu_twin(name, force_driver):
     """Literal buffer (K2) and sequence triples (K4) of the last compressed block, as the block pipeline
     left them in its scratch, against the oracle's dump of the same block.  (The general drivers are forced; the small-file
-    kernel's intermediates: test_small_file_kernel_intermediates_match_cpu_twin.)"""
+    kernel's intermediates: test_small_file_kernel_intermediates_match_cpu_twin.)  zeros_128k / rle_500k: a match of 131 070 bytes --
+    the plan's 8-byte entries spell a length of 0xFFFF or more in their second array (mzd_k_execute.h: plan_store)."""
     v = next(x for x in VECS if x.name == name)
     force_driver("2" if v.out_len > 131072 else "1")
     rc, out, blocks, dump = oracle.decode(v.comp, cap=v.out_len, want_trace=True, dump=True)
