@@ -94,6 +94,36 @@ def test_phase_intermediates_match_cpu_twin(name, force_driver):
     assert seq == dump["seq"]
 
 
+@pytest.mark.parametrize("driver", ["1", "1w", "1p", "4", "5"])
+def test_sequences_with_lengths_of_64_kib_and_more(driver, force_driver):
+    """The block pipeline's plan holds a sequence in 8 bytes, 16 bits a length; a literal run or a match of 0xFFFF bytes or more stands in full
+    in the plan's second array (mzd_k_execute.h: plan_store / plan_expand).  Frames whose one compressed block has a literal run of 100 000
+    bytes in front of a match of 30 000 (raw literals: noise), the same with the lengths around the escape value, and the two in a
+    multi-block file: bytes against the generator's, the sequence triples against the oracle's dump."""
+    if not oracle.LibZstd.available():
+        pytest.skip("no libzstd to build the frames with")
+    rng = np.random.RandomState(5)
+    noise = rng.randint(0, 256, size=140000, dtype=np.uint8).tobytes()
+    raws = [noise[:100000] + noise[1000:31000] + b"abc" * 10,
+            noise[:65535] + noise[100:65635] + b"xyz",      # ll = 65535 = the escape value itself, ml = 65535
+            noise[:65534] + noise[7:65541] + noise[:9],      # one below: the 16-bit form
+            noise[:120000] + noise[:5000] + noise[60000:126000] + noise[20000:90000] + b"tail"]  # two blocks and more: the block tasks' hand-overs
+    comps = [oracle.LibZstd.compress(r, level=3, checksum=True) for r in raws]
+    force_driver(driver)
+    res = mzd.decode_batch(comps, [len(r) for r in raws])
+    for k, (r, (st, out)) in enumerate(zip(raws, res)):
+        assert st == 0 and out == r, (k, st)
+    for k in (0, 1, 2):
+        rc, out, blocks, dump = oracle.decode(comps[k], cap=len(raws[k]), want_trace=True, dump=True)
+        assert rc == 0 and out == raws[k]
+        st, got = mzd.decode(comps[k], len(raws[k]))
+        assert st == 0 and got == raws[k]
+        lit, seq = mzd.debug_last_block(0)
+        assert seq == dump["seq"], k
+        if k == 0:
+            assert any(ll >= 0xFFFF for ll, _, _ in seq)
+
+
 def test_dst_too_small_and_empty():
     v = next(x for x in VECS if x.name == "json_4k")
     st, _ = mzd.decode(v.comp, 100)
